@@ -1,0 +1,481 @@
+"""CPU oracle for the AutoProg VOLO/DeiT training hot path.
+
+TEST INFRASTRUCTURE ONLY.  This is a from-scratch restatement (closed forms, functional
+style, plain torch CPU fp32/fp64 + numpy) of the arithmetic the reference performs on
+its hot path.  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg
+of ``bench.py`` may import it; the product package ``autoprog_amd`` never does.
+
+Parity pin: every function here is checked against golden vectors emitted by the real
+reference (``tools/gen_golden.py`` imports /root/reference in the build container and
+writes ``tests/golden/*.npz``); see ``tests/test_oracle_golden.py``.  DeiT arithmetic
+lives in un-vendored timm 0.4.5 (``timm.models.vision_transformer``) and is restated
+from its published algorithm: **parity unpinned** for ``vit_forward`` (cross-checked
+against the pinned VOLO blocks instead).
+
+All ``file:line`` citations are relative to the reference tree.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+# --------------------------------------------------------------------------------------
+# integer bookkeeping (bit-exact rows A11, A13)
+# --------------------------------------------------------------------------------------
+
+def make_divisible(v, divisor=8, min_value=None, round_limit=0.9):
+    """prog/progressive.py:34-40."""
+    floor = min_value or divisor
+    out = max(floor, int(v + divisor / 2) // divisor * divisor)
+    if out < round_limit * v:
+        out += divisor
+    return out
+
+
+def new_idx(idx: int, prev_l: int, new_l: int) -> int:
+    """prog/helpers.py:254-258 -- source layer feeding destination layer ``idx``."""
+    reps = new_l // prev_l
+    plain = prev_l - new_l % prev_l          # number of source layers repeated `reps` times
+    first = idx * prev_l // (reps * prev_l)
+    if first < plain:
+        return first
+    return (idx + plain) * prev_l // (reps * prev_l + prev_l)
+
+
+def get_new_layer_idx(prev_l: int, new_l: int) -> List[int]:
+    """prog/helpers.py:261-262 -- destination layers that duplicate their predecessor."""
+    return [i for i in range(new_l) if new_idx(i, prev_l, new_l) == new_idx(i - 1, prev_l, new_l)]
+
+
+def stage_depths(l: int) -> List[int]:
+    """models/submodels.py:19-25 and models/volo.py:602-607: total depth -> per-stage."""
+    if l > 2:
+        l0 = make_divisible(l * 0.23, 2)
+        return [l0, l - l0, 0, 0]
+    return [1, 1, 0, 0]
+
+
+def skip_layer_table(layer_num: int, min_layer_num: int, max_layer_num: int) -> List[List[int]]:
+    """models/volo.py:598-609: per-stage indices of identity (skipped) layers."""
+    cur = [make_divisible(layer_num * 0.23, 2)]
+    cur = [cur[0], layer_num - cur[0], 0, 0]
+    lo0 = make_divisible(min_layer_num * 0.23, 2)
+    lo = [lo0, min_layer_num - lo0, 0, 0]
+    hi0 = make_divisible(max_layer_num * 0.23, 2)
+    hi = [hi0, max_layer_num - hi0, 0, 0]
+    table = []
+    for s in range(4):
+        fresh = get_new_layer_idx(lo[s], hi[s]) if hi[s] > 0 else []
+        extra = cur[s] - lo[s]
+        table.append(fresh if extra == 0 else fresh[:-extra])
+    return table
+
+
+def parse_variant(variant: str) -> Tuple[str, int, int]:
+    """'volo_h12_l18' -> ('volo', 12, 18) (models/submodels.py:16-17, intended behaviour)."""
+    fam, h, l = variant.split("_")
+    return fam, int(h.lstrip("h")), int(l.lstrip("l"))
+
+
+def variant_arch(variant: str) -> dict:
+    """models/submodels.py:9-40 architecture table for 'volo_h{H}_l{L}'."""
+    fam, h, l = parse_variant(variant)
+    assert fam == "volo" and h % 2 == 0
+    return dict(layers=stage_depths(l), embed_dims=[16 * h, 32 * h, 32 * h, 32 * h],
+                num_heads=[h // 2, h, h, h], mlp_ratios=[3, 3, 3, 3],
+                downsamples=[True, False, False, False],
+                outlook_attention=[True, False, False, False], post_layers=["ca", "ca"],
+                stem_hidden_dim=64)
+
+
+VOLO_PRESETS = {  # models/volo.py:697-821
+    "volo_d1": dict(layers=[4, 4, 8, 2], embed_dims=[192, 384, 384, 384], num_heads=[6, 12, 12, 12],
+                    mlp_ratios=[3, 3, 3, 3], stem_hidden_dim=64),
+    "volo_d2": dict(layers=[6, 4, 10, 4], embed_dims=[256, 512, 512, 512], num_heads=[8, 16, 16, 16],
+                    mlp_ratios=[3, 3, 3, 3], stem_hidden_dim=64),
+    "volo_d3": dict(layers=[8, 8, 16, 4], embed_dims=[256, 512, 512, 512], num_heads=[8, 16, 16, 16],
+                    mlp_ratios=[3, 3, 3, 3], stem_hidden_dim=64),
+    "volo_d4": dict(layers=[8, 8, 16, 4], embed_dims=[384, 768, 768, 768], num_heads=[12, 16, 16, 16],
+                    mlp_ratios=[3, 3, 3, 3], stem_hidden_dim=64),
+    "volo_d5": dict(layers=[12, 12, 20, 4], embed_dims=[384, 768, 768, 768], num_heads=[12, 16, 16, 16],
+                    mlp_ratios=[4, 4, 4, 4], stem_hidden_dim=128),
+}
+
+
+def rand_bbox(size: Sequence[int], lam: float, scale: int = 1, rng=np.random):
+    """models/volo.py:319-339.  ``size`` is the [B,H,W,C] token shape; note the first box
+    axis is the H axis although it is named W.  RNG call order: randint(W) then randint(H)."""
+    gw = size[1] // scale
+    gh = size[2] // scale
+    cut = np.sqrt(1.0 - lam)
+    cw = int(gw * cut)
+    ch = int(gh * cut)
+    cx = rng.randint(gw)
+    cy = rng.randint(gh)
+    x1 = int(np.clip(cx - cw // 2, 0, gw))
+    y1 = int(np.clip(cy - ch // 2, 0, gh))
+    x2 = int(np.clip(cx + cw // 2, 0, gw))
+    y2 = int(np.clip(cy + ch // 2, 0, gh))
+    return x1, y1, x2, y2
+
+
+def draw_mix_box(token_shape: Sequence[int], pooling_scale: int = 2, beta: float = 1.0, rng=np.random):
+    """models/volo.py:650-653: lam ~ Beta(beta,beta) then rand_bbox on the pooled grid."""
+    lam = rng.beta(beta, beta)
+    return lam, rand_bbox(token_shape, lam, scale=pooling_scale, rng=rng)
+
+
+def progressive_schedule(num_stages, epochs, r_scale, h_scale, l_scale, aa_scale, dp_scale, re_scale,
+                         resize_scale, aa, drop_path, reprob, scale, r_max=224, h_max=12, l_max=18):
+    """prog/progressive.py:4-31 as a pure function of the flags."""
+    lin = lambda lo: np.linspace(lo, 1.0, num_stages)
+    e = [int(i) for i in np.linspace(0, epochs, num_stages + 1) // 1][:-1]
+    r = [make_divisible(i, 32) for i in lin(r_scale) * r_max]
+    h = [make_divisible(i, 2) for i in lin(h_scale) * h_max]
+    l = [make_divisible(i, 1) for i in lin(l_scale) * l_max]
+    m_max = float(aa.split("-")[1].lstrip("m"))
+    mags = [round(max(0.0, i)) for i in lin(aa_scale) * m_max]
+    aas = ["rand-m{}-mstd0.5-inc1".format(m) if m > 0 else "" for m in mags]
+    dp = [max(0.0, i) for i in lin(dp_scale) * drop_path]
+    re = [max(0.0, i) for i in lin(re_scale) * reprob]
+    rs = [[max(0.0, a), max(0.0, b)] for a, b in zip(lin(resize_scale[0]) * scale[0], lin(resize_scale[1]) * scale[1])]
+    return e, r, h, l, aas, dp, re, rs
+
+
+# --------------------------------------------------------------------------------------
+# floating-point building blocks
+# --------------------------------------------------------------------------------------
+
+def layernorm(x, w, b, eps=1e-5):
+    """nn.LayerNorm over the last dim: biased variance, affine (row N0)."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
+
+
+def linear(x, w, b=None):
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def gelu(x):
+    """exact erf GELU (nn.GELU default), models/volo.py:157."""
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def mlp(x, p: Params, pre: str):
+    """models/volo.py:161-167."""
+    return linear(gelu(linear(x, p[pre + "fc1.weight"], p[pre + "fc1.bias"])),
+                  p[pre + "fc2.weight"], p[pre + "fc2.bias"])
+
+
+def avgpool_ceil(x, s: int):
+    """AvgPool2d(s, s, ceil_mode=True) on [B,H,W,C]: edge windows are clipped and divided
+    by the clipped element count (models/volo.py:75,87)."""
+    B, H, W, C = x.shape
+    h, w = -(-H // s), -(-W // s)
+    xp = x.new_zeros(B, h * s, w * s, C)
+    xp[:, :H, :W] = x
+    ones = x.new_zeros(1, h * s, w * s, 1)
+    ones[:, :H, :W] = 1
+    tot = xp.reshape(B, h, s, w, s, C).sum((2, 4))
+    cnt = ones.reshape(1, h, s, w, s, 1).sum((2, 4))
+    return tot / cnt
+
+
+def outlook_core(v, logits, heads: int, K: int = 3, P: int = 1, S: int = 2):
+    """Closed form of unfold -> softmax(attn) @ v -> fold (models/volo.py:83-98).
+
+    v      [B,H,W,C]            values (after the v projection)
+    logits [B,h,w,heads*K^4]    attn projection of the pooled tokens, channel =
+                                head*K^4 + p*K^2 + q  (models/volo.py:88-90)
+    returns Y [B,H,W,C] = fold of per-window outputs (before proj).
+    """
+    B, H, W, C = v.shape
+    hd = C // heads
+    h, w = -(-H // S), -(-W // S)
+    KK = K * K
+    A = logits.reshape(B, h, w, heads, KK, KK) * (hd ** -0.5)
+    Pm = torch.softmax(A, dim=-1)
+    Hp, Wp = max(H + 2 * P, S * (h - 1) + K), max(W + 2 * P, S * (w - 1) + K)
+    vp = v.new_zeros(B, Hp, Wp, heads, hd)
+    vp[:, P:P + H, P:P + W] = v.reshape(B, H, W, heads, hd)
+    # Vn[b,i,j,q] = vp[b, S*i + q//K, S*j + q%K]
+    Vn = torch.stack([vp[:, (q // K):(q // K) + S * h:S, (q % K):(q % K) + S * w:S] for q in range(KK)], dim=3)
+    # O[b,i,j,p,head,:] = sum_q Pm[b,i,j,head,p,q] * Vn[b,i,j,q,head,:]
+    O = torch.einsum("bijhpq,bijqhd->bijphd", Pm, Vn)
+    yp = v.new_zeros(B, Hp, Wp, heads, hd)
+    for p in range(KK):
+        yp[:, (p // K):(p // K) + S * h:S, (p % K):(p % K) + S * w:S] += O[:, :, :, p]
+    return yp[:, P:P + H, P:P + W].reshape(B, H, W, C)
+
+
+def outlook_attention(x, p: Params, pre: str, heads: int, K=3, P=1, S=2):
+    """OutlookAttention.forward, models/volo.py:77-103 (v has no bias: qkv_bias=False)."""
+    v = linear(x, p[pre + "v.weight"], p.get(pre + "v.bias"))
+    logits = linear(avgpool_ceil(x, S), p[pre + "attn.weight"], p[pre + "attn.bias"])
+    y = outlook_core(v, logits, heads, K, P, S)
+    return linear(y, p[pre + "proj.weight"], p[pre + "proj.bias"])
+
+
+def mhsa_core(qkv, heads: int):
+    """softmax(q k^T * hd^-0.5) v on packed qkv [B,N,3C], channel = which*C+head*hd+d
+    (models/volo.py:188-197).  Returns [B,N,C]."""
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    hd = C // heads
+    q, k, v = qkv.reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    att = torch.softmax((q @ k.transpose(-1, -2)) * (hd ** -0.5), dim=-1)
+    return (att @ v).transpose(1, 2).reshape(B, N, C)
+
+
+def attention(x, p: Params, pre: str, heads: int):
+    """Attention.forward, models/volo.py:185-201, on [B,N,C] tokens."""
+    qkv = linear(x, p[pre + "qkv.weight"], p.get(pre + "qkv.bias"))
+    return linear(mhsa_core(qkv, heads), p[pre + "proj.weight"], p[pre + "proj.bias"])
+
+
+def class_attention(x, p: Params, pre: str, heads: int):
+    """ClassAttention.forward, models/volo.py:261-277: one query (token 0), N keys; the
+    scale multiplies q before the product."""
+    B, N, C = x.shape
+    hd = C // heads
+    kv = linear(x, p[pre + "kv.weight"], p.get(pre + "kv.bias")).reshape(B, N, 2, heads, hd)
+    k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)          # [B,heads,N,hd]
+    q = linear(x[:, :1], p[pre + "q.weight"], p.get(pre + "q.bias")).reshape(B, heads, 1, hd)
+    att = torch.softmax((q * hd ** -0.5) @ k.transpose(-1, -2), dim=-1)
+    out = (att @ v).transpose(1, 2).reshape(B, 1, C)
+    return linear(out, p[pre + "proj.weight"], p[pre + "proj.bias"])
+
+
+def drop_path_scale(mask: Optional[torch.Tensor], keep: float, y):
+    """timm DropPath: y / keep * mask_b.  ``mask`` None => identity."""
+    if mask is None:
+        return y
+    return y / keep * mask.reshape(-1, *([1] * (y.dim() - 1))).to(y.dtype)
+
+
+def outlooker(x, p: Params, pre: str, heads: int):
+    """Outlooker.forward, models/volo.py:140-144 (drop_path is always 0 here)."""
+    x = x + outlook_attention(layernorm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"]), p, pre + "attn.", heads)
+    return x + mlp(layernorm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"]), p, pre + "mlp.")
+
+
+def transformer(x, p: Params, pre: str, heads: int, dp_masks=None, keep: float = 1.0):
+    """Transformer.forward, models/volo.py:230-234, x [B,H,W,C]; dp_masks = (mask1, mask2)."""
+    B, H, W, C = x.shape
+    m1, m2 = dp_masks if dp_masks is not None else (None, None)
+    a = attention(layernorm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"]).reshape(B, H * W, C), p, pre + "attn.", heads)
+    x = x + drop_path_scale(m1, keep, a.reshape(B, H, W, C))
+    return x + drop_path_scale(m2, keep, mlp(layernorm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"]), p, pre + "mlp."))
+
+
+def class_block(x, p: Params, pre: str, heads: int):
+    """ClassBlock.forward, models/volo.py:304-308: only token 0 is updated."""
+    cls = x[:, :1] + class_attention(layernorm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"]), p, pre + "attn.", heads)
+    cls = cls + mlp(layernorm(cls, p[pre + "norm2.weight"], p[pre + "norm2.bias"]), p, pre + "mlp.")
+    return torch.cat([cls, x[:, 1:]], dim=1)
+
+
+def batchnorm_train(x, w, b, eps=1e-5):
+    """BatchNorm2d in training mode (batch statistics, biased variance)."""
+    mu = x.mean((0, 2, 3), keepdim=True)
+    var = ((x - mu) ** 2).mean((0, 2, 3), keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w.reshape(1, -1, 1, 1) + b.reshape(1, -1, 1, 1)
+
+
+def batchnorm_eval(x, w, b, rm, rv, eps=1e-5):
+    sh = (1, -1, 1, 1)
+    return (x - rm.reshape(sh)) * torch.rsqrt(rv.reshape(sh) + eps) * w.reshape(sh) + b.reshape(sh)
+
+
+def patch_embed(x, p: Params, train: bool, patch_size: int = 8, pre: str = "patch_embed."):
+    """PatchEmbed.forward, models/volo.py:376-380: conv7x7 s2 -> BN -> ReLU -> 2x(conv3x3 ->
+    BN -> ReLU) -> conv(patch/2) stride patch/2 with bias.  Returns tokens [B,H,W,C]."""
+    strides = [(2, 3), (1, 1), (1, 1)]
+    for i, (s, pad) in zip((0, 3, 6), strides):
+        x = F.conv2d(x, p[pre + "conv.%d.weight" % i], None, stride=s, padding=pad)
+        bn = pre + "conv.%d." % (i + 1)
+        if train:
+            x = batchnorm_train(x, p[bn + "weight"], p[bn + "bias"])
+        else:
+            x = batchnorm_eval(x, p[bn + "weight"], p[bn + "bias"], p[bn + "running_mean"], p[bn + "running_var"])
+        x = torch.relu(x)
+    k = patch_size // 2
+    x = F.conv2d(x, p[pre + "proj.weight"], p[pre + "proj.bias"], stride=k)
+    return x.permute(0, 2, 3, 1)
+
+
+def downsample(x, p: Params, pre: str, k: int = 2):
+    """Downsample.forward, models/volo.py:392-396 == patch-gather GEMM on NHWC tokens."""
+    B, H, W, C = x.shape
+    w = p[pre + "proj.weight"]                       # [Cout, Cin, k, k]
+    patches = x.reshape(B, H // k, k, W // k, k, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // k, W // k, k * k * C)
+    wmat = w.permute(0, 2, 3, 1).reshape(w.shape[0], k * k * C)   # (ky,kx,cin) order
+    return patches @ wmat.t() + p[pre + "proj.bias"]
+
+
+def interpolate_pos_encoding(pos, h0: int, w0: int):
+    """VOLO.interpolate_pos_encoding, models/volo.py:580-596 (bicubic, scale_factor form)."""
+    h, w = pos.shape[1], pos.shape[2]
+    if h == h0 and w == w0:
+        return pos
+    out = F.interpolate(pos.permute(0, 3, 1, 2), scale_factor=((h0 + 0.1) / h, (w0 + 0.1) / w), mode="bicubic")
+    assert out.shape[-2] == h0 and out.shape[-1] == w0
+    return out.permute(0, 2, 3, 1)
+
+
+def mix_token_swap(x, box, scale: int):
+    """models/volo.py:654-658 / 685-689: region [x1*s:x2*s, y1*s:y2*s] (first index = H axis)
+    is replaced by the batch-flipped tensor's region."""
+    x1, y1, x2, y2 = [scale * int(v) for v in box]
+    out = x.clone()
+    out[:, x1:x2, y1:y2] = x.flip(0)[:, x1:x2, y1:y2]
+    return out
+
+
+def volo_forward(p: Params, img, layers, embed_dims, num_heads, train: bool, mix=None,
+                 skip: Optional[List[List[int]]] = None, dp_masks: Optional[dict] = None,
+                 drop_path_rate: float = 0.0, patch_size: int = 8, pooling_scale: int = 2, **_):
+    """VOLO.forward, models/volo.py:644-694, for the model_variant/volo_d* families
+    (outlook stage -> downsample -> transformer stages -> 2 class blocks -> heads).
+
+    mix      None or (lam, (bbx1,bby1,bbx2,bby2)) used when ``train`` (mix-token).
+    skip     per-stage identity-layer indices (set_sample_config), default none.
+    dp_masks {(stage, idx): (mask1, mask2)} per-sample keep masks for DropPath; the keep
+             probability follows models/volo.py:428-437.
+    Returns (x_cls, x_aux, box) in train mode, fused logits in eval mode.
+    """
+    x = patch_embed(img, p, train, patch_size)
+    box = (0, 0, 0, 0)
+    if train and mix is not None:
+        box = tuple(int(v) for v in mix[1])
+        x = mix_token_swap(x, box, pooling_scale)
+    skip = skip or [[], [], [], []]
+    total = sum(layers)
+    net_idx = 0
+    for s, depth in enumerate(layers):
+        if net_idx == 2:    # pos embed is added before the first transformer stage (models/volo.py:627)
+            x = x + interpolate_pos_encoding(p["pos_embed"], x.shape[1], x.shape[2])
+        for i in range(depth):
+            if i in skip[s]:
+                continue
+            pre = "network.%d.%d." % (net_idx, i)
+            if s == 0:
+                x = outlooker(x, p, pre, num_heads[0])
+            else:
+                rate = drop_path_rate * (i + sum(layers[:s])) / (total - 1) if total > 1 else 0.0
+                masks = dp_masks.get((s, i)) if (dp_masks and train and rate > 0) else None
+                x = transformer(x, p, pre, num_heads[s], masks, 1.0 - rate)
+        net_idx += 1
+        if s == 0:
+            x = downsample(x, p, "network.%d." % net_idx)
+            net_idx += 1
+    B, H, W, C = x.shape
+    x = x.reshape(B, H * W, C)
+    x = torch.cat([p["cls_token"].expand(B, -1, -1), x], dim=1)
+    for j in range(2):
+        x = class_block(x, p, "post_network.%d." % j, num_heads[-1])
+    x = layernorm(x, p["norm.weight"], p["norm.bias"])
+    x_cls = linear(x[:, 0], p["head.weight"], p["head.bias"])
+    x_aux = linear(x[:, 1:], p["aux_head.weight"], p["aux_head.bias"])
+    if not train:
+        return x_cls + 0.5 * x_aux.max(1)[0]
+    if mix is not None:
+        nc = x_aux.shape[-1]
+        x_aux = mix_token_swap(x_aux.reshape(B, H, W, nc), box, 1).reshape(B, H * W, nc)
+    return x_cls, x_aux, box
+
+
+# --------------------------------------------------------------------------------------
+# losses (rows L1-L4), loss/cross_entropy.py
+# --------------------------------------------------------------------------------------
+
+def soft_target_ce(x, t):
+    """loss/cross_entropy.py:30-36: mean_i( -sum_c t_ic * log_softmax(x_i)_c ); the target is
+    tiled when x has more rows."""
+    if x.shape[0] != t.shape[0]:
+        t = t.repeat(x.shape[0] // t.shape[0], 1)
+    lse = torch.logsumexp(x, dim=-1, keepdim=True)
+    return (-(t * (x - lse)).sum(-1)).mean()
+
+
+def _token_label_targets(aux_shape, target):
+    B, N, C = aux_shape
+    if target.dim() == 2:
+        return target, target.repeat(1, N).reshape(B * N, C), None
+    t_aux = target[:, :, 2:].transpose(1, 2).reshape(-1, C)
+    return target[:, :, 1], t_aux, target[:, :, 0]
+
+
+def token_label_ce(outputs, target, dense_weight=1.0, cls_weight=1.0):
+    """TokenLabelCrossEntropy.forward, loss/cross_entropy.py:136-156."""
+    out, aux, (x1, y1, x2, y2) = outputs
+    B, N, C = aux.shape
+    t_cls, t_aux, _ = _token_label_targets(aux.shape, target)
+    lam = 1 - ((x2 - x1) * (y2 - y1) / N)
+    if lam < 1:
+        t_cls = lam * t_cls + (1 - lam) * t_cls.flip(0)
+    return cls_weight * soft_target_ce(out, t_cls) + dense_weight * soft_target_ce(aux.reshape(-1, C), t_aux)
+
+
+def token_label_gt_ce(outputs, target, dense_weight=1.0, cls_weight=1.0):
+    """TokenLabelGTCrossEntropy.forward, loss/cross_entropy.py:62-89."""
+    out, aux, (x1, y1, x2, y2) = outputs
+    B, N, C = aux.shape
+    t_cls, t_aux, gt = _token_label_targets(aux.shape, target)
+    if gt is not None:
+        same = (gt.max(-1)[1] == t_cls.max(-1)[1])
+        ratio = (0.9 - 0.4 * same.to(t_cls.dtype)).unsqueeze(-1)
+        t_cls = t_cls * ratio + gt * (1 - ratio)
+    lam = 1 - ((x2 - x1) * (y2 - y1) / N)
+    if lam < 1:
+        t_cls = lam * t_cls + (1 - lam) * t_cls.flip(0)
+    return cls_weight * soft_target_ce(out, t_cls) + dense_weight * soft_target_ce(aux.reshape(-1, C), t_aux)
+
+
+def token_label_soft_target_ce(x, target):
+    """TokenLabelSoftTargetCrossEntropy.forward, loss/cross_entropy.py:101-109."""
+    if x.shape[0] != target.shape[0]:
+        target = target.repeat(x.shape[0] // target.shape[0], 1)
+    if target.dim() == 3 and target.shape[-1] == 2:
+        target = target[:, :, 1]
+    return soft_target_ce(x, target)
+
+
+# --------------------------------------------------------------------------------------
+# DeiT / timm VisionTransformer restatement (parity unpinned, see module docstring)
+# --------------------------------------------------------------------------------------
+
+def vit_block(x, p: Params, pre: str, heads: int, eps=1e-6, dp_masks=None, keep=1.0):
+    m1, m2 = dp_masks if dp_masks is not None else (None, None)
+    x = x + drop_path_scale(m1, keep, attention(layernorm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps), p, pre + "attn.", heads))
+    return x + drop_path_scale(m2, keep, mlp(layernorm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"], eps), p, pre + "mlp."))
+
+
+def vit_forward(p: Params, img, depth: int, heads: int, patch: int = 16, distilled: bool = False,
+                train: bool = True, skip: Sequence[int] = ()):
+    """timm 0.4.5 VisionTransformer.forward (+ DistilledVisionTransformer, models/deit.py:32-59)."""
+    w = p["patch_embed.proj.weight"]
+    x = F.conv2d(img, w, p["patch_embed.proj.bias"], stride=patch).flatten(2).transpose(1, 2)
+    B = x.shape[0]
+    toks = [p["cls_token"].expand(B, -1, -1)]
+    if distilled:
+        toks.append(p["dist_token"].expand(B, -1, -1))
+    x = torch.cat(toks + [x], dim=1) + p["pos_embed"]
+    for i in range(depth):
+        if i in skip:
+            continue
+        x = vit_block(x, p, "blocks.%d." % i, heads)
+    x = layernorm(x, p["norm.weight"], p["norm.bias"], 1e-6)
+    y = linear(x[:, 0], p["head.weight"], p["head.bias"])
+    if not distilled:
+        return y
+    yd = linear(x[:, 1], p["head_dist.weight"], p["head_dist.bias"])
+    return (y, yd) if train else (y + yd) / 2

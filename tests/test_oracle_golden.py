@@ -1,0 +1,211 @@
+"""Pin the CPU oracle (oracle/ref_cpu.py) against golden vectors produced by the real
+reference (tools/gen_golden.py).  Tolerances: integer rows exact; fp32 rows <= 1e-5 rel
+(SURVEY.md section 8(c) row O5)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from tests._golden import load, sub, tensors, rel_err, max_err
+
+TOL = 1e-5
+
+
+def _params(d, prefix, dtype=torch.float64, grad=True):
+    out = {}
+    for k, v in sub(d, prefix + ".w").items():
+        t = torch.from_numpy(v)
+        if t.dtype.is_floating_point:
+            t = t.to(dtype)
+            if grad:
+                t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+# ------------------------------------------------------------------ integer rows (bit exact)
+def test_make_divisible_table():
+    g = load("int_tables")
+    got = np.array([[R.make_divisible(float(v), int(d)) for d in g["md_div"]] for v in g["md_v"]])
+    assert np.array_equal(got, g["md_out"])
+
+
+def test_new_idx_tables():
+    g = load("int_tables")
+    for (prev, new), row, fresh in zip(g["ni_pairs"], g["ni_map"], g["ni_fresh"]):
+        prev, new = int(prev), int(new)
+        assert [R.new_idx(i, prev, new) for i in range(new)] == list(row[:new])
+        assert R.get_new_layer_idx(prev, new) == [int(v) for v in fresh if v >= 0]
+
+
+def test_survey_pinned_index_values():
+    assert R.get_new_layer_idx(7, 14) == [1, 3, 5, 7, 9, 11, 13]
+    assert R.get_new_layer_idx(2, 4) == [1, 3]
+    assert R.get_new_layer_idx(8, 14) == [3, 5, 7, 9, 11, 13]
+    assert R.get_new_layer_idx(11, 14) == [9, 11, 13]
+    assert [R.stage_depths(l) for l in (9, 12, 15, 18)] == [[2, 7, 0, 0], [4, 8, 0, 0], [4, 11, 0, 0], [4, 14, 0, 0]]
+
+
+def test_skip_masks():
+    g = load("int_tables")
+    for (l, lmin, lmax, d0, d1), mask in zip(g["ss_cfg"], g["ss_mask"]):
+        table = R.skip_layer_table(int(l), int(lmin), int(lmax))
+        flags = [int(i in table[0]) for i in range(d0)] + [int(i in table[1]) for i in range(d1)]
+        assert flags == [int(v) for v in mask if v >= 0], (l, lmin, lmax)
+
+
+def test_stage_depths():
+    g = load("int_tables")
+    for l, l0 in zip(g["depth_l"], g["depth_l0"]):
+        assert R.make_divisible(int(l) * 0.23, 2) == int(l0)
+
+
+def test_rand_bbox_sequences():
+    g = load("int_tables")
+    for (seed, grid), row in zip(g["bb_seed"], g["bb_out"]):
+        rng = np.random.RandomState(int(seed))
+        lam, box = R.draw_mix_box((4, int(grid), int(grid), 8), 2, 1.0, rng)
+        assert lam == row[0]
+        assert list(box) == [int(v) for v in row[1:]]
+
+
+@pytest.mark.parametrize("tag,kw", [("script", dict(aa_scale=0.5, dp_scale=0.0, re_scale=0.0, epochs=100)), ("default", {}),
+                                    ("s3", dict(num_stages=3, epochs=90, r_scale=0.6, l_scale=0.4))])
+def test_progressive_schedule(tag, kw):
+    g = load("int_tables")
+    args = dict(num_stages=4, epochs=300, r_scale=0.5, h_scale=1.0, l_scale=0.5, aa_scale=0.0, dp_scale=-0.5, re_scale=-0.5,
+                resize_scale=[1.0, 1.0], aa="rand-m9-mstd0.5-inc1", drop_path=0.1, reprob=0.25, scale=[0.08, 1.0])
+    args.update(kw)
+    e, r, h, l, aa, dp, re, rs = R.progressive_schedule(**args)
+    mags = [int(s.split("-")[1].lstrip("m")) if s else 0 for s in aa]
+    for nm, val in zip(("e", "r", "h", "l", "aa"), (e, r, h, l, mags)):
+        assert list(val) == [int(v) for v in g["ps_%s_%s" % (tag, nm)]], nm
+    for nm, val in zip(("dp", "re", "rs"), (dp, re, rs)):
+        assert np.array_equal(np.array(val), g["ps_%s_%s" % (tag, nm)]), nm
+    if tag == "script":
+        assert r == [128, 160, 192, 224] and l == [9, 12, 15, 18] and e == [0, 25, 50, 75]
+
+
+# ------------------------------------------------------------------ fp rows
+def _check_module(d, tag, fn, wnames=None):
+    p = _params(d, tag)
+    x = torch.from_numpy(d[tag + ".x"]).double().requires_grad_(True)
+    y = fn(x, p)
+    assert rel_err(y, d[tag + ".y"]) < TOL, tag
+    y.backward(torch.from_numpy(d[tag + ".dy"]).double())
+    assert rel_err(x.grad, d[tag + ".dx"]) < TOL, tag
+    for k, gv in sub(d, tag + ".g").items():
+        assert rel_err(p[k].grad, gv) < TOL, (tag, k)
+
+
+@pytest.mark.parametrize("tag", ["even8", "odd7", "rect6x10", "odd5x9", "even16"])
+def test_outlook_attention(tag):
+    d = load("outlook_attn")
+    heads = int(d[tag + ".heads"])
+    _check_module(d, tag, lambda x, p: R.outlook_attention(x, p, "", heads))
+
+
+def test_blocks():
+    d = load("blocks")
+    H = 2
+    _check_module(d, "mlp", lambda x, p: R.mlp(x, p, ""))
+    _check_module(d, "attention", lambda x, p: R.attention(x.reshape(x.shape[0], -1, x.shape[-1]), p, "", H).reshape(x.shape))
+    _check_module(d, "attention_n25", lambda x, p: R.attention(x.reshape(x.shape[0], -1, x.shape[-1]), p, "", H).reshape(x.shape))
+    _check_module(d, "class_attention", lambda x, p: R.class_attention(x, p, "", H))
+    _check_module(d, "class_block", lambda x, p: R.class_block(x, p, "", H))
+    _check_module(d, "outlooker", lambda x, p: R.outlooker(x, p, "", H))
+    _check_module(d, "transformer", lambda x, p: R.transformer(x, p, "", H))
+    _check_module(d, "downsample", lambda x, p: R.downsample(x, p, ""))
+    _check_module(d, "layernorm_1e-05", lambda x, p: R.layernorm(x, p["weight"], p["bias"], 1e-5))
+    _check_module(d, "layernorm_1e-06", lambda x, p: R.layernorm(x, p["weight"], p["bias"], 1e-6))
+
+
+def test_stem_train_and_eval():
+    d = load("stem")
+    p = _params(d, "train")
+    x = torch.from_numpy(d["train.x"]).double()
+    y = R.patch_embed(x, p, train=True, patch_size=8, pre="")
+    assert rel_err(y.permute(0, 3, 1, 2), d["train.y"]) < TOL
+    y.backward(torch.from_numpy(d["train.dy"]).double().permute(0, 2, 3, 1))
+    for k, gv in sub(d, "train.g").items():
+        assert rel_err(p[k].grad, gv) < 5e-5, k
+    ye = R.patch_embed(x, {k: v.detach() for k, v in p.items()}, train=False, patch_size=8, pre="")
+    assert rel_err(ye.permute(0, 3, 1, 2), d["eval.y"]) < TOL
+
+
+def test_pos_interp():
+    d = load("pos_interp")
+    pos = torch.from_numpy(d["pos"])
+    for g in (8, 10, 12, 14, 16, 7):
+        assert max_err(R.interpolate_pos_encoding(pos, g, g), d["interp_%d" % g]) < 1e-6
+    pos4 = torch.from_numpy(d["pos4"])
+    for g in (2, 3, 4, 6):
+        assert max_err(R.interpolate_pos_encoding(pos4, g, g), d["interp4_%d" % g]) < 1e-6
+
+
+@pytest.mark.parametrize("tag,variant", [("h2_l3", "volo_h2_l3"), ("h2_l6", "volo_h2_l6")])
+def test_volo_full_train_eval(tag, variant):
+    d = load("volo_full")
+    arch = R.variant_arch(variant)
+    p = _params(d, tag)
+    x = torch.from_numpy(d[tag + ".x"]).double()
+    rng = np.random.RandomState(int(d[tag + ".np_seed"]))
+    g1 = x.shape[-1] // 8
+    lam, box = R.draw_mix_box((x.shape[0], g1, g1, arch["embed_dims"][0]), 2, 1.0, rng)
+    assert lam == float(d[tag + ".lam"]) and list(box) == [int(v) for v in d[tag + ".bbox"]]
+    # the fixture's state dict was captured AFTER the train forward: running stats are not inputs of train mode
+    x_cls, x_aux, bb = R.volo_forward(p, x, train=True, mix=(lam, box), **arch)
+    assert rel_err(x_cls, d[tag + ".x_cls"]) < TOL and rel_err(x_aux, d[tag + ".x_aux"]) < TOL
+    loss = R.token_label_ce((x_cls, x_aux, bb), torch.from_numpy(d[tag + ".target"]).double(), 0.5, 1.0)
+    assert abs(float(loss) - float(d[tag + ".loss"])) < 1e-6
+    loss.backward()
+    for k, gv in sub(d, tag + ".g").items():
+        assert rel_err(p[k].grad, gv) < 1e-4, k
+    ye = R.volo_forward({k: v.detach() for k, v in p.items()}, x, train=False, **arch)
+    assert rel_err(ye, d[tag + ".eval_y"]) < TOL
+
+
+def test_supernet_subconfigs():
+    d = load("volo_full")
+    arch = R.variant_arch("volo_h2_l6")
+    p = _params(d, "super", grad=False)
+    x = torch.from_numpy(d["super.x"]).double()
+    for l in (3, 4, 5, 6):
+        skip = R.skip_layer_table(l, 3, 6)
+        y = R.volo_forward(p, x, train=False, skip=skip, **arch)
+        assert rel_err(y, d["super.eval_y_l%d" % l]) < TOL, l
+
+
+def test_losses():
+    d = load("loss")
+    for tag, fn, tkey, dw, cw in [("tl_box", R.token_label_ce, "t3", 0.5, 1.0), ("tl_nobox", R.token_label_ce, "t3", 0.5, 1.0),
+                                  ("tl_2d", R.token_label_ce, "t2", 1.0, 1.0), ("gt_box", R.token_label_gt_ce, "t3", 0.5, 1.0),
+                                  ("gt_2d", R.token_label_gt_ce, "t2", 0.5, 1.0)]:
+        cls = torch.from_numpy(d["cls"]).double().requires_grad_(True)
+        aux = torch.from_numpy(d["aux"]).double().requires_grad_(True)
+        bb = tuple(int(v) for v in d[tag + ".bbox"])
+        loss = fn((cls, aux, bb), torch.from_numpy(d[tkey]).double(), dw, cw)
+        assert abs(float(loss) - float(d[tag + ".loss"])) < 1e-6, tag
+        loss.backward()
+        assert rel_err(cls.grad, d[tag + ".dcls"]) < TOL and rel_err(aux.grad, d[tag + ".daux"]) < TOL, tag
+    x = torch.from_numpy(d["st.x"]).double().requires_grad_(True)
+    loss = R.soft_target_ce(x, torch.from_numpy(d["t2"]).double())
+    assert abs(float(loss) - float(d["st.loss"])) < 1e-6
+    loss.backward()
+    assert rel_err(x.grad, d["st.dx"]) < TOL
+    x = torch.from_numpy(d["tlst.x"]).double().requires_grad_(True)
+    loss = R.token_label_soft_target_ce(x, torch.from_numpy(d["tlst.t"]).double())
+    assert abs(float(loss) - float(d["tlst.loss"])) < 1e-6
+    loss.backward()
+    assert rel_err(x.grad, d["tlst.dx"]) < TOL
+
+
+def test_deit_block_matches_pinned_volo_block():
+    """DeiT arithmetic is un-vendored (parity unpinned); its block equals the pinned VOLO
+    Transformer math up to layout / eps, so cross-check vit_block against it."""
+    d = load("blocks")
+    p = _params(d, "transformer", grad=False)
+    x = torch.from_numpy(d["transformer.x"]).double()
+    B, H, W, C = x.shape
+    y = R.vit_block(x.reshape(B, H * W, C), p, "", 2, eps=1e-5).reshape(B, H, W, C)
+    assert rel_err(y, d["transformer.y"]) < TOL
