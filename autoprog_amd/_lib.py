@@ -1,0 +1,73 @@
+"""ctypes binding of libautoprog_hip.so (the C ABI declared in include/autoprog_hip.h).
+
+The library is the product: there is NO fallback.  Importing this module on a machine
+without the built .so, or calling an op without a GPU tensor, raises immediately.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libautoprog_hip.so")
+
+
+class GemmEpilogue(Structure):
+    _fields_ = [("bias", c_void_p), ("gelu", c_int), ("preact_out", c_void_p), ("dgelu_of", c_void_p),
+                ("row_scale", c_void_p), ("rows_per_scale", c_int), ("residual", c_void_p), ("ldr", c_int)]
+
+
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+_SIGNATURES = {
+    "ap_abi_version": (c_int, []),
+    "ap_error_string": (c_char_p, [_I]),
+    "ap_cast_f32_bf16": (_I, [_P, _P, _L, _P]),
+    "ap_cast_bf16_f32": (_I, [_P, _P, _L, _P]),
+    "ap_cast_transpose_f32_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ap_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
+    "ap_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "ap_gemm_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, POINTER(GemmEpilogue), _P]),
+    "ap_gemm_tn_acc": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "ap_colsum_acc": (_I, [_P, _I, _P, _I, _I, _P]),
+    "ap_outlook_fwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "ap_outlook_bwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "ap_avgpool2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ap_avgpool2_bwd_acc": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "ap_mhsa_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "ap_mhsa_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "ap_class_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "ap_class_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "ap_mix_token_swap": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ap_soft_ce_fwd_bwd": (_I, [_P, _I, _P, _L, _L, _L, _I, _P, _P, _F, _L, _I, _P]),
+    "ap_row_scale": (_I, [_P, _P, _P, _L, _I, _I, _P]),
+    "ap_add_bcast": (_I, [_P, _P, _P, _L, _L, _P]),
+    "ap_sum_reps_acc": (_I, [_P, _L, _L, _I, _P]),
+}
+# ap_sum_reps_acc(x, out, n, reps, stream)
+_SIGNATURES["ap_sum_reps_acc"] = (_I, [_P, _P, _L, _I, _P])
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+
+class AutoProgHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise AutoProgHipError(
+            "libautoprog_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C autoprog_amd/csrc`; there is no CPU/PyTorch fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(code, what):
+    if code != 0:
+        raise AutoProgHipError("%s failed: %s (code %d)" % (what, lib.ap_error_string(code).decode(), code))

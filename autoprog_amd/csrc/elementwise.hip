@@ -1,0 +1,280 @@
+// HBM-bound helper kernels: precision casts, DropPath row scaling, broadcast add and its
+// gradient, mix-token region swap, 2x2 ceil-mode average pooling, column sums (bias grads).
+// All bf16 traffic is 16 bytes per lane (8 elements); grids are capped and grid-strided.
+#include "common.h"
+
+static inline int grid_for(int64_t work_items, int block = 256, int cap = 256 * 8) {
+    int64_t g = ceil_div64(work_items, block);
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+// ------------------------------------------------------------------------------------ casts
+__global__ void k_cast_f32_bf16(const float* __restrict__ s, bf16_t* __restrict__ d, int64_t n) {
+    const int64_t nv = n >> 3;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        const float4 a = reinterpret_cast<const float4*>(s)[2 * i];
+        const float4 b = reinterpret_cast<const float4*>(s)[2 * i + 1];
+        u32x4 o;
+        o[0] = pack_bf2(a.x, a.y); o[1] = pack_bf2(a.z, a.w); o[2] = pack_bf2(b.x, b.y); o[3] = pack_bf2(b.z, b.w);
+        st16(d + 8 * i, o);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) d[(nv << 3) + threadIdx.x] = f2bf(s[(nv << 3) + threadIdx.x]);
+}
+__global__ void k_cast_bf16_f32(const bf16_t* __restrict__ s, float* __restrict__ d, int64_t n) {
+    const int64_t nv = n >> 3;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        float f[8];
+        unpack8(ld16(s + 8 * i), f);
+        reinterpret_cast<float4*>(d)[2 * i] = make_float4(f[0], f[1], f[2], f[3]);
+        reinterpret_cast<float4*>(d)[2 * i + 1] = make_float4(f[4], f[5], f[6], f[7]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) d[(nv << 3) + threadIdx.x] = bf2f(s[(nv << 3) + threadIdx.x]);
+}
+// 32x32 tile transpose through LDS: dst[c][r] = src[r][c]
+__global__ void k_cast_transpose(const float* __restrict__ s, bf16_t* __restrict__ d, int rows, int cols, int ld) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: 8 rows per pass
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? s[(int64_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;          // dst row = c, dst col = r
+        if (c < cols && r < ld) d[(int64_t)c * ld + r] = f2bf(tile[tx][i]);
+    }
+}
+
+// ------------------------------------------------------------------------------ row scaling
+__global__ void k_row_scale(const bf16_t* __restrict__ x, const float* __restrict__ sc, bf16_t* __restrict__ y,
+                            int64_t M, int Cv, int rps) {
+    const int64_t total = M * Cv;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t m = i / Cv;
+        const float s = sc[m / rps];
+        float f[8];
+        unpack8(ld16(x + 8 * i), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] *= s;
+        st16(y + 8 * i, pack8(f));
+    }
+}
+__global__ void k_add_bcast(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
+                            int64_t nv, int64_t bv) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        float fa[8], fb[8];
+        unpack8(ld16(a + 8 * i), fa);
+        unpack8(ld16(b + 8 * (i % bv)), fb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fa[j] += fb[j];
+        st16(y + 8 * i, pack8(fa));
+    }
+}
+__global__ void k_sum_reps_acc(const bf16_t* __restrict__ x, float* __restrict__ out, int64_t nv, int reps) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < reps; ++r) {
+            float f[8];
+            unpack8(ld16(x + 8 * (r * nv + i)), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += f[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[8 * i + j] += acc[j];
+    }
+}
+
+// ------------------------------------------------------------------------------- mix token
+__global__ void k_mix_swap(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int Cv,
+                           int r0, int r1, int c0, int c1) {
+    const int64_t total = (int64_t)B * H * W * Cv;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t img = (int64_t)H * W * Cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t b = i / img, rem = i - b * img;
+        const int pix = (int)(rem / Cv);
+        const int r = pix / W, c = pix - r * W;
+        const bool in = (r >= r0) & (r < r1) & (c >= c0) & (c < c1);
+        const int64_t src = in ? ((int64_t)(B - 1 - b) * img + rem) : i;
+        st16(y + 8 * i, ld16(x + 8 * src));
+    }
+}
+
+// --------------------------------------------------------------------------------- pooling
+__global__ void k_avgpool2_fwd(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int Cv) {
+    const int h = (H + 1) >> 1, w = (W + 1) >> 1;
+    const int64_t total = (int64_t)B * h * w * Cv;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int cv = (int)(i % Cv);
+        int64_t t = i / Cv;
+        const int j = (int)(t % w); t /= w;
+        const int ii = (int)(t % h);
+        const int64_t b = t / h;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int cnt = 0;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int yy = 2 * ii + dy, xx = 2 * j + dx;
+                if (yy < H && xx < W) {
+                    float f[8];
+                    unpack8(ld16(x + 8 * (((b * H + yy) * W + xx) * Cv + cv)), f);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] += f[k];
+                    ++cnt;
+                }
+            }
+        const float inv = 1.0f / (float)cnt;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] *= inv;
+        st16(y + 8 * i, pack8(acc));
+    }
+}
+__global__ void k_avgpool2_bwd_acc(const bf16_t* __restrict__ dp, bf16_t* __restrict__ dx, int B, int H, int W, int Cv) {
+    const int h = (H + 1) >> 1, w = (W + 1) >> 1;
+    const int64_t total = (int64_t)B * H * W * Cv;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int cv = (int)(i % Cv);
+        int64_t t = i / Cv;
+        const int xx = (int)(t % W); t /= W;
+        const int yy = (int)(t % H);
+        const int64_t b = t / H;
+        const int ii = yy >> 1, j = xx >> 1;
+        const int cnt = ((2 * ii + 1 < H) ? 2 : 1) * ((2 * j + 1 < W) ? 2 : 1);
+        const float inv = 1.0f / (float)cnt;
+        float g[8], f[8];
+        unpack8(ld16(dp + 8 * (((b * h + ii) * w + j) * Cv + cv)), g);
+        unpack8(ld16(dx + 8 * i), f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] += g[k] * inv;
+        st16(dx + 8 * i, pack8(f));
+    }
+}
+
+// --------------------------------------------------------------------------------- colsum
+// out[n] += sum_m A[m,n].  Block = 256 threads = 32 column-chunks(8 cols) x 8 row lanes.
+__global__ void k_colsum_acc(const bf16_t* __restrict__ A, int lda, float* __restrict__ out, int M, int N, int rows_per_block) {
+    __shared__ float red[8][256 + 8];
+    const int cchunk = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int n0 = (blockIdx.x * 32 + cchunk) * 8;
+    const int m_begin = blockIdx.y * rows_per_block;
+    const int m_end = min(M, m_begin + rows_per_block);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (n0 < N) {
+        for (int m = m_begin + rl; m < m_end; m += 8) {
+            float f[8];
+            unpack8(ld16(A + (int64_t)m * lda + n0), f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += f[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[rl][cchunk * 8 + k] = acc[k];
+    __syncthreads();
+    const int col = threadIdx.x;          // 256 columns per block
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[r][col];
+    const int n = blockIdx.x * 256 + col;
+    if (n < N) atomicAdd(out + n, s);
+}
+
+// ===================================================================================== C ABI
+extern "C" {
+
+int ap_abi_version(void) { return 1; }
+
+const char* ap_error_string(int code) {
+    switch (code) {
+        case AP_OK: return "ok";
+        case AP_ERR_SHAPE: return "shape/stride constraint violated";
+        case AP_ERR_UNSUPPORTED: return "configuration not supported by the gfx950 kernels";
+        case AP_ERR_LAUNCH: return "kernel launch failed";
+        case AP_ERR_NULL: return "null pointer";
+        default: return "unknown error";
+    }
+}
+
+int ap_cast_f32_bf16(const float* src, ap_bf16* dst, int64_t n, ap_stream_t stream) {
+    if (!src || !dst) return AP_ERR_NULL;
+    if (n <= 0) return AP_OK;
+    hipLaunchKernelGGL(k_cast_f32_bf16, dim3(grid_for(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    return ap_check_launch();
+}
+int ap_cast_bf16_f32(const ap_bf16* src, float* dst, int64_t n, ap_stream_t stream) {
+    if (!src || !dst) return AP_ERR_NULL;
+    if (n <= 0) return AP_OK;
+    hipLaunchKernelGGL(k_cast_bf16_f32, dim3(grid_for(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    return ap_check_launch();
+}
+int ap_cast_transpose_f32_bf16(const float* src, ap_bf16* dst, int rows, int cols, int ld_dst, ap_stream_t stream) {
+    if (!src || !dst) return AP_ERR_NULL;
+    if (rows <= 0 || cols <= 0 || ld_dst < rows) return AP_ERR_SHAPE;
+    dim3 grid((cols + 31) / 32, (ld_dst + 31) / 32);
+    hipLaunchKernelGGL(k_cast_transpose, grid, dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols, ld_dst);
+    return ap_check_launch();
+}
+int ap_row_scale(const ap_bf16* x, const float* scale, ap_bf16* y, int64_t M, int C, int rows_per_scale, ap_stream_t stream) {
+    if (!x || !scale || !y) return AP_ERR_NULL;
+    if ((C & 7) || rows_per_scale <= 0) return AP_ERR_SHAPE;
+    if (M <= 0) return AP_OK;
+    hipLaunchKernelGGL(k_row_scale, dim3(grid_for(M * (C / 8))), dim3(256), 0, (hipStream_t)stream, x, scale, y, M, C / 8, rows_per_scale);
+    return ap_check_launch();
+}
+int ap_add_bcast(const ap_bf16* a, const ap_bf16* b, ap_bf16* y, int64_t n, int64_t b_elems, ap_stream_t stream) {
+    if (!a || !b || !y) return AP_ERR_NULL;
+    if ((n & 7) || (b_elems & 7) || b_elems <= 0 || n % b_elems) return AP_ERR_SHAPE;
+    if (n == 0) return AP_OK;
+    hipLaunchKernelGGL(k_add_bcast, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, a, b, y, n / 8, b_elems / 8);
+    return ap_check_launch();
+}
+int ap_sum_reps_acc(const ap_bf16* x, float* out, int64_t n, int reps, ap_stream_t stream) {
+    if (!x || !out) return AP_ERR_NULL;
+    if ((n & 7) || reps <= 0) return AP_ERR_SHAPE;
+    if (n == 0) return AP_OK;
+    hipLaunchKernelGGL(k_sum_reps_acc, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, x, out, n / 8, reps);
+    return ap_check_launch();
+}
+int ap_mix_token_swap(const ap_bf16* x, ap_bf16* y, int B, int H, int W, int C, int r0, int r1, int c0, int c1, ap_stream_t stream) {
+    if (!x || !y) return AP_ERR_NULL;
+    if ((C & 7) || B <= 0 || H <= 0 || W <= 0 || x == y) return AP_ERR_SHAPE;
+    hipLaunchKernelGGL(k_mix_swap, dim3(grid_for((int64_t)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       x, y, B, H, W, C / 8, r0, r1, c0, c1);
+    return ap_check_launch();
+}
+int ap_avgpool2_fwd(const ap_bf16* x, ap_bf16* y, int B, int H, int W, int C, ap_stream_t stream) {
+    if (!x || !y) return AP_ERR_NULL;
+    if ((C & 7) || B <= 0 || H <= 0 || W <= 0) return AP_ERR_SHAPE;
+    const int h = (H + 1) / 2, w = (W + 1) / 2;
+    hipLaunchKernelGGL(k_avgpool2_fwd, dim3(grid_for((int64_t)B * h * w * (C / 8))), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C / 8);
+    return ap_check_launch();
+}
+int ap_avgpool2_bwd_acc(const ap_bf16* dpooled, ap_bf16* dx, int B, int H, int W, int C, ap_stream_t stream) {
+    if (!dpooled || !dx) return AP_ERR_NULL;
+    if ((C & 7) || B <= 0 || H <= 0 || W <= 0) return AP_ERR_SHAPE;
+    hipLaunchKernelGGL(k_avgpool2_bwd_acc, dim3(grid_for((int64_t)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, dpooled, dx, B, H, W, C / 8);
+    return ap_check_launch();
+}
+int ap_colsum_acc(const ap_bf16* A, int lda, float* out, int M, int N, ap_stream_t stream) {
+    if (!A || !out) return AP_ERR_NULL;
+    if ((lda & 7) || M <= 0 || N <= 0 || lda < N) return AP_ERR_SHAPE;
+    const int gx = (N + 255) / 256;
+    int gy = (M + 255) / 256;                         // >= 256 rows per block
+    const int cap = (2048 + gx - 1) / gx;
+    if (gy > cap) gy = cap;
+    const int rows_per_block = (M + gy - 1) / gy;
+    hipLaunchKernelGGL(k_colsum_acc, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, A, lda, out, M, N, rows_per_block);
+    return ap_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,302 @@
+// bf16 MFMA GEMMs for the Linear layers of the VOLO/DeiT hot path (models/volo.py:67,68,71,
+// 156,158,180,182,253,256,258,547,553 and their autograd backward).
+//
+//   ap_gemm_nt     C[M,N]  = epi(A[M,K] . B[N,K]^T)      forward (B = weight) and input-gradient
+//                                                        (B = pre-transposed weight) GEMMs
+//   ap_gemm_tn_acc C[N1,N2] += A[M,N1]^T . B[M,N2]       weight gradients, fp32 accumulate
+//
+// Both use v_mfma_f32_16x16x32_bf16 (lane maps pinned on hardware by tools/probe, profiles/
+// r01_hw_probe.txt): A operand lane l holds A[row l&15][k 8*(l>>4)+j], B operand B[k][col l&15],
+// accumulator D[row 4*(l>>4)+r][col l&15].
+//
+// gemm_nt: 128x128x64 tile, 4 waves (2x2) x 64x64 per wave.  Operands are staged global ->
+// registers -> LDS (16-byte chunks) with the 16-B chunk index XORed by (row&7): ds_write_b128 of a
+// row and ds_read_b128 of an MFMA fragment are both bank-conflict free.  The MFMA is issued as
+// D = W_frag (A operand) x X_frag (B operand) so that a lane ends with 4 CONSECUTIVE output columns
+// of one output row -> 8-byte bf16 stores and vector loads of bias / residual in the epilogue.
+// The next K tile's global loads are issued before the MFMAs of the current one.
+//
+// gemm_tn: the reduction runs over the token axis, which is the SLOW axis of both operands, so
+// fragments are fetched with ds_read_b64_tr_b16 (hardware transpose) from row-major [64 tok][128]
+// LDS tiles; the chunk swizzle f(row) keeps those transposed reads conflict free.  The token range
+// is split across blockIdx.z and partial tiles are added with fp32 atomics (few MB per call).
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+// XCD-aware bijective remap of the linear block id: blocks that share an XCD (id % 8) get a
+// contiguous range of tiles, so neighbouring tiles (same A row panel) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + k;
+}
+
+struct EpiArgs {
+    const float* bias; int gelu; bf16_t* preact; const bf16_t* dgelu_of; const float* row_scale;
+    int rows_per_scale; const bf16_t* residual; int ldr;
+};
+
+__global__ void __launch_bounds__(256)
+k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
+          int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
+    __shared__ __attribute__((aligned(16))) bf16_t sA[BM * BK];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[BN * BK];
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, g = lane >> 4;
+
+    // staging assignment: 4 chunks per operand per thread: rows (tid>>3)+32*i, chunk kc = tid&7
+    const int srow = tid >> 3, kc = tid & 7;
+    const bf16_t* ga[4];
+    const bf16_t* gb[4];
+    int soff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = srow + 32 * i;
+        ga[i] = A + (int64_t)min(m0 + r, M - 1) * lda + kc * 8;
+        gb[i] = B + (int64_t)min(n0 + r, N - 1) * ldb + kc * 8;
+        soff[i] = r * BK + ((kc ^ (r & 7)) << 3);          // in elements
+    }
+    u32x4 ra[4], rb[4];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    auto gload = [&](int k0) {
+        const bool ok = (k0 + kc * 8) < K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = ok ? ld16(ga[i] + k0) : zero4;
+            rb[i] = ok ? ld16(gb[i] + k0) : zero4;
+        }
+    };
+
+    f32x4 acc[4][4];     // [nt][mt]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { st16(sA + soff[i], ra[i]); st16(sB + soff[i], rb[i]); }
+        __syncthreads();
+        if (k0 + BK < K) gload(k0 + BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xf[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ra_ = wm * 64 + t * 16 + fr;
+                const int rb_ = wn * 64 + t * 16 + fr;
+                xf[t] = as_bf16x8(ld16(sA + ra_ * BK + (((ks * 4 + g) ^ (ra_ & 7)) << 3)));
+                wf[t] = as_bf16x8(ld16(sB + rb_ * BK + (((ks * 4 + g) ^ (rb_ & 7)) << 3)));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    const bool vec_ok = ((ldc & 3) == 0) && (ep.residual == nullptr || (ep.ldr & 3) == 0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wm * 64 + mt * 16 + fr;
+        if (m >= M) continue;
+        const float rs = ep.row_scale ? ep.row_scale[m / ep.rows_per_scale] : 1.0f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wn * 64 + nt * 16 + 4 * g;
+            if (n >= N) continue;
+            float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
+            const bool full = (n + 3 < N) && vec_ok;
+            if (ep.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < N) v[r] += ep.bias[n + r];
+            }
+            if (ep.gelu) {
+                if (ep.preact) {
+                    bf16_t* p = ep.preact + (int64_t)m * ldc + n;
+                    if (full) { u32x2 o; o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]); *reinterpret_cast<u32x2*>(p) = o; }
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < N) p[r] = f2bf(v[r]);
+                    }
+                    // the activation is applied to the ROUNDED pre-activation so that backward
+                    // (which reads the stored bf16 h) differentiates exactly what forward computed
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = bf2f(f2bf(v[r]));
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (ep.dgelu_of) {
+                const bf16_t* hp = ep.dgelu_of + (int64_t)m * ldc + n;
+                if (full) {
+                    const u32x2 h = *reinterpret_cast<const u32x2*>(hp);
+                    v[0] *= gelu_erf_grad(bf_lo(h[0])); v[1] *= gelu_erf_grad(bf_hi(h[0]));
+                    v[2] *= gelu_erf_grad(bf_lo(h[1])); v[3] *= gelu_erf_grad(bf_hi(h[1]));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) v[r] *= gelu_erf_grad(bf2f(hp[r]));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= rs;
+            if (ep.residual) {
+                const bf16_t* rp = ep.residual + (int64_t)m * ep.ldr + n;
+                if (full) {
+                    const u32x2 h = *reinterpret_cast<const u32x2*>(rp);
+                    v[0] += bf_lo(h[0]); v[1] += bf_hi(h[0]); v[2] += bf_lo(h[1]); v[3] += bf_hi(h[1]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) v[r] += bf2f(rp[r]);
+                }
+            }
+            bf16_t* cp = C + (int64_t)m * ldc + n;
+            if (full) { u32x2 o; o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]); *reinterpret_cast<u32x2*>(cp) = o; }
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(v[r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ wgrad
+#define TM 64          // tokens per step (MFMA reduction)
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int row0, int col0, int lane) {
+    // fragment for MFMA 16x16x32 whose k axis is the tile ROW axis: rows row0+8g..+7, cols col0..+15
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int r1 = row0 + 8 * g + q, r2 = r1 + 4;
+    const int j = (col0 >> 3) + (p >> 1);
+    const bf16_t* a1 = tile + r1 * 128 + ((j ^ tn_swz(r1)) << 3) + (p & 1) * 4;
+    const bf16_t* a2 = tile + r2 * 128 + ((j ^ tn_swz(r2)) << 3) + (p & 1) * 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a2));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ void __launch_bounds__(256)
+k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+          int M, int N1, int N2, int steps_per_split) {
+    __shared__ __attribute__((aligned(16))) bf16_t sA[TM * 128];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[TM * 128];
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int step_begin = blockIdx.z * steps_per_split;
+    const int total_steps = (M + TM - 1) / TM;
+    const int step_end = min(total_steps, step_begin + steps_per_split);
+    if (step_begin >= step_end) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int srow = tid >> 4, j = tid & 15;            // 4 chunks: rows srow + 16*i, chunk j
+    const bool a_ok = (n0 + j * 8) < N1, b_ok = (k0 + j * 8) < N2;
+    u32x4 ra[4], rb[4];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    auto gload = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = step * TM + srow + 16 * i;
+            const bool ok = m < M;
+            ra[i] = (ok && a_ok) ? ld16(A + (int64_t)m * lda + n0 + j * 8) : zero4;
+            rb[i] = (ok && b_ok) ? ld16(B + (int64_t)m * ldb + k0 + j * 8) : zero4;
+        }
+    };
+    f32x4 acc[4][4];     // [nt][kt]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    gload(step_begin);
+    for (int step = step_begin; step < step_end; ++step) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = srow + 16 * i;
+            const int off = r * 128 + ((j ^ tn_swz(r)) << 3);
+            st16(sA + off, ra[i]);
+            st16(sB + off, rb[i]);
+        }
+        __syncthreads();
+        if (step + 1 < step_end) gload(step + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = tr_frag(sA, ks * 32, wn * 64 + t * 16, lane);
+                bfr[t] = tr_frag(sB, ks * 32, wk * 64 + t * 16, lane);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int fr = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int kk = k0 + wk * 64 + kt * 16 + fr;
+            if (kk >= N2) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + nt * 16 + 4 * g + r;
+                if (n < N1) atomicAdd(C + (int64_t)n * ldc + kk, acc[nt][kt][r]);
+            }
+        }
+}
+
+extern "C" {
+
+int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C, int ldc, int M, int N, int K,
+               const ap_gemm_epilogue* epi, ap_stream_t stream) {
+    if (!A || !B || !C) return AP_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0) return AP_ERR_SHAPE;
+    if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N) return AP_ERR_SHAPE;
+    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0};
+    if (epi) {
+        ep.bias = epi->bias; ep.gelu = epi->gelu; ep.preact = epi->preact_out; ep.dgelu_of = epi->dgelu_of;
+        ep.row_scale = epi->row_scale; ep.rows_per_scale = epi->rows_per_scale > 0 ? epi->rows_per_scale : 1;
+        ep.residual = epi->residual; ep.ldr = epi->ldr;
+        if (ep.residual && ep.ldr < N) return AP_ERR_SHAPE;
+    }
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int ntiles = tiles_m * tiles_n;
+    hipLaunchKernelGGL(k_gemm_nt, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ntiles, ep);
+    return ap_check_launch();
+}
+
+int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* C, int ldc, int M, int N1, int N2,
+                   ap_stream_t stream) {
+    if (!A || !B || !C) return AP_ERR_NULL;
+    if (M <= 0 || N1 <= 0 || N2 <= 0) return AP_ERR_SHAPE;
+    if ((lda & 7) || (ldb & 7) || lda < N1 || ldb < N2 || ldc < N2) return AP_ERR_SHAPE;
+    const int t1 = (N1 + 127) / 128, t2 = (N2 + 127) / 128;
+    const int total_steps = (M + TM - 1) / TM;
+    int splits = (1024 + t1 * t2 - 1) / (t1 * t2);        // aim at ~4 blocks per CU
+    if (splits > total_steps) splits = total_steps;
+    if (splits < 1) splits = 1;
+    const int sps = (total_steps + splits - 1) / splits;
+    splits = (total_steps + sps - 1) / sps;
+    hipLaunchKernelGGL(k_gemm_tn, dim3(t1, t2, splits), dim3(256), 0, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N1, N2, sps);
+    return ap_check_launch();
+}
+
+}  // extern "C"

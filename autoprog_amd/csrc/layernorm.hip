@@ -1,0 +1,192 @@
+// LayerNorm forward / backward for token-major bf16 activations (nn.LayerNorm semantics:
+// biased variance, fp32 statistics, affine) -- reference call sites models/volo.py:122,131,
+// 213,221,290,297,550.  HBM-bound: one pass over x (fwd), one pass over (dy, x[, dres]) (bwd).
+//
+// Mapping: a row is owned by a group of G lanes (G = 16/32/64, power of two >= C/8), every lane
+// holds V 16-byte chunks (8 channels) of the row; reductions are wavefront shuffles (xor < G).
+// Rows are grid-strided so every lane keeps the same channels and accumulates dgamma/dbeta in
+// registers; those are reduced through LDS per block and added with fp32 atomics.
+#include "common.h"
+
+template <int V>
+__global__ void __launch_bounds__(256)
+k_ln_fwd(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+         bf16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+         int64_t rows, int C, int G, float eps) {
+    const int lane_in_group = threadIdx.x & (G - 1);
+    const int groups_per_block = 256 / G;
+    const int group = threadIdx.x / G;
+    const int nchunks = C >> 3;
+    const float invC = 1.0f / (float)C;
+    for (int64_t row = (int64_t)blockIdx.x * groups_per_block + group; row < rows; row += (int64_t)gridDim.x * groups_per_block) {
+        float v[V][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int ch = lane_in_group + i * G;
+            if (ch < nchunks) {
+                unpack8(ld16(x + row * C + 8 * ch), v[i]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += v[i][k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[i][k] = 0.f;
+            }
+        }
+        for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mu = s * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int ch = lane_in_group + i * G;
+            if (ch < nchunks) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
+            }
+        }
+        for (int o = G >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rs = rsqrtf(q * invC + eps);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int ch = lane_in_group + i * G;
+            if (ch < nchunks) {
+                const float4 g0 = reinterpret_cast<const float4*>(gamma)[2 * ch], g1 = reinterpret_cast<const float4*>(gamma)[2 * ch + 1];
+                const float4 b0 = reinterpret_cast<const float4*>(beta)[2 * ch], b1 = reinterpret_cast<const float4*>(beta)[2 * ch + 1];
+                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                float o8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o8[k] = (v[i][k] - mu) * rs * gg[k] + bb[k];
+                st16(y + row * C + 8 * ch, pack8(o8));
+            }
+        }
+        if (lane_in_group == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256)
+k_ln_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+         const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
+         bf16_t* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+         int64_t rows, int C, int G) {
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [groups_per_block][C] x 2
+    const int lane_in_group = threadIdx.x & (G - 1);
+    const int groups_per_block = 256 / G;
+    const int group = threadIdx.x / G;
+    const int nchunks = C >> 3;
+    const float invC = 1.0f / (float)C;
+    float gam[V][8], ag[V][8], ab[V][8];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int ch = lane_in_group + i * G;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; gam[i][k] = (ch < nchunks) ? gamma[8 * ch + k] : 0.f; }
+    }
+    for (int64_t row = (int64_t)blockIdx.x * groups_per_block + group; row < rows; row += (int64_t)gridDim.x * groups_per_block) {
+        const float mu = mean[row], rs = rstd[row];
+        float g[V][8], xh[V][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int ch = lane_in_group + i * G;
+            if (ch < nchunks) {
+                float d8[8], x8[8];
+                unpack8(ld16(dy + row * C + 8 * ch), d8);
+                unpack8(ld16(x + row * C + 8 * ch), x8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    xh[i][k] = (x8[k] - mu) * rs;
+                    g[i][k] = d8[k] * gam[i][k];
+                    s1 += g[i][k];
+                    s2 += g[i][k] * xh[i][k];
+                    ag[i][k] += d8[k] * xh[i][k];
+                    ab[i][k] += d8[k];
+                }
+            }
+        }
+        for (int o = G >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        s1 *= invC; s2 *= invC;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int ch = lane_in_group + i * G;
+            if (ch < nchunks) {
+                float o8[8];
+                if (dres != nullptr) unpack8(ld16(dres + row * C + 8 * ch), o8);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o8[k] = 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o8[k] += rs * (g[i][k] - s1 - xh[i][k] * s2);
+                st16(dx + row * C + 8 * ch, pack8(o8));
+            }
+        }
+    }
+    // block reduction of the per-lane dgamma/dbeta partials, then one atomic per channel per block
+    float* rg = red;
+    float* rb = red + groups_per_block * C;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int ch = lane_in_group + i * G;
+        if (ch < nchunks) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { rg[group * C + 8 * ch + k] = ag[i][k]; rb[group * C + 8 * ch + k] = ab[i][k]; }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float sg = 0.f, sb = 0.f;
+        for (int gi = 0; gi < groups_per_block; ++gi) { sg += rg[gi * C + c]; sb += rb[gi * C + c]; }
+        atomicAdd(dgamma + c, sg);
+        atomicAdd(dbeta + c, sb);
+    }
+}
+
+static int pick_group(int C, int* V) {
+    const int nch = C / 8;
+    int G = 16;
+    while (G < 64 && G < nch) G <<= 1;
+    int v = (nch + G - 1) / G;
+    *V = v <= 1 ? 1 : (v <= 2 ? 2 : 4);
+    return G;
+}
+
+extern "C" {
+
+int ap_layernorm_fwd(const ap_bf16* x, const float* gamma, const float* beta, ap_bf16* y, float* mean, float* rstd,
+                     int64_t rows, int C, float eps, ap_stream_t stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd) return AP_ERR_NULL;
+    if (C <= 0 || (C & 7)) return AP_ERR_SHAPE;
+    if (C > 2048) return AP_ERR_UNSUPPORTED;
+    if (rows <= 0) return AP_OK;
+    int V; const int G = pick_group(C, &V);
+    const int gpb = 256 / G;
+    int64_t grid = ceil_div64(rows, gpb);
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipStream_t s = (hipStream_t)stream;
+    if (V == 1) hipLaunchKernelGGL(k_ln_fwd<1>, dim3((int)grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
+    else if (V == 2) hipLaunchKernelGGL(k_ln_fwd<2>, dim3((int)grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
+    else hipLaunchKernelGGL(k_ln_fwd<4>, dim3((int)grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
+    return ap_check_launch();
+}
+
+int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* mean, const float* rstd,
+                     const ap_bf16* dres, ap_bf16* dx, float* dgamma, float* dbeta, int64_t rows, int C, ap_stream_t stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) return AP_ERR_NULL;
+    if (C <= 0 || (C & 7)) return AP_ERR_SHAPE;
+    if (C > 2048) return AP_ERR_UNSUPPORTED;
+    if (rows <= 0) return AP_OK;
+    int V; const int G = pick_group(C, &V);
+    const int gpb = 256 / G;
+    int64_t grid = ceil_div64(rows, gpb);
+    if (grid > 1024) grid = 1024;           // bounds the dgamma/dbeta atomic traffic
+    const size_t lds = (size_t)2 * gpb * C * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (V == 1) hipLaunchKernelGGL(k_ln_bwd<1>, dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);
+    else if (V == 2) hipLaunchKernelGGL(k_ln_bwd<2>, dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);
+    else hipLaunchKernelGGL(k_ln_bwd<4>, dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);
+    return ap_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,427 @@
+// Fused multi-head self-attention core for short sequences (N <= 256 tokens, head_dim 32):
+//   softmax(q k^T * scale) v   (models/volo.py:188-197) and its backward.
+// One workgroup (4 waves) per (image, head); K/V (and Q/dO in backward) of that head live in LDS
+// for the whole kernel, so qkv is read once from HBM (HBM-bound: ~3*N*32*2 B in, N*32*2 B out).
+//
+// MFMA v_mfma_f32_16x16x32_bf16 (k = head_dim = 32: one instruction per 16x16 score tile):
+//   forward : S^T tile = K_tile . Q_tile^T  -> lane holds 4 keys x 1 query per tile, the whole
+//             score row of a query is spread over the 4 lanes (l, l+16, l+32, l+48): softmax
+//             max/sum = in-register + 2 shuffles.  P then feeds the PV product directly as the
+//             MFMA A operand (k order permuted, hardware-probe-verified), V is fetched with
+//             ds_read_b64_tr_b16 from the row-major LDS image (no transposed copy).
+//   backward: two passes over the LDS-resident head, both reduction-free across waves:
+//             pass A, wave owns 16 keys  : dV += P^T dO, dK += dS^T Q   (S,dP recomputed)
+//             pass B, wave owns 16 queries: dQ += dS K                  (S^T,dP^T recomputed)
+// LDS tiles are [tokens][32] bf16 (64-byte rows) with the 16-byte chunk index XORed by
+// f((row>>2)&3), f = {0,2,3,1}: conflict-free for both the ds_read_b128 row reads and the
+// transposed reads.
+#include "common.h"
+
+#define AHD 32
+
+__device__ __forceinline__ int att_off(int row, int chunk) {       // element offset of a 16-B chunk
+    const int f = (0x78 >> (((row >> 2) & 3) << 1)) & 3;
+    return row * AHD + ((chunk ^ f) << 3);
+}
+__device__ __forceinline__ bf16x8 att_row_frag(const bf16_t* tile, int row0, int lane) {
+    // operand whose k axis is the head dim: tile row row0+(lane&15), chunk lane>>4
+    return __builtin_bit_cast(bf16x8, ld16(tile + att_off(row0 + (lane & 15), lane >> 4)));
+}
+__device__ __forceinline__ bf16x8 att_tr_frag(const bf16_t* tile, int row0, int dt, int lane) {
+    // operand whose k axis is the TOKEN axis in the accumulator-permuted order:
+    // k = 8g+j  <->  token row0 + 16*(j>>2) + 4g + (j&3); column = dt*16 + (lane&15)
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int r1 = row0 + 4 * g + q, r2 = r1 + 16;
+    const int ch = 2 * dt + (p >> 1), e = (p & 1) * 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + att_off(r1, ch) + e));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + att_off(r2, ch) + e));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
+    u32x4 v;
+    v[0] = pack_bf2(a[0], a[1]); v[1] = pack_bf2(a[2], a[3]); v[2] = pack_bf2(b[0], b[1]); v[3] = pack_bf2(b[2], b[3]);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// stage rows [0,Npad) of one [N, ld] strided matrix slice (32 columns) into a swizzled LDS tile
+__device__ __forceinline__ void att_stage(bf16_t* tile, const bf16_t* src, int64_t ld, int N, int Npad) {
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    for (int idx = threadIdx.x; idx < Npad * 4; idx += 256) {
+        const int row = idx >> 2, c = idx & 3;
+        const u32x4 v = (row < N) ? ld16(src + (int64_t)row * ld + c * 8) : zero4;
+        st16(tile + att_off(row, c), v);
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+k_mhsa_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    constexpr int Npad = NT * 16;
+    bf16_t* Ks = smem;
+    bf16_t* Vs = smem + Npad * AHD;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int C = heads * AHD;
+    const int64_t ld = 3 * C;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + h * AHD;
+    att_stage(Ks, base + C, ld, N, Npad);
+    att_stage(Vs, base + 2 * C, ld, N, Npad);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
+    const float c2 = scale * 1.4426950408889634f;
+    const int nq = (N + 15) >> 4;
+    for (int qt = wave; qt < nq; qt += 4) {
+        const int qrow = min(qt * 16 + fr, N - 1);
+        const bf16x8 qf = __builtin_bit_cast(bf16x8, ld16(base + (int64_t)qrow * ld + g * 8));
+        f32x4 s[NT];
+        float mx = -1.0e30f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, t * 16, lane), qf, z, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = t * 16 + 4 * g + r;
+                s[t][r] = (key < N) ? s[t][r] * c2 : -1.0e30f;
+                mx = fmaxf(mx, s[t][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[t][r] = exp2f(s[t][r] - mx); sum += s[t][r]; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s2 = 0; s2 < NT / 2; ++s2) {
+            const bf16x8 pf = pack_frag(s[2 * s2], s[2 * s2 + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, att_tr_frag(Vs, 32 * s2, dt, lane), o[dt], 0, 0, 0);
+        }
+        const float inv = 1.0f / sum;
+        if (g == 0 && qt * 16 + fr < N) lse[((int64_t)b * heads + h) * N + qt * 16 + fr] = (mx + log2f(sum)) * 0.6931471805599453f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ir = __shfl(inv, 4 * g + r, 64);
+            const int q = qt * 16 + 4 * g + r;
+            if (q < N) {
+                bf16_t* op = out + ((int64_t)b * N + q) * C + h * AHD + fr;
+                op[0] = f2bf(o[0][r] * ir);
+                op[16] = f2bf(o[1][r] * ir);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)
+k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+           const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int heads, float scale, int NT) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    const int Npad = NT * 16;
+    bf16_t* Qs = smem;
+    bf16_t* Ks = Qs + Npad * AHD;
+    bf16_t* Vs = Ks + Npad * AHD;
+    bf16_t* Gs = Vs + Npad * AHD;                                  // dO
+    float* fl = reinterpret_cast<float*>(Gs + Npad * AHD);         // lse * log2(e)   (+huge for padded rows)
+    float* fd = fl + Npad;                                         // delta = rowsum(dO * O)
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int C = heads * AHD;
+    const int64_t ld = 3 * C;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + h * AHD;
+    const bf16_t* obase = out + (int64_t)b * N * C + h * AHD;
+    const bf16_t* gbase = dout + (int64_t)b * N * C + h * AHD;
+    att_stage(Qs, base, ld, N, Npad);
+    att_stage(Ks, base + C, ld, N, Npad);
+    att_stage(Vs, base + 2 * C, ld, N, Npad);
+    att_stage(Gs, gbase, C, N, Npad);
+    for (int idx = threadIdx.x; idx < Npad * 4; idx += 256) {      // Npad*4 is a multiple of 128: whole waves
+        const int row = idx >> 2, c = idx & 3;
+        float part = 0.f;
+        if (row < N) {
+            float a[8], d[8];
+            unpack8(ld16(obase + (int64_t)row * C + c * 8), a);
+            unpack8(ld16(gbase + (int64_t)row * C + c * 8), d);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) part += a[k] * d[k];
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        if (c == 0) {
+            fd[row] = part;
+            fl[row] = (row < N) ? lse[((int64_t)b * heads + h) * N + row] * 1.4426950408889634f : 1.0e30f;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
+    const float c2 = scale * 1.4426950408889634f;
+    const int ntile = (N + 15) >> 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    bf16_t* dbase = dqkv + (int64_t)b * N * ld + h * AHD;
+
+    // ---- pass A: this wave owns key tile jt -> dK, dV
+    for (int jt = wave; jt < ntile; jt += 4) {
+        const bf16x8 kf = att_row_frag(Ks, jt * 16, lane);
+        const bf16x8 vf = att_row_frag(Vs, jt * 16, lane);
+        f32x4 dk[2] = {z, z}, dv[2] = {z, z};
+#pragma unroll 1
+        for (int qs = 0; qs < NT / 2; ++qs) {
+            f32x4 p[2], ds[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int q0 = (2 * qs + hf) * 16;
+                const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Qs, q0, lane), kf, z, 0, 0, 0);
+                const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Gs, q0, lane), vf, z, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = q0 + 4 * g + r;
+                    const float pv = exp2f(sc[r] * c2 - fl[q]);
+                    p[hf][r] = pv;
+                    ds[hf][r] = pv * (dp[r] - fd[q]) * scale;
+                }
+            }
+            const bf16x8 pf = pack_frag(p[0], p[1]);
+            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, att_tr_frag(Gs, 32 * qs, dt, lane), dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, att_tr_frag(Qs, 32 * qs, dt, lane), dk[dt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = jt * 16 + 4 * g + r;
+            if (key < N) {
+                bf16_t* kp = dbase + (int64_t)key * ld + C + fr;
+                kp[0] = f2bf(dk[0][r]); kp[16] = f2bf(dk[1][r]);
+                kp[C] = f2bf(dv[0][r]); kp[C + 16] = f2bf(dv[1][r]);
+            }
+        }
+    }
+    // ---- pass B: this wave owns query tile qt -> dQ
+    for (int qt = wave; qt < ntile; qt += 4) {
+        const bf16x8 qf = att_row_frag(Qs, qt * 16, lane);
+        const bf16x8 gf = att_row_frag(Gs, qt * 16, lane);
+        const float flq = fl[qt * 16 + fr], fdq = fd[qt * 16 + fr];
+        f32x4 dq[2] = {z, z};
+#pragma unroll 1
+        for (int ks = 0; ks < NT / 2; ++ks) {
+            f32x4 ds[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int k0 = (2 * ks + hf) * 16;
+                const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, k0, lane), qf, z, 0, 0, 0);
+                const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Vs, k0, lane), gf, z, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + 4 * g + r;
+                    const float pv = (key < N) ? exp2f(sc[r] * c2 - flq) : 0.f;
+                    ds[hf][r] = pv * (dp[r] - fdq) * scale;
+                }
+            }
+            const bf16x8 dsf = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, att_tr_frag(Ks, 32 * ks, dt, lane), dq[dt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = qt * 16 + 4 * g + r;
+            if (q < N) {
+                bf16_t* qp = dbase + (int64_t)q * ld + fr;
+                qp[0] = f2bf(dq[0][r]); qp[16] = f2bf(dq[1][r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- class attention
+// one query (token 0) per image and head: HBM-bound VALU kernel, 4 lanes x 16 B per key row.
+__global__ void __launch_bounds__(256)
+k_class_attn_fwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, bf16_t* __restrict__ out,
+                 float* __restrict__ probs, int N, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // scores[N] | red[64*32]
+    float* sc = sm;
+    float* red = sm + ((N + 63) & ~63);
+    __shared__ float wred[8];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int C = heads * AHD;
+    const int part = threadIdx.x & 3, kslot = threadIdx.x >> 2;          // 64 keys per pass
+    float qv[8];
+    unpack8(ld16(q + (int64_t)b * C + h * AHD + part * 8), qv);
+    const bf16_t* kb = kv + (int64_t)b * N * 2 * C + h * AHD + part * 8;
+    float mx = -1.0e30f;
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        const int key = k0 + kslot;
+        float d = 0.f;
+        if (key < N) {
+            float kk[8];
+            unpack8(ld16(kb + (int64_t)key * 2 * C), kk);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d += qv[i] * kk[i];
+        }
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d *= scale;
+        if (key < N) { if (part == 0) sc[key] = d; mx = fmaxf(mx, d); }
+    }
+    mx = group_max<64>(mx);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    float sum = 0.f;
+    for (int key = threadIdx.x; key < N; key += 256) { const float e = __expf(sc[key] - mx); sc[key] = e; sum += e; }
+    sum = group_sum<64>(sum);
+    if ((threadIdx.x & 63) == 0) wred[4 + (threadIdx.x >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (wred[4] + wred[5] + wred[6] + wred[7]);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        const int key = k0 + kslot;
+        if (key < N) {
+            const float p = sc[key] * inv;
+            if (part == 0) probs[((int64_t)b * heads + h) * N + key] = p;
+            float vv[8];
+            unpack8(ld16(kb + (int64_t)key * 2 * C + C), vv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += p * vv[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[kslot * 32 + part * 8 + i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float s = 0.f;
+        for (int k = 0; k < 64; ++k) s += red[k * 32 + threadIdx.x];
+        out[(int64_t)b * C + h * AHD + threadIdx.x] = f2bf(s);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_class_attn_bwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, const float* __restrict__ probs,
+                 const bf16_t* __restrict__ dout, bf16_t* __restrict__ dq, bf16_t* __restrict__ dkv,
+                 int N, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // dp[N] | red[64*32]
+    float* dps = sm;
+    float* red = sm + ((N + 63) & ~63);
+    __shared__ float wred[4];
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int C = heads * AHD;
+    const int part = threadIdx.x & 3, kslot = threadIdx.x >> 2;
+    float qv[8], gv[8];
+    unpack8(ld16(q + (int64_t)b * C + h * AHD + part * 8), qv);
+    unpack8(ld16(dout + (int64_t)b * C + h * AHD + part * 8), gv);
+    const bf16_t* kb = kv + (int64_t)b * N * 2 * C + h * AHD + part * 8;
+    bf16_t* db = dkv + (int64_t)b * N * 2 * C + h * AHD + part * 8;
+    const float* pr = probs + ((int64_t)b * heads + h) * N;
+    // dp_k = <dout, V_k>;  dV_k = p_k * dout;  dot = sum_k p_k dp_k
+    float dot = 0.f;
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        const int key = k0 + kslot;
+        float d = 0.f;
+        if (key < N) {
+            float vv[8], o8[8];
+            unpack8(ld16(kb + (int64_t)key * 2 * C + C), vv);
+            const float p = pr[key];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { d += gv[i] * vv[i]; o8[i] = p * gv[i]; }
+            st16(db + (int64_t)key * 2 * C + C, pack8(o8));
+        }
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        if (key < N && part == 0) { dps[key] = d; dot += pr[key] * d; }
+    }
+    dot = group_sum<64>(dot);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    dot = wred[0] + wred[1] + wred[2] + wred[3];
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        const int key = k0 + kslot;
+        if (key < N) {
+            const float ds = pr[key] * (dps[key] - dot) * scale;       // d(score)/d(q.k)
+            float kk[8], o8[8];
+            unpack8(ld16(kb + (int64_t)key * 2 * C), kk);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { acc[i] += ds * kk[i]; o8[i] = ds * qv[i]; }
+            st16(db + (int64_t)key * 2 * C, pack8(o8));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[kslot * 32 + part * 8 + i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float s = 0.f;
+        for (int k = 0; k < 64; ++k) s += red[k * 32 + threadIdx.x];
+        dq[(int64_t)b * C + h * AHD + threadIdx.x] = f2bf(s);
+    }
+}
+
+#define MHSA_DISPATCH(KERNEL, NTV, ...)                                                          \
+    switch (NTV) {                                                                               \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, grid, dim3(256), lds, s, __VA_ARGS__); break;      \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), lds, s, __VA_ARGS__); break;      \
+        case 6: hipLaunchKernelGGL(KERNEL<6>, grid, dim3(256), lds, s, __VA_ARGS__); break;      \
+        case 8: hipLaunchKernelGGL(KERNEL<8>, grid, dim3(256), lds, s, __VA_ARGS__); break;      \
+        case 10: hipLaunchKernelGGL(KERNEL<10>, grid, dim3(256), lds, s, __VA_ARGS__); break;    \
+        case 12: hipLaunchKernelGGL(KERNEL<12>, grid, dim3(256), lds, s, __VA_ARGS__); break;    \
+        case 14: hipLaunchKernelGGL(KERNEL<14>, grid, dim3(256), lds, s, __VA_ARGS__); break;    \
+        default: hipLaunchKernelGGL(KERNEL<16>, grid, dim3(256), lds, s, __VA_ARGS__); break;    \
+    }
+
+extern "C" {
+
+int ap_mhsa_fwd(const ap_bf16* qkv, ap_bf16* out, float* lse, int B, int N, int heads, int hd, float scale, ap_stream_t stream) {
+    if (!qkv || !out || !lse) return AP_ERR_NULL;
+    if (B <= 0 || N <= 0 || heads <= 0) return AP_ERR_SHAPE;
+    if (hd != AHD || N > 256) return AP_ERR_UNSUPPORTED;
+    const int nt = 2 * ((N + 31) / 32);
+    const dim3 grid(B * heads);
+    const size_t lds = (size_t)2 * nt * 16 * AHD * sizeof(bf16_t);
+    hipStream_t s = (hipStream_t)stream;
+    MHSA_DISPATCH(k_mhsa_fwd, nt, qkv, out, lse, N, heads, scale)
+    return ap_check_launch();
+}
+
+int ap_mhsa_bwd(const ap_bf16* qkv, const ap_bf16* out, const ap_bf16* dout, const float* lse, ap_bf16* dqkv,
+                int B, int N, int heads, int hd, float scale, ap_stream_t stream) {
+    if (!qkv || !out || !dout || !lse || !dqkv) return AP_ERR_NULL;
+    if (B <= 0 || N <= 0 || heads <= 0) return AP_ERR_SHAPE;
+    if (hd != AHD || N > 256) return AP_ERR_UNSUPPORTED;
+    const int nt = 2 * ((N + 31) / 32);
+    const dim3 grid(B * heads);
+    const size_t lds = (size_t)4 * nt * 16 * AHD * sizeof(bf16_t) + (size_t)2 * nt * 16 * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_mhsa_bwd, grid, dim3(256), lds, s, qkv, out, dout, lse, dqkv, N, heads, scale, nt);
+    return ap_check_launch();
+}
+
+int ap_class_attn_fwd(const ap_bf16* q, const ap_bf16* kv, ap_bf16* out, float* probs, int B, int N, int heads, int hd,
+                      float scale, ap_stream_t stream) {
+    if (!q || !kv || !out || !probs) return AP_ERR_NULL;
+    if (B <= 0 || N <= 0 || heads <= 0) return AP_ERR_SHAPE;
+    if (hd != AHD) return AP_ERR_UNSUPPORTED;
+    const size_t lds = ((size_t)((N + 63) & ~63) + 64 * 32) * sizeof(float);
+    if (lds > 64 * 1024) return AP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_class_attn_fwd, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, out, probs, N, heads, scale);
+    return ap_check_launch();
+}
+
+int ap_class_attn_bwd(const ap_bf16* q, const ap_bf16* kv, const float* probs, const ap_bf16* dout, ap_bf16* dq, ap_bf16* dkv,
+                      int B, int N, int heads, int hd, float scale, ap_stream_t stream) {
+    if (!q || !kv || !probs || !dout || !dq || !dkv) return AP_ERR_NULL;
+    if (B <= 0 || N <= 0 || heads <= 0) return AP_ERR_SHAPE;
+    if (hd != AHD) return AP_ERR_UNSUPPORTED;
+    const size_t lds = ((size_t)((N + 63) & ~63) + 64 * 32) * sizeof(float);
+    if (lds > 64 * 1024) return AP_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_class_attn_bwd, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, probs, dout, dq, dkv, N, heads, scale);
+    return ap_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// Dense soft-target cross entropy, forward + gradient in one pass over (logits, target):
+//   row_loss = lse*sum_c t - sum_c t*x ;  dx = gscale*(softmax(x)*sum_c t - t)
+// (loss/cross_entropy.py:35-36; token-label targets are CLASS-major [B,C,2+N] while logits are
+// token-major [B*N,C], loss/cross_entropy.py:147-148 -- the transpose is done through LDS).
+// HBM-bound: logits 2 B + target 4 B + dlogits 2 B per (row, class).
+//
+// Block = one (batch, tile of TN=16 tokens).  Phase A: the target tile is read coalesced along
+// the token axis (16 consecutive fp32 = 64 B per class) and stored token-major in LDS with an
+// odd row stride.  Phase B: each wave owns 4 rows; lanes stride over classes (coalesced logits),
+// keep the row in registers, reduce max / sum-exp / sum t / sum t*x with wavefront shuffles.
+#include "common.h"
+
+#define CE_TN 16
+#define CE_MAXV 8          // classes per lane pairs: supports C <= 64*2*CE_MAXV = 1024
+
+__global__ void __launch_bounds__(256)
+k_soft_ce(const bf16_t* __restrict__ logits, int ldx, const float* __restrict__ target, int64_t t_sb, int64_t t_sc,
+          int64_t t_sn, int rows_per_batch, float* __restrict__ row_loss, bf16_t* __restrict__ dlogits,
+          float gscale, int64_t M, int C, int tiles_per_batch) {
+    extern __shared__ __attribute__((aligned(16))) float tt[];      // [CE_TN][Cp] Cp odd
+    const int Cp = C | 1;
+    const int64_t b = blockIdx.x / tiles_per_batch;
+    const int n0 = (blockIdx.x % tiles_per_batch) * CE_TN;
+    const int ntok = min(CE_TN, rows_per_batch - n0);
+    // ---- phase A: target tile -> LDS (token-major)
+    {
+        const int tn = threadIdx.x & (CE_TN - 1), cl = threadIdx.x / CE_TN;     // 16 classes per pass
+        const float* tb = target + b * t_sb + (int64_t)(n0 + tn) * t_sn;
+        for (int c = cl; c < C; c += 256 / CE_TN) {
+            if (tn < ntok) tt[tn * Cp + c] = tb[(int64_t)c * t_sc];
+        }
+    }
+    __syncthreads();
+    // ---- phase B
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int tn = wave; tn < ntok; tn += 4) {
+        const int64_t row = b * rows_per_batch + n0 + tn;
+        if (row >= M) break;
+        const bf16_t* xr = logits + row * ldx;
+        const float* tr = tt + tn * Cp;
+        float xv[CE_MAXV][2];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < CE_MAXV; ++i) {
+            const int c = 2 * (lane + 64 * i);
+            if (c + 1 < C) {
+                const unsigned u = *reinterpret_cast<const unsigned*>(xr + c);
+                xv[i][0] = bf_lo(u); xv[i][1] = bf_hi(u);
+                mx = fmaxf(mx, fmaxf(xv[i][0], xv[i][1]));
+            } else if (c < C) {
+                xv[i][0] = bf2f(xr[c]); xv[i][1] = -3.0e38f;
+                mx = fmaxf(mx, xv[i][0]);
+            } else { xv[i][0] = -3.0e38f; xv[i][1] = -3.0e38f; }
+        }
+        mx = group_max<64>(mx);
+        float se = 0.f, st = 0.f, stx = 0.f;
+#pragma unroll
+        for (int i = 0; i < CE_MAXV; ++i) {
+            const int c = 2 * (lane + 64 * i);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (c + k < C) {
+                    const float t = tr[c + k];
+                    se += __expf(xv[i][k] - mx);
+                    st += t;
+                    stx += t * xv[i][k];
+                }
+            }
+        }
+        se = group_sum<64>(se); st = group_sum<64>(st); stx = group_sum<64>(stx);
+        const float lse = mx + __logf(se);
+        if (lane == 0) row_loss[row] = lse * st - stx;
+        bf16_t* dr = dlogits + row * ldx;
+#pragma unroll
+        for (int i = 0; i < CE_MAXV; ++i) {
+            const int c = 2 * (lane + 64 * i);
+            if (c < ldx) {      // ldx is even (multiple of 8): pairs never straddle the row end
+                float d0 = 0.f, d1 = 0.f;
+                if (c < C) d0 = gscale * (__expf(xv[i][0] - lse) * st - tr[c]);
+                if (c + 1 < C) d1 = gscale * (__expf(xv[i][1] - lse) * st - tr[c + 1]);
+                *reinterpret_cast<unsigned*>(dr + c) = pack_bf2(d0, d1);
+            }
+        }
+    }
+}
+
+extern "C" int ap_soft_ce_fwd_bwd(const ap_bf16* logits, int ldx, const float* target, int64_t t_sb, int64_t t_sc,
+                                  int64_t t_sn, int rows_per_batch, float* row_loss, ap_bf16* dlogits,
+                                  float grad_scale, int64_t M, int C, ap_stream_t stream) {
+    if (!logits || !target || !row_loss || !dlogits) return AP_ERR_NULL;
+    if (C <= 0 || ldx < C || (ldx & 7) || rows_per_batch <= 0 || M % rows_per_batch) return AP_ERR_SHAPE;
+    if (ldx > 64 * 2 * CE_MAXV) return AP_ERR_UNSUPPORTED;
+    if (M == 0) return AP_OK;
+    const int tiles = (rows_per_batch + CE_TN - 1) / CE_TN;
+    const int64_t blocks = (M / rows_per_batch) * tiles;
+    const size_t lds = (size_t)CE_TN * (C | 1) * sizeof(float);
+    hipLaunchKernelGGL(k_soft_ce, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, logits, ldx, target, t_sb, t_sc,
+                       t_sn, rows_per_batch, row_loss, dlogits, grad_scale, M, C, tiles);
+    return ap_check_launch();
+}

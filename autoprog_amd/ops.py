@@ -1,0 +1,243 @@
+"""Tensor-level wrappers over the C ABI (include/autoprog_hip.h).
+
+Every function takes/returns torch CUDA tensors, allocates outputs with torch (device memory
+and streams are PyTorch plumbing), and enqueues the gfx950 kernel on the current stream.
+There is no fallback path: a CPU tensor or a missing library raises.
+"""
+import ctypes
+import math
+
+import torch
+
+from ._lib import GemmEpilogue, AutoProgHipError, check, lib
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t, dtype, name):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise AutoProgHipError("%s must be a CUDA tensor (the HIP path has no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise AutoProgHipError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise AutoProgHipError("%s must be contiguous" % name)
+    return t
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------ casts
+def cast_bf16(src):
+    _req(src, torch.float32, "src")
+    dst = torch.empty(src.shape, dtype=BF16, device=src.device)
+    check(lib.ap_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "ap_cast_f32_bf16")
+    return dst
+
+
+def cast_f32(src):
+    _req(src, BF16, "src")
+    dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    check(lib.ap_cast_bf16_f32(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "ap_cast_bf16_f32")
+    return dst
+
+
+def cast_transpose_bf16(w):
+    """fp32 [rows, cols] -> bf16 [cols, round_up(rows, 8)] (pad columns zero)."""
+    _req(w, torch.float32, "w")
+    rows, cols = w.shape
+    ld = round_up(rows, 8)
+    dst = torch.empty((cols, ld), dtype=BF16, device=w.device)
+    check(lib.ap_cast_transpose_f32_bf16(w.data_ptr(), dst.data_ptr(), rows, cols, ld, _stream()), "ap_cast_transpose_f32_bf16")
+    return dst
+
+
+# -------------------------------------------------------------------------------- layernorm
+def layernorm_fwd(x, gamma, beta, eps):
+    _req(x, BF16, "x"); _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.ap_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                               rows, C, float(eps), _stream()), "ap_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta):
+    """dx = dres + dLN/dx ; dgamma/dbeta (fp32) are accumulated in place."""
+    _req(dy, BF16, "dy"); _req(x, BF16, "x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x)
+    check(lib.ap_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                               dres.data_ptr() if dres is not None else None, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                               rows, C, _stream()), "ap_layernorm_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------------- gemm
+def gemm_nt(a, b, n=None, k=None, bias=None, gelu=False, preact_out=None, dgelu_of=None, row_scale=None,
+            rows_per_scale=1, residual=None, out=None, ldc=None):
+    """out[M, :n] = epilogue(a[M, :k] @ b[:n, :k]^T); a/b bf16 2-D (row stride = shape[1])."""
+    _req(a, BF16, "a"); _req(b, BF16, "b")
+    M = a.shape[0]
+    n = b.shape[0] if n is None else n
+    k = a.shape[1] if k is None else k
+    if out is None:
+        ldc = round_up(n, 8) if ldc is None else ldc
+        out = torch.empty((M, ldc), dtype=BF16, device=a.device)
+    else:
+        ldc = out.shape[1]
+    epi = GemmEpilogue()
+    epi.bias = bias.data_ptr() if bias is not None else None
+    epi.gelu = 1 if gelu else 0
+    epi.preact_out = preact_out.data_ptr() if preact_out is not None else None
+    epi.dgelu_of = dgelu_of.data_ptr() if dgelu_of is not None else None
+    epi.row_scale = row_scale.data_ptr() if row_scale is not None else None
+    epi.rows_per_scale = int(rows_per_scale)
+    epi.residual = residual.data_ptr() if residual is not None else None
+    epi.ldr = residual.shape[1] if residual is not None else 0
+    check(lib.ap_gemm_nt(a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1], out.data_ptr(), ldc, M, n, k,
+                         ctypes.byref(epi), _stream()), "ap_gemm_nt")
+    return out
+
+
+def gemm_tn_acc(a, b, c, n1=None, n2=None):
+    """c[:n1, :n2] += a[:, :n1]^T @ b[:, :n2]   (c fp32, accumulated)."""
+    _req(a, BF16, "a"); _req(b, BF16, "b"); _req(c, torch.float32, "c")
+    n1 = c.shape[0] if n1 is None else n1
+    n2 = c.shape[1] if n2 is None else n2
+    check(lib.ap_gemm_tn_acc(a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1], c.data_ptr(), c.shape[1], a.shape[0], n1, n2,
+                             _stream()), "ap_gemm_tn_acc")
+    return c
+
+
+def colsum_acc(a, out, n=None):
+    _req(a, BF16, "a"); _req(out, torch.float32, "out")
+    n = out.numel() if n is None else n
+    check(lib.ap_colsum_acc(a.data_ptr(), a.shape[1], out.data_ptr(), a.shape[0], n, _stream()), "ap_colsum_acc")
+    return out
+
+
+# ---------------------------------------------------------------------------------- outlook
+def outlook_fwd(v, logits, heads, scale):
+    _req(v, BF16, "v"); _req(logits, BF16, "logits")
+    B, H, W, C = v.shape
+    y = torch.empty_like(v)
+    check(lib.ap_outlook_fwd(v.data_ptr(), logits.data_ptr(), logits.shape[-1], y.data_ptr(), B, H, W, heads, C // heads,
+                             float(scale), _stream()), "ap_outlook_fwd")
+    return y
+
+
+def outlook_bwd(v, logits, dy, heads, scale):
+    _req(v, BF16, "v"); _req(logits, BF16, "logits"); _req(dy, BF16, "dy")
+    B, H, W, C = v.shape
+    dv = torch.empty_like(v)
+    dlogits = torch.empty_like(logits)
+    check(lib.ap_outlook_bwd(v.data_ptr(), logits.data_ptr(), logits.shape[-1], dy.data_ptr(), dv.data_ptr(), dlogits.data_ptr(),
+                             B, H, W, heads, C // heads, float(scale), _stream()), "ap_outlook_bwd")
+    return dv, dlogits
+
+
+def avgpool2_fwd(x):
+    _req(x, BF16, "x")
+    B, H, W, C = x.shape
+    y = torch.empty((B, (H + 1) // 2, (W + 1) // 2, C), dtype=BF16, device=x.device)
+    check(lib.ap_avgpool2_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "ap_avgpool2_fwd")
+    return y
+
+
+def avgpool2_bwd_acc(dpooled, dx):
+    _req(dpooled, BF16, "dpooled"); _req(dx, BF16, "dx")
+    B, H, W, C = dx.shape
+    check(lib.ap_avgpool2_bwd_acc(dpooled.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()), "ap_avgpool2_bwd_acc")
+    return dx
+
+
+# ------------------------------------------------------------------------------------- mhsa
+def mhsa_fwd(qkv, B, N, heads, scale):
+    _req(qkv, BF16, "qkv")
+    C = qkv.shape[-1] // 3
+    out = torch.empty((B * N, C), dtype=BF16, device=qkv.device)
+    lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+    check(lib.ap_mhsa_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, heads, C // heads, float(scale), _stream()), "ap_mhsa_fwd")
+    return out, lse
+
+
+def mhsa_bwd(qkv, out, dout, lse, B, N, heads, scale):
+    _req(qkv, BF16, "qkv"); _req(out, BF16, "out"); _req(dout, BF16, "dout")
+    C = qkv.shape[-1] // 3
+    dqkv = torch.empty_like(qkv)
+    check(lib.ap_mhsa_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), B, N, heads, C // heads,
+                          float(scale), _stream()), "ap_mhsa_bwd")
+    return dqkv
+
+
+def class_attn_fwd(q, kv, B, N, heads, scale):
+    _req(q, BF16, "q"); _req(kv, BF16, "kv")
+    C = q.shape[-1]
+    out = torch.empty((B, C), dtype=BF16, device=q.device)
+    probs = torch.empty((B, heads, N), dtype=torch.float32, device=q.device)
+    check(lib.ap_class_attn_fwd(q.data_ptr(), kv.data_ptr(), out.data_ptr(), probs.data_ptr(), B, N, heads, C // heads, float(scale),
+                                _stream()), "ap_class_attn_fwd")
+    return out, probs
+
+
+def class_attn_bwd(q, kv, probs, dout, B, N, heads, scale):
+    _req(dout, BF16, "dout")
+    C = q.shape[-1]
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    check(lib.ap_class_attn_bwd(q.data_ptr(), kv.data_ptr(), probs.data_ptr(), dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(),
+                                B, N, heads, C // heads, float(scale), _stream()), "ap_class_attn_bwd")
+    return dq, dkv
+
+
+# ------------------------------------------------------------------------------ misc fused
+def mix_token_swap(x, r0, r1, c0, c1):
+    _req(x, BF16, "x")
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    check(lib.ap_mix_token_swap(x.data_ptr(), y.data_ptr(), B, H, W, C, int(r0), int(r1), int(c0), int(c1), _stream()), "ap_mix_token_swap")
+    return y
+
+
+def soft_ce_fwd_bwd(logits, C, target, t_sb, t_sc, t_sn, rows_per_batch, grad_scale):
+    """returns (row_loss fp32 [M], dlogits bf16 like logits)."""
+    _req(logits, BF16, "logits")
+    if not (target.is_cuda and target.dtype == torch.float32):
+        raise AutoProgHipError("target must be a CUDA fp32 tensor (any strides; pass them explicitly)")
+    M, ldx = logits.shape
+    row_loss = torch.empty(M, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    check(lib.ap_soft_ce_fwd_bwd(logits.data_ptr(), ldx, target.data_ptr(), int(t_sb), int(t_sc), int(t_sn), int(rows_per_batch),
+                                 row_loss.data_ptr(), dlogits.data_ptr(), float(grad_scale), M, C, _stream()), "ap_soft_ce_fwd_bwd")
+    return row_loss, dlogits
+
+
+def row_scale(x, scale, rows_per_scale):
+    _req(x, BF16, "x"); _req(scale, torch.float32, "scale")
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib.ap_row_scale(x.data_ptr(), scale.data_ptr(), y.data_ptr(), x.numel() // C, C, int(rows_per_scale), _stream()), "ap_row_scale")
+    return y
+
+
+def add_bcast(a, b):
+    _req(a, BF16, "a"); _req(b, BF16, "b")
+    y = torch.empty_like(a)
+    check(lib.ap_add_bcast(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), b.numel(), _stream()), "ap_add_bcast")
+    return y
+
+
+def sum_reps_acc(x, out, reps):
+    _req(x, BF16, "x"); _req(out, torch.float32, "out")
+    check(lib.ap_sum_reps_acc(x.data_ptr(), out.data_ptr(), out.numel(), int(reps), _stream()), "ap_sum_reps_acc")
+    return out

@@ -1,0 +1,132 @@
+/*
+ * autoprog_hip.h -- C ABI of libautoprog_hip.so: the MI355X (gfx950) kernels behind the
+ * AutoProg VOLO/DeiT training hot path.
+ *
+ * The reference (changlin31/AutoProg) has no FFI/plugin ABI: its hot path is Python
+ * nn.Modules calling ATen ops.  This header is therefore
+ * build-defined (row B2); each entry point names the reference call site whose device
+ * arithmetic it replaces (file:line relative to the reference tree).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed for the call; nothing is allocated,
+ *     freed or synchronised inside; work is enqueued on `stream` (a hipStream_t)
+ *   - bf16 tensors are passed as uint16_t*, row-major, leading dimension in ELEMENTS and a
+ *     multiple of 8 (16-byte rows); fp32 statistics / parameters / gradients are float*
+ *   - return 0 on success, a negative AP_ERR_* otherwise (no exceptions cross the ABI)
+ *   - entry points are re-entrant and thread-compatible (no global mutable state)
+ */
+#ifndef AUTOPROG_HIP_H
+#define AUTOPROG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ap_stream_t;          /* hipStream_t */
+typedef uint16_t ap_bf16;
+
+enum {
+    AP_OK = 0,
+    AP_ERR_SHAPE = -1,        /* a size/stride violates the documented constraints */
+    AP_ERR_UNSUPPORTED = -2,  /* valid request outside what the kernels implement  */
+    AP_ERR_LAUNCH = -3,       /* hipGetLastError() != hipSuccess after a launch    */
+    AP_ERR_NULL = -4          /* a required pointer is NULL                         */
+};
+
+int ap_abi_version(void);
+const char* ap_error_string(int code);
+
+/* ---- precision plumbing (apex O1 casts, main_prog.py:491: fp32 master -> 16-bit) ------- */
+int ap_cast_f32_bf16(const float* src, ap_bf16* dst, int64_t n, ap_stream_t stream);
+int ap_cast_bf16_f32(const ap_bf16* src, float* dst, int64_t n, ap_stream_t stream);
+/* dst[c*ld_dst + r] = bf16(src[r*cols + c]); columns rows..ld_dst-1 of dst are zeroed */
+int ap_cast_transpose_f32_bf16(const float* src, ap_bf16* dst, int rows, int cols, int ld_dst, ap_stream_t stream);
+
+/* ---- LayerNorm (nn.LayerNorm: models/volo.py:122,131,213,221,290,297,550) ------------- */
+int ap_layernorm_fwd(const ap_bf16* x, const float* gamma, const float* beta, ap_bf16* y,
+                     float* mean, float* rstd, int64_t rows, int C, float eps, ap_stream_t stream);
+/* dx = dres + d(LN)/dx ; dgamma/dbeta are ACCUMULATED (+=) with fp32 atomics */
+int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* mean,
+                     const float* rstd, const ap_bf16* dres /*nullable*/, ap_bf16* dx,
+                     float* dgamma, float* dbeta, int64_t rows, int C, ap_stream_t stream);
+
+/* ---- Linear layers (nn.Linear: models/volo.py:67,68,71,156,158,180,182,253,256,258,547,553)
+ * C[M,N] = epilogue( A[M,K] . B[N,K]^T )   bf16 in, fp32 MFMA accumulate, bf16 out
+ * epilogue order: +bias[n]; GELU (optionally also storing the pre-activation); * gelu'(h[m,n]);
+ * * row_scale[m / rows_per_scale] (DropPath, timm); + residual[m,n]                         */
+typedef struct ap_gemm_epilogue {
+    const float* bias;          /* [N] or NULL */
+    int gelu;                   /* 1: out = gelu_erf(v) (models/volo.py:157) */
+    ap_bf16* preact_out;        /* with gelu: also store v (pre-activation) here, ld = ldc */
+    const ap_bf16* dgelu_of;    /* out = v * gelu'(dgelu_of[m,n]) (backward of the above), ld = ldc */
+    const float* row_scale;     /* [ceil(M/rows_per_scale)] or NULL */
+    int rows_per_scale;
+    const ap_bf16* residual;    /* [M,N] with leading dimension ldr, or NULL */
+    int ldr;
+} ap_gemm_epilogue;
+int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C, int ldc,
+               int M, int N, int K, const ap_gemm_epilogue* epi, ap_stream_t stream);
+/* weight gradient: C[N1,N2] += A[M,N1]^T . B[M,N2]   (fp32 accumulate into C, atomics) */
+int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* C, int ldc,
+                   int M, int N1, int N2, ap_stream_t stream);
+/* bias gradient: out[n] += sum_m A[m,n] */
+int ap_colsum_acc(const ap_bf16* A, int lda, float* out, int M, int N, ap_stream_t stream);
+
+/* ---- Outlook attention core (models/volo.py:83-98: unfold, softmax, attn@v, fold) -------
+ * v [B,H,W,C], logits [B*h*w, ldl] with channel = head*81 + p*9 + q (kernel 3, pad 1, stride 2),
+ * y [B,H,W,C].  C = heads*hd.                                                               */
+int ap_outlook_fwd(const ap_bf16* v, const ap_bf16* logits, int ldl, ap_bf16* y,
+                   int B, int H, int W, int heads, int hd, float scale, ap_stream_t stream);
+int ap_outlook_bwd(const ap_bf16* v, const ap_bf16* logits, int ldl, const ap_bf16* dy,
+                   ap_bf16* dv, ap_bf16* dlogits, int B, int H, int W, int heads, int hd,
+                   float scale, ap_stream_t stream);
+/* AvgPool2d(2,2,ceil_mode=True) on NHWC tokens (models/volo.py:75,87) */
+int ap_avgpool2_fwd(const ap_bf16* x, ap_bf16* y, int B, int H, int W, int C, ap_stream_t stream);
+/* dx[b,y,x,:] += dpooled[b,y/2,x/2,:] / count */
+int ap_avgpool2_bwd_acc(const ap_bf16* dpooled, ap_bf16* dx, int B, int H, int W, int C, ap_stream_t stream);
+
+/* ---- Multi-head self-attention core (models/volo.py:188-197) ---------------------------
+ * qkv [B,N,3C] packed (channel = which*C + head*hd + d), out [B,N,C], lse [B,heads,N]      */
+int ap_mhsa_fwd(const ap_bf16* qkv, ap_bf16* out, float* lse, int B, int N, int heads, int hd,
+                float scale, ap_stream_t stream);
+int ap_mhsa_bwd(const ap_bf16* qkv, const ap_bf16* out, const ap_bf16* dout, const float* lse,
+                ap_bf16* dqkv, int B, int N, int heads, int hd, float scale, ap_stream_t stream);
+
+/* ---- Class attention core (models/volo.py:264-274): one query per image ----------------
+ * q [B,C] (un-scaled), kv [B,N,2C] (channel = which*C + head*hd + d), out [B,C], probs [B,heads,N] */
+int ap_class_attn_fwd(const ap_bf16* q, const ap_bf16* kv, ap_bf16* out, float* probs,
+                      int B, int N, int heads, int hd, float scale, ap_stream_t stream);
+int ap_class_attn_bwd(const ap_bf16* q, const ap_bf16* kv, const float* probs, const ap_bf16* dout,
+                      ap_bf16* dq, ap_bf16* dkv, int B, int N, int heads, int hd, float scale,
+                      ap_stream_t stream);
+
+/* ---- Mix-token region swap (models/volo.py:654-658, 685-689) ----------------------------
+ * y = x except y[b, r0:r1, c0:c1, :] = x[B-1-b, r0:r1, c0:c1, :]  (x: [B,H,W,C])            */
+int ap_mix_token_swap(const ap_bf16* x, ap_bf16* y, int B, int H, int W, int C,
+                      int r0, int r1, int c0, int c1, ap_stream_t stream);
+
+/* ---- Dense soft-target cross entropy (loss/cross_entropy.py:35-36, 147-156) -------------
+ * logits [M,ldx] (C valid classes); target element (row,c) =
+ *   target[(row / rows_per_batch)*t_sb + c*t_sc + (row % rows_per_batch)*t_sn]   (fp32)
+ * row_loss[row] = -sum_c t*log_softmax(x);  dlogits = grad_scale*(softmax*sum_c t - t)
+ * (columns C..ldx-1 of dlogits are zeroed).                                               */
+int ap_soft_ce_fwd_bwd(const ap_bf16* logits, int ldx, const float* target, int64_t t_sb,
+                       int64_t t_sc, int64_t t_sn, int rows_per_batch, float* row_loss,
+                       ap_bf16* dlogits, float grad_scale, int64_t M, int C, ap_stream_t stream);
+
+/* ---- small fused elementwise helpers ---------------------------------------------------- */
+/* y[m,:] = x[m,:] * scale[m / rows_per_scale] */
+int ap_row_scale(const ap_bf16* x, const float* scale, ap_bf16* y, int64_t M, int C,
+                 int rows_per_scale, ap_stream_t stream);
+/* y = a + b (b broadcast over the leading `reps` copies when b_elems < n) */
+int ap_add_bcast(const ap_bf16* a, const ap_bf16* b, ap_bf16* y, int64_t n, int64_t b_elems, ap_stream_t stream);
+/* out[i] += sum over reps of x[r*n + i]  (fp32 accumulate; gradient of a broadcast add) */
+int ap_sum_reps_acc(const ap_bf16* x, float* out, int64_t n, int reps, ap_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUTOPROG_HIP_H */

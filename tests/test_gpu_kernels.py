@@ -1,0 +1,265 @@
+"""Kernel-level parity: every C-ABI entry point (through autoprog_amd.ops -> ctypes ->
+libautoprog_hip.so) against the CPU oracle on the same seeded, bf16-rounded inputs.
+
+Tolerances: bf16 outputs <= 1e-2 rel-L2 per tensor against
+the fp32/fp64 oracle evaluated on the bf16-rounded inputs (expected ~3e-3 = bf16 rounding of
+the output); fp32-accumulated weight gradients <= 3e-3; integer/bookkeeping ops exact.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+TOL_BF16 = 1e-2
+TOL_F32 = 3e-3
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    from autoprog_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+# ------------------------------------------------------------------------------------------
+def test_abi_loaded(ops):
+    from autoprog_amd._lib import lib, LIB_PATH
+    assert lib.ap_abi_version() == 1
+    assert LIB_PATH.endswith("libautoprog_hip.so")
+
+
+def test_casts(ops):
+    x = torch.randn(1000, 37)
+    y = ops.cast_bf16(dev(x))
+    assert torch.equal(y.cpu(), x.to(torch.bfloat16))
+    assert torch.equal(ops.cast_f32(y).cpu(), x.to(torch.bfloat16).float())
+    w = torch.randn(486, 192)
+    wt = ops.cast_transpose_bf16(dev(w))
+    assert wt.shape == (192, 488)
+    assert torch.equal(wt[:, :486].cpu(), w.t().to(torch.bfloat16))
+    assert float(wt[:, 486:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("rows,C,eps", [(1000, 192, 1e-5), (777, 384, 1e-5), (50, 32, 1e-5), (33, 64, 1e-6), (64, 768, 1e-6),
+                                       (20, 1152, 1e-5)])
+def test_layernorm(ops, rows, C, eps):
+    x = rnd(rows, C, scale=2.0, seed=1) + 0.5
+    g = torch.randn(C, generator=torch.Generator().manual_seed(2)) * 0.3 + 1
+    b = torch.randn(C, generator=torch.Generator().manual_seed(3)) * 0.3
+    dy = rnd(rows, C, seed=4)
+    dres = rnd(rows, C, seed=5)
+    xr = x.double().requires_grad_(True)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = R.layernorm(xr, gr, br, eps)
+    yr.backward(dy.double())
+    y, mean, rstd = ops.layernorm_fwd(dev(x), dev(g), dev(b), eps)
+    assert rel(y, yr) < TOL_BF16
+    dg = torch.zeros(C, device="cuda")
+    db = torch.zeros(C, device="cuda")
+    dx = ops.layernorm_bwd(dev(dy), dev(x), dev(g), mean, rstd, dev(dres), dg, db)
+    assert rel(dx, xr.grad + dres.double()) < TOL_BF16
+    assert rel(dg, gr.grad) < TOL_F32 and rel(db, br.grad) < TOL_F32
+    dx2 = ops.layernorm_bwd(dev(dy), dev(x), dev(g), mean, rstd, None, dg, db)
+    assert rel(dx2, xr.grad) < TOL_BF16
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 192, 192), (300, 486, 192), (128, 1152, 384), (77, 1000, 384),
+                                   (512, 384, 1152), (130, 32, 32), (64, 96, 96), (200, 16, 64), (392, 384, 768)])
+def test_gemm_nt_plain_and_bias(ops, M, N, K):
+    a, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    ref = a.double() @ w.double().t()
+    out = ops.gemm_nt(dev(a), dev(w))
+    assert out.shape == (M, ops.round_up(N, 8))
+    assert rel(out[:, :N], ref) < TOL_BF16
+    out = ops.gemm_nt(dev(a), dev(w), bias=dev(bias))
+    assert rel(out[:, :N], ref + bias.double()) < TOL_BF16
+
+
+def test_gemm_nt_epilogues(ops):
+    M, N, K, rps = 392, 576, 192, 196
+    a, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    res = rnd(M, N, seed=4)
+    rs = torch.tensor([0.0, 1.0 / 0.9])
+    lin = a.double() @ w.double().t() + bias.double()
+    # gelu with pre-activation side output
+    h = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    out = ops.gemm_nt(dev(a), dev(w), bias=dev(bias), gelu=True, preact_out=h)
+    assert rel(h, lin) < TOL_BF16
+    assert rel(out, R.gelu(h.double().cpu())) < TOL_BF16          # activation of the ROUNDED pre-activation
+    # residual + row scale (DropPath)
+    out = ops.gemm_nt(dev(a), dev(w), bias=dev(bias), row_scale=dev(rs), rows_per_scale=rps, residual=dev(res))
+    ref = lin * rs.double().repeat_interleave(rps)[:, None] + res.double()
+    assert rel(out, ref) < TOL_BF16
+    assert torch.equal(out[:rps].cpu(), res[:rps])               # dropped samples pass the residual through exactly
+    # dgelu epilogue
+    hh = rnd(M, N, seed=6)
+    hr = hh.double().requires_grad_(True)
+    R.gelu(hr).backward(torch.ones(M, N, dtype=torch.float64))
+    out = ops.gemm_nt(dev(a), dev(w), dgelu_of=dev(hh))
+    assert rel(out, (a.double() @ w.double().t()) * hr.grad) < TOL_BF16
+
+
+@pytest.mark.parametrize("M,N1,N2", [(1024, 128, 128), (1000, 192, 576), (3000, 486, 192), (25088 // 8, 1152, 384), (130, 1000, 384),
+                                     (77, 32, 96), (500, 16, 64)])
+def test_gemm_tn_acc(ops, M, N1, N2):
+    l1, l2 = ops.round_up(N1, 8), ops.round_up(N2, 8)
+    a, b = rnd(M, l1, seed=1), rnd(M, l2, seed=2)
+    c0 = torch.randn(N1, N2, generator=torch.Generator().manual_seed(3))
+    c = dev(c0)
+    ops.gemm_tn_acc(dev(a), dev(b), c)
+    ref = c0.double() + a[:, :N1].double().t() @ b[:, :N2].double()
+    assert rel(c, ref) < TOL_F32
+
+
+def test_colsum(ops):
+    for M, N in [(1000, 192), (77, 486), (5000, 1000), (10, 16)]:
+        a = rnd(M, ops.round_up(N, 8), seed=M)
+        out = torch.zeros(N, device="cuda")
+        ops.colsum_acc(dev(a), out)
+        assert rel(out, a[:, :N].double().sum(0)) < TOL_F32
+
+
+@pytest.mark.parametrize("B,H,W,heads", [(2, 8, 8, 2), (2, 7, 7, 2), (1, 6, 10, 2), (2, 5, 9, 1), (3, 28, 28, 6), (1, 16, 16, 3), (2, 20, 20, 1)])
+def test_outlook_core(ops, B, H, W, heads):
+    C = heads * 32
+    h, w = (H + 1) // 2, (W + 1) // 2
+    ldl = ops.round_up(heads * 81, 8)
+    v = rnd(B, H, W, C, seed=1)
+    logits = rnd(B * h * w, ldl, scale=2.0, seed=2)
+    dy = rnd(B, H, W, C, seed=3)
+    scale = 32 ** -0.5
+    vr = v.double().requires_grad_(True)
+    lr = logits[:, :heads * 81].double().reshape(B, h, w, heads * 81).requires_grad_(True)
+    yr = R.outlook_core(vr, lr, heads)
+    yr.backward(dy.double())
+    y = ops.outlook_fwd(dev(v), dev(logits), heads, scale)
+    assert rel(y, yr) < TOL_BF16
+    dv, dl = ops.outlook_bwd(dev(v), dev(logits), dev(dy), heads, scale)
+    assert rel(dv, vr.grad) < TOL_BF16
+    assert rel(dl[:, :heads * 81], lr.grad.reshape(B * h * w, heads * 81)) < TOL_BF16
+    if ldl > heads * 81:
+        assert float(dl[:, heads * 81:].float().abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 32), (2, 7, 7, 64), (1, 5, 9, 32), (2, 28, 28, 192)])
+def test_avgpool(ops, B, H, W, C):
+    x = rnd(B, H, W, C, seed=1)
+    xr = x.double().requires_grad_(True)
+    pr = R.avgpool_ceil(xr, 2)
+    dp = rnd(*pr.shape, seed=2)
+    pr.backward(dp.double())
+    p = ops.avgpool2_fwd(dev(x))
+    assert rel(p, pr) < TOL_BF16
+    base = rnd(B, H, W, C, seed=3)
+    dx = dev(base).clone()
+    ops.avgpool2_bwd_acc(dev(dp), dx)
+    assert rel(dx, base.double() + xr.grad) < TOL_BF16
+
+
+@pytest.mark.parametrize("B,N,heads", [(2, 196, 12), (3, 64, 2), (2, 100, 4), (1, 144, 12), (2, 197, 3), (2, 25, 2), (1, 256, 2), (5, 36, 1)])
+def test_mhsa(ops, B, N, heads):
+    C = heads * 32
+    qkv = rnd(B * N, 3 * C, seed=1)
+    do = rnd(B * N, C, seed=2)
+    scale = 32 ** -0.5
+    qr = qkv.double().reshape(B, N, 3 * C).requires_grad_(True)
+    orf = R.mhsa_core(qr, heads)
+    orf.backward(do.double().reshape(B, N, C))
+    o, lse = ops.mhsa_fwd(dev(qkv), B, N, heads, scale)
+    assert rel(o, orf.reshape(B * N, C)) < TOL_BF16
+    q, k, _ = qkv.double().reshape(B, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+    lse_ref = torch.logsumexp(q @ k.transpose(-1, -2) * scale, dim=-1)
+    assert float((lse.cpu().double() - lse_ref).abs().max()) < 2e-3
+    dqkv = ops.mhsa_bwd(dev(qkv), o, dev(do), lse, B, N, heads, scale)
+    g = qr.grad.reshape(B * N, 3, C)
+    d = dqkv.reshape(B * N, 3, C)
+    for i, nm in enumerate("qkv"):
+        assert rel(d[:, i], g[:, i]) < 1.5e-2, nm
+
+
+@pytest.mark.parametrize("B,N,heads", [(2, 197, 12), (3, 65, 2), (4, 17, 1)])
+def test_class_attention(ops, B, N, heads):
+    C = heads * 32
+    q, kv, do = rnd(B, C, seed=1), rnd(B * N, 2 * C, seed=2), rnd(B, C, seed=3)
+    scale = 32 ** -0.5
+    qr = q.double().requires_grad_(True)
+    kvr = kv.double().reshape(B, N, 2, heads, 32).requires_grad_(True)
+    kk, vv = kvr[:, :, 0].transpose(1, 2), kvr[:, :, 1].transpose(1, 2)
+    att = torch.softmax((qr.reshape(B, heads, 1, 32) * scale) @ kk.transpose(-1, -2), dim=-1)
+    orf = (att @ vv).transpose(1, 2).reshape(B, C)
+    orf.backward(do.double())
+    o, probs = ops.class_attn_fwd(dev(q), dev(kv), B, N, heads, scale)
+    assert rel(o, orf) < TOL_BF16
+    assert rel(probs, att.reshape(B, heads, N)) < 1e-3
+    dq, dkv = ops.class_attn_bwd(dev(q), dev(kv), probs, dev(do), B, N, heads, scale)
+    assert rel(dq, qr.grad) < TOL_BF16
+    assert rel(dkv, kvr.grad.reshape(B * N, 2 * C)) < TOL_BF16
+
+
+def test_mix_token_swap_exact(ops):
+    x = rnd(5, 12, 10, 32, seed=1)
+    for box in [(1, 2, 4, 5), (0, 0, 0, 0), (0, 0, 6, 5), (3, 1, 6, 2)]:
+        y = ops.mix_token_swap(dev(x), 2 * box[0], 2 * box[2], 2 * box[1], 2 * box[3])
+        assert torch.equal(y.cpu(), R.mix_token_swap(x, box, 2))
+
+
+@pytest.mark.parametrize("B,N,C", [(4, 196, 1000), (3, 16, 16), (2, 9, 20), (5, 1, 1000), (2, 36, 12)])
+def test_soft_ce(ops, B, N, C):
+    ldx = ops.round_up(C, 8)
+    g = torch.Generator().manual_seed(B * 31 + N)
+    logits = torch.zeros(B * N, ldx, dtype=torch.bfloat16)
+    logits[:, :C] = (torch.randn(B * N, C, generator=g) * 2).to(torch.bfloat16)
+    target = torch.rand(B, C, 2 + N, generator=g) * (torch.rand(B, C, 2 + N, generator=g) < 0.05) + 0.1 / C
+    gs = 0.5 / (B * N)
+    xr = logits[:, :C].double().requires_grad_(True)
+    t_aux = target[:, :, 2:].transpose(1, 2).reshape(-1, C).double()
+    lse = torch.logsumexp(xr, -1, keepdim=True)
+    rows = -(t_aux * (xr - lse)).sum(-1)
+    (rows.sum() * gs).backward()
+    tdev = dev(target)
+    row_loss, dl = ops.soft_ce_fwd_bwd(dev(logits), C, tdev[:, :, 2:], tdev.stride(0), tdev.stride(1), tdev.stride(2), N, gs)
+    assert rel(row_loss, rows) < 1e-4
+    assert rel(dl[:, :C], xr.grad) < TOL_BF16
+    if ldx > C:
+        assert float(dl[:, C:].float().abs().sum()) == 0.0
+    assert abs(float(R.soft_target_ce(xr.detach(), t_aux)) - float(row_loss.double().mean())) < 1e-4
+
+
+def test_small_elementwise(ops):
+    x = rnd(6 * 49, 64, seed=1)
+    sc = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25, 1.25])
+    y = ops.row_scale(dev(x), dev(sc), 49)
+    assert rel(y, x.double() * sc.double().repeat_interleave(49)[:, None]) < 1e-2
+    a, b = rnd(4, 7, 7, 64, seed=2), rnd(1, 7, 7, 64, seed=3)
+    assert rel(ops.add_bcast(dev(a), dev(b)), a.double() + b.double()) < 1e-2
+    out = torch.zeros(7 * 7 * 64, device="cuda")
+    ops.sum_reps_acc(dev(a), out, 4)
+    assert rel(out, a.double().sum(0).reshape(-1)) < 1e-3
+
+
+def test_errors_are_loud(ops):
+    from autoprog_amd._lib import AutoProgHipError
+    with pytest.raises(AutoProgHipError):
+        ops.layernorm_fwd(torch.zeros(4, 64, dtype=torch.bfloat16), torch.ones(64), torch.zeros(64), 1e-5)   # CPU tensor
+    with pytest.raises(AutoProgHipError):
+        ops.mhsa_fwd(torch.zeros(2 * 300, 96, dtype=torch.bfloat16, device="cuda"), 2, 300, 1, 32 ** -0.5)   # N > 256
