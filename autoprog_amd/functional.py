@@ -1,0 +1,394 @@
+"""Autograd layer over the HIP kernels: hand-written forward/backward pairs for the heavy
+blocks (Transformer, Outlooker) plus fine-grained Functions (LayerNorm, Linear, class
+attention, dense CE, mix-token, positional add) used by the thin tail of the network.
+
+Precision contract (the bf16 counterpart of the reference's apex-O1 recipe):
+fp32 master parameters, bf16 activations and bf16 copies of the Linear weights (recast once
+per optimizer step), fp32 MFMA accumulation, fp32 LayerNorm / softmax / loss statistics and
+fp32 parameter gradients.
+"""
+import math
+
+import torch
+
+from . import ops
+from ._lib import AutoProgHipError
+
+BF16 = torch.bfloat16
+
+
+# ------------------------------------------------------------------------------ weight bank
+class _WeightBank:
+    """bf16 (and transposed bf16) copies of fp32 Linear weights, refreshed when the parameter's
+    storage or version counter changes (i.e. after optimizer.step() / load_state_dict()).  Replaces
+    apex's per-call casts.  The copies are stored ON the Parameter object, so they can never
+    outlive it or be confused with another parameter that reuses its address."""
+
+    @staticmethod
+    def _key(p):
+        return (p.data_ptr(), p._version, tuple(p.shape))
+
+    @staticmethod
+    def _flat(p):
+        w = p.detach()
+        return w.reshape(w.shape[0], -1).contiguous()
+
+    def get(self, p):
+        if not isinstance(p, torch.nn.Parameter):      # derived tensor (e.g. permuted conv weight): no caching
+            return ops.cast_bf16(self._flat(p))
+        ent = getattr(p, "_ap_bf16", None)
+        key = self._key(p)
+        if ent is None or ent[0] != key:
+            ent = (key, ops.cast_bf16(self._flat(p)))
+            p._ap_bf16 = ent
+        return ent[1]
+
+    def get_t(self, p):
+        if not isinstance(p, torch.nn.Parameter):
+            return ops.cast_transpose_bf16(self._flat(p))
+        ent = getattr(p, "_ap_bf16_t", None)
+        key = self._key(p)
+        if ent is None or ent[0] != key:
+            ent = (key, ops.cast_transpose_bf16(self._flat(p)))
+            p._ap_bf16_t = ent
+        return ent[1]
+
+    @staticmethod
+    def clear(module):
+        for p in module.parameters():
+            p.__dict__.pop("_ap_bf16", None)
+            p.__dict__.pop("_ap_bf16_t", None)
+
+
+bank = _WeightBank()
+
+
+def _zeros_like_params(params):
+    """one zeroed fp32 slab + per-parameter views (gradient accumulators for one block)"""
+    sizes = [p.numel() if p is not None else 0 for p in params]
+    total = sum(sizes)
+    ref = next(p for p in params if p is not None)
+    slab = torch.zeros(total, dtype=torch.float32, device=ref.device)
+    out, off = [], 0
+    for p, n in zip(params, sizes):
+        out.append(slab[off:off + n].view(p.shape) if p is not None else None)
+        off += n
+    return out
+
+
+def _g2(w):
+    """2-D view of a (possibly conv-shaped) weight gradient buffer"""
+    return w.view(w.shape[0], -1)
+
+
+def _linear_bwd(g, x_in, w, dw, db, n=None, dgelu_of=None, need_dx=True):
+    """shared backward of y = x W^T + b given g = dL/dy (bf16 [M, ld]); accumulates dw/db."""
+    n = w.shape[0] if n is None else n
+    ops.gemm_tn_acc(g, x_in, _g2(dw), n1=n, n2=_g2(dw).shape[1])
+    if db is not None:
+        ops.colsum_acc(g, db, n)
+    if not need_dx:
+        return None
+    wt = bank.get_t(w)                       # [K, ld(N)]
+    return ops.gemm_nt(g, wt, n=wt.shape[0], k=wt.shape[1], dgelu_of=dgelu_of)
+
+
+# ----------------------------------------------------------------------- transformer block
+class TransformerBlockFn(torch.autograd.Function):
+    """x -> x + rs1*(proj(mhsa(qkv(LN1 x)))) -> + rs2*(fc2(gelu(fc1(LN2 .))))
+    (Transformer.forward, models/volo.py:230-234; timm Block for DeiT).  rs1/rs2 are the
+    per-sample DropPath factors (mask/keep) or None."""
+
+    @staticmethod
+    def forward(ctx, x, rs1, rs2, n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b,
+                B, N, heads, eps):
+        C = x.shape[-1]
+        x2 = x.reshape(B * N, C).contiguous()
+        scale = (C // heads) ** -0.5
+        xn1, m1, r1 = ops.layernorm_fwd(x2, n1w, n1b, eps)
+        qkv = ops.gemm_nt(xn1, bank.get(qkv_w), bias=qkv_b)
+        o, lse = ops.mhsa_fwd(qkv, B, N, heads, scale)
+        x1 = ops.gemm_nt(o, bank.get(proj_w), bias=proj_b, row_scale=rs1, rows_per_scale=N, residual=x2)
+        xn2, m2, r2 = ops.layernorm_fwd(x1, n2w, n2b, eps)
+        h = torch.empty((B * N, fc1_w.shape[0]), dtype=BF16, device=x.device)
+        a = ops.gemm_nt(xn2, bank.get(fc1_w), bias=fc1_b, gelu=True, preact_out=h)
+        y = ops.gemm_nt(a, bank.get(fc2_w), bias=fc2_b, row_scale=rs2, rows_per_scale=N, residual=x1)
+        ctx.save_for_backward(x2, m1, r1, xn1, qkv, o, lse, x1, m2, r2, xn2, h, a, rs1, rs2,
+                              n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
+        ctx.cfg = (B, N, heads, scale)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2, m1, r1, xn1, qkv, o, lse, x1, m2, r2, xn2, h, a, rs1, rs2,
+         n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b) = ctx.saved_tensors
+        B, N, heads, scale = ctx.cfg
+        params = (n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
+        (dn1w, dn1b, dqkv_w, dqkv_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = _zeros_like_params(params)
+        dy2 = dy.reshape(x2.shape).contiguous()
+        # MLP branch
+        g2 = ops.row_scale(dy2, rs2, N) if rs2 is not None else dy2
+        dh = _linear_bwd(g2, a, fc2_w, dfc2_w, dfc2_b, dgelu_of=h)
+        dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b)
+        dx1 = ops.layernorm_bwd(dxn2, x1, n2w, m2, r2, dy2, dn2w, dn2b)
+        # attention branch
+        g1 = ops.row_scale(dx1, rs1, N) if rs1 is not None else dx1
+        do = _linear_bwd(g1, o, proj_w, dproj_w, dproj_b)
+        dqkv = ops.mhsa_bwd(qkv, o, do, lse, B, N, heads, scale)
+        dxn1 = _linear_bwd(dqkv, xn1, qkv_w, dqkv_w, dqkv_b)
+        dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b)
+        return (dx.view(dy.shape), None, None, dn1w, dn1b, dqkv_w, dqkv_b, dproj_w, dproj_b, dn2w, dn2b,
+                dfc1_w, dfc1_b, dfc2_w, dfc2_b, None, None, None, None)
+
+
+# ------------------------------------------------------------------------- outlooker block
+class OutlookerBlockFn(torch.autograd.Function):
+    """Outlooker.forward (models/volo.py:140-144) with OutlookAttention (models/volo.py:77-103):
+    x += proj(outlook(v(LN1 x), attn(pool(LN1 x)))) ; x += fc2(gelu(fc1(LN2 x)))."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, v_w, v_b, attn_w, attn_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b,
+                heads, eps):
+        B, H, W, C = x.shape
+        T = B * H * W
+        x2 = x.reshape(T, C).contiguous()
+        scale = (C // heads) ** -0.5
+        xn1, m1, r1 = ops.layernorm_fwd(x2, n1w, n1b, eps)
+        v = ops.gemm_nt(xn1, bank.get(v_w), bias=v_b)
+        pooled = ops.avgpool2_fwd(xn1.view(B, H, W, C))
+        pooled2 = pooled.view(-1, C)
+        logits = ops.gemm_nt(pooled2, bank.get(attn_w), bias=attn_b)                 # [B*h*w, ld(heads*81)]
+        yo = ops.outlook_fwd(v.view(B, H, W, C), logits, heads, scale)
+        x1 = ops.gemm_nt(yo.view(T, C), bank.get(proj_w), bias=proj_b, residual=x2)
+        xn2, m2, r2 = ops.layernorm_fwd(x1, n2w, n2b, eps)
+        h = torch.empty((T, fc1_w.shape[0]), dtype=BF16, device=x.device)
+        a = ops.gemm_nt(xn2, bank.get(fc1_w), bias=fc1_b, gelu=True, preact_out=h)
+        y = ops.gemm_nt(a, bank.get(fc2_w), bias=fc2_b, residual=x1)
+        ctx.save_for_backward(x2, m1, r1, xn1, v, pooled2, logits, yo, x1, m2, r2, xn2, h, a,
+                              n1w, n1b, v_w, v_b, attn_w, attn_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
+        ctx.cfg = (B, H, W, C, heads, scale)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2, m1, r1, xn1, v, pooled2, logits, yo, x1, m2, r2, xn2, h, a,
+         n1w, n1b, v_w, v_b, attn_w, attn_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b) = ctx.saved_tensors
+        B, H, W, C, heads, scale = ctx.cfg
+        T = B * H * W
+        params = (n1w, n1b, v_w, v_b, attn_w, attn_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
+        (dn1w, dn1b, dv_w, dv_b, dattn_w, dattn_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = _zeros_like_params(params)
+        dy2 = dy.reshape(T, C).contiguous()
+        dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, dgelu_of=h)
+        dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b)
+        dx1 = ops.layernorm_bwd(dxn2, x1, n2w, m2, r2, dy2, dn2w, dn2b)
+        dyo = _linear_bwd(dx1, yo.view(T, C), proj_w, dproj_w, dproj_b)
+        dv, dlogits = ops.outlook_bwd(v.view(B, H, W, C), logits, dyo.view(B, H, W, C), heads, scale)
+        dpooled = _linear_bwd(dlogits, pooled2, attn_w, dattn_w, dattn_b, n=attn_w.shape[0])
+        dxn1 = _linear_bwd(dv.view(T, C), xn1, v_w, dv_w, dv_b)
+        ops.avgpool2_bwd_acc(dpooled.view(B, (H + 1) // 2, (W + 1) // 2, C), dxn1.view(B, H, W, C))
+        dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b)
+        return (dx.view(dy.shape), dn1w, dn1b, dv_w, dv_b, dattn_w, dattn_b, dproj_w, dproj_b, dn2w, dn2b,
+                dfc1_w, dfc1_b, dfc2_w, dfc2_b, None, None)
+
+
+# --------------------------------------------------------------------- fine-grained pieces
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        xc = x.contiguous()
+        y, m, r = ops.layernorm_fwd(xc, w, b, eps)
+        ctx.save_for_backward(xc, w, m, r)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, w, m, r = ctx.saved_tensors
+        dw = torch.zeros_like(w)
+        db = torch.zeros_like(w)
+        dx = ops.layernorm_bwd(dy.contiguous(), xc, w, m, r, None, dw, db)
+        return dx, dw, db, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = [gelu](x W^T + b) on bf16 activations; W may be conv-shaped ([N, ...] flattened)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gelu):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K).contiguous()
+        N = w.shape[0]
+        h = torch.empty((x2.shape[0], ops.round_up(N, 8)), dtype=BF16, device=x.device) if gelu else None
+        y = ops.gemm_nt(x2, bank.get(w), n=N, k=K, bias=b, gelu=gelu, preact_out=h)
+        ctx.save_for_backward(x2, w, b, h)
+        ctx.lead = x.shape[:-1]
+        ctx.gelu = gelu
+        out = y.view(*x.shape[:-1], y.shape[-1])
+        return out if y.shape[-1] == N else out[..., :N]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, b, h = ctx.saved_tensors
+        N = w.shape[0]
+        ld = ops.round_up(N, 8)
+        g = dy.reshape(-1, N)
+        if ld != N:                                   # test-size heads: re-pad the gradient rows
+            gp = torch.zeros((g.shape[0], ld), dtype=BF16, device=g.device)
+            gp[:, :N] = g
+            g = gp
+        g = g.contiguous()
+        if ctx.gelu:                                  # dL/dh = dL/da * gelu'(h): identity-weight GEMM is wasteful; do it in torch
+            hf = h.float()
+            cdf = 0.5 * (1.0 + torch.erf(hf * 0.7071067811865476))
+            pdf = torch.exp(-0.5 * hf * hf) * 0.3989422804014327
+            g = (g.float() * (cdf + hf * pdf)).to(BF16)
+        dw = torch.zeros_like(w)
+        db = torch.zeros_like(b) if b is not None else None
+        dx = _linear_bwd(g, x2, w, dw, db, n=N, need_dx=ctx.needs_input_grad[0])
+        if dx is not None:
+            dx = dx[:, :x2.shape[1]] if dx.shape[1] != x2.shape[1] else dx
+            dx = dx.reshape(*ctx.lead, x2.shape[1])
+        return dx, dw, db, None
+
+
+class ClassAttnFn(torch.autograd.Function):
+    """ClassAttention core (models/volo.py:264-274): q [B,C] (un-scaled), kv [B,N,2C]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads):
+        B, N, C2 = kv.shape
+        qc, kvc = q.contiguous(), kv.contiguous()
+        scale = (C2 // 2 // heads) ** -0.5
+        o, probs = ops.class_attn_fwd(qc, kvc.view(B * N, C2), B, N, heads, scale)
+        ctx.save_for_backward(qc, kvc, probs)
+        ctx.cfg = (B, N, heads, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qc, kvc, probs = ctx.saved_tensors
+        B, N, heads, scale = ctx.cfg
+        dq, dkv = ops.class_attn_bwd(qc, kvc.view(B * N, -1), probs, do.contiguous(), B, N, heads, scale)
+        return dq, dkv.view(kvc.shape), None
+
+
+class MixSwapFn(torch.autograd.Function):
+    """y[b, r0:r1, c0:c1] = x[B-1-b, r0:r1, c0:c1] (models/volo.py:654-658, 685-689); the
+    backward is the same permutation."""
+
+    @staticmethod
+    def forward(ctx, x, r0, r1, c0, c1):
+        ctx.box = (r0, r1, c0, c1)
+        return ops.mix_token_swap(x.contiguous(), r0, r1, c0, c1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.mix_token_swap(dy.contiguous(), *ctx.box), None, None, None, None
+
+
+class AddPosFn(torch.autograd.Function):
+    """x [B,h,w,C] bf16 + pos [1,h,w,C] fp32 (models/volo.py:627-629)."""
+
+    @staticmethod
+    def forward(ctx, x, pos):
+        ctx.pos_shape = pos.shape
+        ctx.B = x.shape[0]
+        return ops.add_bcast(x.contiguous(), ops.cast_bf16(pos.contiguous()))
+
+    @staticmethod
+    def backward(ctx, dy):
+        dpos = torch.zeros(ctx.pos_shape, dtype=torch.float32, device=dy.device)
+        dyc = dy.contiguous()
+        ops.sum_reps_acc(dyc, dpos, ctx.B)
+        return dyc, dpos
+
+
+class SoftTargetCEFn(torch.autograd.Function):
+    """mean over rows of -sum_c t*log_softmax(x) (loss/cross_entropy.py:35-36) with the
+    gradient produced in the same pass.  target is addressed through explicit strides so the
+    class-major token-label tensor [B,C,2+N] is consumed in place (loss/cross_entropy.py:147-148)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, t_sb, t_sc, t_sn, rows_per_batch):
+        M, C = logits.shape
+        ld = ops.round_up(C, 8)
+        if ld != C or not logits.is_contiguous():
+            xp = torch.zeros((M, ld), dtype=BF16, device=logits.device)
+            xp[:, :C] = logits
+        else:
+            xp = logits
+        row_loss, dl = ops.soft_ce_fwd_bwd(xp, C, target, t_sb, t_sc, t_sn, rows_per_batch, 1.0 / M)
+        ctx.save_for_backward(dl)
+        ctx.C = C
+        return row_loss.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        M = dl.shape[0]
+        out = ops.row_scale(dl, g.reshape(1).float().contiguous(), M)
+        return (out if out.shape[1] == ctx.C else out[:, :ctx.C]), None, None, None, None, None
+
+
+class OutlookCoreFn(torch.autograd.Function):
+    """unfold -> softmax -> attn@v -> fold (models/volo.py:83-98) on v [B,H,W,C], logits [B*h*w, ld]."""
+
+    @staticmethod
+    def forward(ctx, v, logits, heads):
+        vc, lc = v.contiguous(), logits.contiguous()
+        scale = (v.shape[-1] // heads) ** -0.5
+        ctx.save_for_backward(vc, lc)
+        ctx.cfg = (heads, scale)
+        return ops.outlook_fwd(vc, lc, heads, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        vc, lc = ctx.saved_tensors
+        heads, scale = ctx.cfg
+        dv, dl = ops.outlook_bwd(vc, lc, dy.contiguous(), heads, scale)
+        return dv, dl, None
+
+
+class AvgPool2Fn(torch.autograd.Function):
+    """AvgPool2d(2,2,ceil_mode=True) on NHWC tokens (models/volo.py:75,87)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return ops.avgpool2_fwd(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dp):
+        dx = torch.zeros(ctx.shape, dtype=BF16, device=dp.device)
+        return ops.avgpool2_bwd_acc(dp.contiguous(), dx)
+
+
+class MhsaFn(torch.autograd.Function):
+    """softmax(q k^T scale) v on packed qkv [B*N, 3C] (models/volo.py:188-197)."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, N, heads):
+        qc = qkv.contiguous()
+        scale = (qc.shape[-1] // 3 // heads) ** -0.5
+        o, lse = ops.mhsa_fwd(qc, B, N, heads, scale)
+        ctx.save_for_backward(qc, o, lse)
+        ctx.cfg = (B, N, heads, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qc, o, lse = ctx.saved_tensors
+        B, N, heads, scale = ctx.cfg
+        return ops.mhsa_bwd(qc, o, do.contiguous(), lse, B, N, heads, scale), None, None, None
+
+
+def to_bf16(x):
+    """fp32/bf16 torch tensor -> contiguous bf16 (autograd-aware torch cast: stem boundary)"""
+    return x.to(BF16).contiguous()
+
+
+def layer_norm(x, w, b, eps):
+    return LayerNormFn.apply(x, w, b, eps)
+
+
+def linear(x, w, b=None, gelu=False):
+    return LinearFn.apply(x, w, b, gelu)

@@ -1,0 +1,536 @@
+"""VOLO on MI355X: host-side mirror of the reference model API (models/volo.py) whose
+arithmetic runs in the gfx950 HIP kernels of libautoprog_hip.so.
+
+Same constructor signatures, parameter names (state-dict keys), forward contracts and
+`set_sample_config` as the reference, so `main_prog.py` / `prog/helpers.py`-style drivers can
+use it as a drop-in; elastic depth / resolution / token count are launch-time arguments of the
+kernels (no weight copies): a supernet keeps all layers and a per-step `ActiveLayerMask`
+selects the active ones.
+
+Activations are bf16 token-major ([B,H,W,C] / [B,N,C]); parameters stay fp32.  The conv stem
+(reference PatchEmbed) runs through torch.nn.functional convolutions (MIOpen) in channels_last
+bf16 -- SURVEY.md section 8 row A8/N3 schedules a hand-written implicit-GEMM for a later round.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as AF
+from ..prog.helpers import ActiveLayerMask
+from .registry import register_model
+
+IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
+BF16 = torch.bfloat16
+
+
+def _cfg(url="", **kwargs):
+    cfg = dict(url=url, num_classes=1000, input_size=(3, 224, 224), pool_size=None, crop_pct=0.96,
+               interpolation="bicubic", mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD,
+               first_conv="patch_embed.proj", classifier="head")
+    cfg.update(kwargs)
+    return cfg
+
+
+default_cfgs = {"volo": _cfg(crop_pct=0.96), "volo_large": _cfg(crop_pct=1.15)}
+
+
+def trunc_normal_(t, std=0.02):
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+def _bf16(x):
+    return x if x.dtype == BF16 else x.to(BF16)
+
+
+class DropPathRng:
+    """source of the per-sample DropPath factors mask/keep (timm DropPath: mask = floor(keep+U)).
+    Masks can be injected for parity runs via `queue`."""
+
+    def __init__(self):
+        self.queue = []
+
+    def draw(self, batch, keep, device):
+        if self.queue:
+            m = self.queue.pop(0)
+            return (m.to(device=device, dtype=torch.float32) / keep).contiguous()
+        return ((keep + torch.rand(batch, device=device)).floor_() / keep).contiguous()
+
+
+class Mlp(nn.Module):
+    """fc2(gelu(fc1(x))) -- reference Mlp (models/volo.py:147-167); dropout p is 0 on this path."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        if drop:
+            raise NotImplementedError("the HIP path implements drop=0 (all shipped configs)")
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, out_features)
+
+    def forward(self, x):
+        h = AF.linear(_bf16(x), self.fc1.weight, self.fc1.bias, gelu=True)
+        return AF.linear(h, self.fc2.weight, self.fc2.bias)
+
+
+class OutlookAttention(nn.Module):
+    """reference OutlookAttention (models/volo.py:48-103); kernel 3 / padding 1 / stride 2."""
+
+    def __init__(self, dim, num_heads, kernel_size=3, padding=1, stride=1, qkv_bias=False, qk_scale=None,
+                 attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        if (kernel_size, padding, stride) != (3, 1, 2):
+            raise NotImplementedError("HIP outlook attention implements kernel 3, padding 1, stride 2 (every VOLO config)")
+        if qk_scale is not None or attn_drop or proj_drop:
+            raise NotImplementedError("qk_scale/attn_drop/proj_drop are not used by any shipped config")
+        self.num_heads = num_heads
+        self.kernel_size, self.padding, self.stride = kernel_size, padding, stride
+        self.scale = (dim // num_heads) ** -0.5
+        self.v = nn.Linear(dim, dim, bias=qkv_bias)
+        self.attn = nn.Linear(dim, kernel_size ** 4 * num_heads)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        x = _bf16(x)
+        B, H, W, C = x.shape
+        v = AF.linear(x, self.v.weight, self.v.bias)
+        pooled = AF.AvgPool2Fn.apply(x)
+        n_out = self.attn.weight.shape[0]
+        logits = AF.linear(pooled.reshape(-1, C), self.attn.weight, self.attn.bias)
+        if logits.shape[-1] % 8:                      # the kernel wants 16-byte rows
+            pad = torch.zeros(logits.shape[0], (-n_out) % 8, dtype=BF16, device=x.device)
+            logits = torch.cat([logits, pad], dim=1)
+        y = AF.OutlookCoreFn.apply(v, logits, self.num_heads)
+        return AF.linear(y, self.proj.weight, self.proj.bias)
+
+
+class Outlooker(nn.Module):
+    """reference Outlooker (models/volo.py:106-144): fused into one forward/backward pair."""
+
+    def __init__(self, dim, kernel_size, padding, stride=1, num_heads=1, mlp_ratio=3.0, attn_drop=0.0, drop_path=0.0,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm, qkv_bias=False, qk_scale=None):
+        super().__init__()
+        if drop_path:
+            raise NotImplementedError("outlooker blocks never receive drop_path in the reference (SURVEY.md 0.1-8)")
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = OutlookAttention(dim, num_heads, kernel_size=kernel_size, padding=padding, stride=stride,
+                                     qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
+        self.is_identity_layer = False
+
+    def set_sample_config(self, is_identity_layer=False):
+        self.is_identity_layer = is_identity_layer
+
+    def forward(self, x):
+        if self.is_identity_layer:
+            return x
+        a, m = self.attn, self.mlp
+        return AF.OutlookerBlockFn.apply(_bf16(x), self.norm1.weight, self.norm1.bias, a.v.weight, a.v.bias, a.attn.weight,
+                                         a.attn.bias, a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias,
+                                         m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, a.num_heads, self.norm1.eps)
+
+
+class Attention(nn.Module):
+    """reference Attention (models/volo.py:170-201), standalone form."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        if qk_scale is not None or attn_drop or proj_drop:
+            raise NotImplementedError("qk_scale/attn_drop/proj_drop are not used by any shipped config")
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        x = _bf16(x)
+        shape = x.shape
+        B, C = shape[0], shape[-1]
+        N = x.numel() // (B * C)
+        qkv = AF.linear(x.reshape(B * N, C), self.qkv.weight, self.qkv.bias)
+        o = AF.MhsaFn.apply(qkv, B, N, self.num_heads)
+        return AF.linear(o, self.proj.weight, self.proj.bias).reshape(shape)
+
+
+class Transformer(nn.Module):
+    """reference Transformer (models/volo.py:204-234): pre-LN block with per-sample DropPath,
+    executed as one fused forward/backward pair."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, attn_drop=0.0, drop_path=0.0,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm, eps=1e-5):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop)
+        self.drop_prob = float(drop_path)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
+        self.is_identity_layer = False
+        self.rng = None                 # DropPathRng shared by the owning model
+
+    def set_sample_config(self, is_identity_layer=False):
+        self.is_identity_layer = is_identity_layer
+
+    def forward(self, x):
+        if self.is_identity_layer:
+            return x
+        x = _bf16(x)
+        B, C = x.shape[0], x.shape[-1]
+        N = x.numel() // (B * C)
+        rs1 = rs2 = None
+        if self.training and self.drop_prob > 0.0:
+            rng = self.rng or _default_rng
+            rs1 = rng.draw(B, 1.0 - self.drop_prob, x.device)
+            rs2 = rng.draw(B, 1.0 - self.drop_prob, x.device)
+        a, m = self.attn, self.mlp
+        return AF.TransformerBlockFn.apply(x, rs1, rs2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,
+                                           a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight,
+                                           m.fc1.bias, m.fc2.weight, m.fc2.bias, B, N, a.num_heads, self.norm1.eps)
+
+
+_default_rng = DropPathRng()
+
+
+class ClassAttention(nn.Module):
+    """reference ClassAttention (models/volo.py:237-277): token 0 queries all tokens."""
+
+    def __init__(self, dim, num_heads=8, head_dim=None, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_dim = head_dim if head_dim is not None else dim // num_heads
+        if qk_scale is not None or attn_drop or proj_drop:
+            raise NotImplementedError("qk_scale/attn_drop/proj_drop are not used by any shipped config")
+        self.scale = self.head_dim ** -0.5
+        inner = self.head_dim * self.num_heads
+        self.kv = nn.Linear(dim, inner * 2, bias=qkv_bias)
+        self.q = nn.Linear(dim, inner, bias=qkv_bias)
+        self.proj = nn.Linear(inner, dim)
+
+    def forward(self, x):
+        x = _bf16(x)
+        B, N, C = x.shape
+        kv = AF.linear(x.reshape(B * N, C), self.kv.weight, self.kv.bias).reshape(B, N, -1)
+        q = AF.linear(x[:, 0], self.q.weight, self.q.bias)
+        o = AF.ClassAttnFn.apply(q, kv, self.num_heads)
+        return AF.linear(o, self.proj.weight, self.proj.bias).unsqueeze(1)
+
+
+class ClassBlock(nn.Module):
+    """reference ClassBlock (models/volo.py:280-308): only the class token is updated."""
+
+    def __init__(self, dim, num_heads, head_dim=None, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0,
+                 drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        if drop_path or drop:
+            raise NotImplementedError("class blocks use drop_path=0, drop=0 in the reference (models/volo.py:529)")
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = ClassAttention(dim, num_heads=num_heads, head_dim=head_dim, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                   attn_drop=attn_drop, proj_drop=drop)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
+
+    def forward_cls(self, x):
+        """x [B,1+N,C] -> updated class token [B,1,C]"""
+        x = _bf16(x)
+        cls = x[:, :1] + self.attn(AF.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps))
+        return cls + self.mlp(AF.layer_norm(cls, self.norm2.weight, self.norm2.bias, self.norm2.eps))
+
+    def forward(self, x):
+        return torch.cat([self.forward_cls(x), x[:, 1:]], dim=1)
+
+
+def get_block(block_type, **kargs):
+    if block_type == "ca":
+        return ClassBlock(**kargs)
+    raise ValueError("unknown post block %r" % (block_type,))
+
+
+def rand_bbox(size, lam, scale=1):
+    """reference rand_bbox (models/volo.py:319-339).  `size` is the [B,H,W,C] token shape; the
+    first box axis runs over H although it is called W there.  Uses the global numpy RNG in the
+    reference's call order (randint(W) then randint(H)) so seeded runs reproduce its boxes."""
+    gw = size[1] // scale
+    gh = size[2] // scale
+    ratio = np.sqrt(1.0 - lam)
+    cw, ch = int(gw * ratio), int(gh * ratio)
+    cx = np.random.randint(gw)
+    cy = np.random.randint(gh)
+    return (int(np.clip(cx - cw // 2, 0, gw)), int(np.clip(cy - ch // 2, 0, gh)),
+            int(np.clip(cx + cw // 2, 0, gw)), int(np.clip(cy + ch // 2, 0, gh)))
+
+
+class PatchEmbed(nn.Module):
+    """reference PatchEmbed (models/volo.py:342-380): conv7x7/s -> BN -> ReLU -> 2x(conv3x3 -> BN ->
+    ReLU) -> conv(patch/s).  Runs in bf16 channels_last through MIOpen (row N3: HIP later)."""
+
+    def __init__(self, img_size=224, stem_conv=False, stem_stride=1, patch_size=8, in_chans=3, hidden_dim=64, embed_dim=384):
+        super().__init__()
+        assert patch_size in [4, 8, 16]
+        self.stem_conv = stem_conv
+        if stem_conv:
+            self.conv = nn.Sequential(
+                nn.Conv2d(in_chans, hidden_dim, kernel_size=7, stride=stem_stride, padding=3, bias=False),
+                nn.BatchNorm2d(hidden_dim), nn.ReLU(inplace=True),
+                nn.Conv2d(hidden_dim, hidden_dim, kernel_size=3, stride=1, padding=1, bias=False),
+                nn.BatchNorm2d(hidden_dim), nn.ReLU(inplace=True),
+                nn.Conv2d(hidden_dim, hidden_dim, kernel_size=3, stride=1, padding=1, bias=False),
+                nn.BatchNorm2d(hidden_dim), nn.ReLU(inplace=True))
+        self.proj = nn.Conv2d(hidden_dim, embed_dim, kernel_size=patch_size // stem_stride, stride=patch_size // stem_stride)
+        self.num_patches = (img_size // patch_size) * (img_size // patch_size)
+
+    def forward(self, x):
+        """[B,3,r,r] -> NCHW feature map (channels_last memory, bf16)"""
+        if not x.is_cuda:
+            raise RuntimeError("autoprog_amd models run on the GPU only (no CPU fallback)")
+        x = x.contiguous(memory_format=torch.channels_last)
+        with torch.autocast("cuda", dtype=BF16):
+            if self.stem_conv:
+                x = self.conv(x)
+            x = self.proj(x)
+        return x
+
+
+class Downsample(nn.Module):
+    """reference Downsample (models/volo.py:383-396): conv k=s=patch on NHWC tokens, executed as a
+    patch-gather + MFMA GEMM."""
+
+    def __init__(self, in_embed_dim, out_embed_dim, patch_size):
+        super().__init__()
+        self.proj = nn.Conv2d(in_embed_dim, out_embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.k = patch_size
+
+    def forward(self, x):
+        x = _bf16(x)
+        B, H, W, C = x.shape
+        k = self.k
+        h, w = H // k, W // k
+        patches = x[:, :h * k, :w * k].reshape(B, h, k, w, k, C).permute(0, 1, 3, 2, 4, 5).reshape(B, h, w, k * k * C)
+        wmat = self.proj.weight.permute(0, 2, 3, 1).reshape(self.proj.weight.shape[0], k * k * C)     # (ky,kx,cin)
+        return AF.linear(patches, wmat, self.proj.bias)
+
+
+def _stage_dpr(drop_path_rate, block_idx, index, layers):
+    return drop_path_rate * (block_idx + sum(layers[:index])) / (sum(layers) - 1)
+
+
+def outlooker_blocks(block_fn, index, dim, layers, num_heads=1, kernel_size=3, padding=1, stride=1, mlp_ratio=3.0,
+                     qkv_bias=False, qk_scale=None, attn_drop=0, drop_path_rate=0.0, **kwargs):
+    """stage-1 builder (models/volo.py:399-417).  Like the reference, the VOLO constructor does not
+    forward drop_path_rate here, so outlookers run without DropPath."""
+    blocks = [block_fn(dim, kernel_size=kernel_size, padding=padding, stride=stride, num_heads=num_heads, mlp_ratio=mlp_ratio,
+                       qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                       drop_path=_stage_dpr(drop_path_rate, i, index, layers) if drop_path_rate else 0.0)
+              for i in range(layers[index])]
+    return nn.Sequential(*blocks)
+
+
+def transformer_blocks(block_fn, index, dim, layers, num_heads, mlp_ratio=3.0, qkv_bias=False, qk_scale=None, attn_drop=0,
+                       drop_path_rate=0.0, **kwargs):
+    """stage-2 builder (models/volo.py:420-441): linearly increasing DropPath rate per block."""
+    blocks = [block_fn(dim, num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                       drop_path=_stage_dpr(drop_path_rate, i, index, layers) if drop_path_rate else 0.0)
+              for i in range(layers[index])]
+    return nn.Sequential(*blocks)
+
+
+class VOLO(nn.Module):
+    """reference VOLO (models/volo.py:444-694) with the same constructor and outputs:
+    train -> (x_cls [B,classes], x_aux [B,N,classes], (bbx1,bby1,bbx2,bby2)); eval -> x_cls + 0.5*max_n x_aux."""
+
+    def __init__(self, layers, img_size=224, in_chans=3, num_classes=1000, patch_size=8, stem_hidden_dim=64, embed_dims=None,
+                 num_heads=None, downsamples=None, outlook_attention=None, mlp_ratios=None, qkv_bias=False, qk_scale=None,
+                 drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, norm_layer=nn.LayerNorm, post_layers=None,
+                 return_mean=False, return_dense=True, mix_token=True, pooling_scale=2, out_kernel=3, out_stride=2, out_padding=1):
+        super().__init__()
+        if drop_rate or attn_drop_rate:
+            raise NotImplementedError("drop_rate/attn_drop_rate are 0 in every shipped config; not implemented on the HIP path")
+        self.num_classes = num_classes
+        self.embed_dim = embed_dims[-1]
+        self.layers = list(layers)
+        self.patch_embed = PatchEmbed(stem_conv=True, stem_stride=2, patch_size=patch_size, in_chans=in_chans,
+                                      hidden_dim=stem_hidden_dim, embed_dim=embed_dims[0])
+        grid = img_size // patch_size // pooling_scale
+        self.pos_embed = nn.Parameter(torch.zeros(1, grid, grid, embed_dims[-1]))
+        self.drop_path_rng = DropPathRng()
+        network = []
+        for i in range(len(layers)):
+            if outlook_attention[i]:
+                stage = outlooker_blocks(Outlooker, i, embed_dims[i], layers, num_heads=num_heads[i], kernel_size=out_kernel,
+                                         stride=out_stride, padding=out_padding, mlp_ratio=mlp_ratios[i], qkv_bias=qkv_bias,
+                                         qk_scale=qk_scale, attn_drop=attn_drop_rate)
+            else:
+                stage = transformer_blocks(Transformer, i, embed_dims[i], layers, num_heads[i], mlp_ratio=mlp_ratios[i],
+                                           qkv_bias=qkv_bias, qk_scale=qk_scale, drop_path_rate=drop_path_rate,
+                                           attn_drop=attn_drop_rate)
+                for blk in stage:
+                    blk.rng = self.drop_path_rng
+            network.append(stage)
+            if downsamples[i]:
+                network.append(Downsample(embed_dims[i], embed_dims[i + 1], 2))
+        self.network = nn.ModuleList(network)
+        self.post_network = None
+        if post_layers is not None:
+            self.post_network = nn.ModuleList([
+                get_block(post_layers[i], dim=embed_dims[-1], num_heads=num_heads[-1], mlp_ratio=mlp_ratios[-1],
+                          qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop_rate, drop_path=0.0)
+                for i in range(len(post_layers))])
+            self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dims[-1]))
+            trunc_normal_(self.cls_token, std=0.02)
+        self.return_mean = return_mean
+        self.return_dense = return_dense
+        if return_dense:
+            assert not return_mean, "cannot return both mean and dense"
+        self.mix_token = mix_token
+        self.pooling_scale = pooling_scale
+        if mix_token:
+            self.beta = 1.0
+            assert return_dense, "return all tokens if mix_token is enabled"
+        if return_dense:
+            self.aux_head = nn.Linear(embed_dims[-1], num_classes) if num_classes > 0 else nn.Identity()
+        self.norm = nn.LayerNorm(embed_dims[-1])
+        self.head = nn.Linear(embed_dims[-1], num_classes) if num_classes > 0 else nn.Identity()
+        trunc_normal_(self.pos_embed, std=0.02)
+        self.apply(self._init_weights)
+        self.active_layers = None          # ActiveLayerMask of the current elastic config (None = all)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token"}
+
+    def get_classifier(self):
+        return self.head
+
+    def reset_classifier(self, num_classes):
+        self.num_classes = num_classes
+        self.head = nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+
+    # ---- elastic depth: one explicit mask object shared with extraction code
+    def set_sample_config(self, config: dict):
+        mask = ActiveLayerMask(config["layer_num"], config["min_layer_num"], config["max_layer_num"])
+        real_stage = 0
+        for stage in self.network:
+            if isinstance(stage, (nn.Sequential, nn.ModuleList)):
+                for idx, blk in enumerate(stage):
+                    blk.set_sample_config(is_identity_layer=mask.is_identity(real_stage, idx))
+                real_stage += 1
+        self.active_layers = mask
+        return mask
+
+    def interpolate_pos_encoding(self, x):
+        """reference VOLO.interpolate_pos_encoding (models/volo.py:580-596), fp32 on the host grid"""
+        h0, w0 = x.shape[1], x.shape[2]
+        h, w = self.pos_embed.shape[1], self.pos_embed.shape[2]
+        if h == h0 and w == w0:
+            return self.pos_embed
+        pos = F.interpolate(self.pos_embed.permute(0, 3, 1, 2), scale_factor=((h0 + 0.1) / h, (w0 + 0.1) / w), mode="bicubic")
+        assert int(w0 + 0.1) == pos.shape[-1] and int(h0 + 0.1) == pos.shape[-2]
+        return pos.permute(0, 2, 3, 1)
+
+    def forward_embeddings(self, x):
+        x = self.patch_embed(x)                 # NCHW logical, channels_last memory
+        return x.permute(0, 2, 3, 1).to(BF16).contiguous()     # [B,H,W,C] token-major (no copy if already NHWC)
+
+    def forward_tokens(self, x):
+        for idx, block in enumerate(self.network):
+            if idx == 2:
+                x = AF.AddPosFn.apply(x, self.interpolate_pos_encoding(x))
+            x = block(x)
+        B, H, W, C = x.shape
+        return x.reshape(B, H * W, C)
+
+    def forward_cls(self, x):
+        B = x.shape[0]
+        cls = self.cls_token.expand(B, -1, -1).to(BF16)
+        for block in self.post_network:
+            cls = block.forward_cls(torch.cat([cls, x], dim=1))
+        return cls, x
+
+    def forward(self, x):
+        x = self.forward_embeddings(x)
+        patch_h = patch_w = 0
+        if self.mix_token and self.training:
+            lam = np.random.beta(self.beta, self.beta)
+            patch_h, patch_w = x.shape[1] // self.pooling_scale, x.shape[2] // self.pooling_scale
+            bbx1, bby1, bbx2, bby2 = rand_bbox(x.size(), lam, scale=self.pooling_scale)
+            s = self.pooling_scale
+            x = AF.MixSwapFn.apply(x, s * bbx1, s * bbx2, s * bby1, s * bby2)
+        else:
+            bbx1, bby1, bbx2, bby2 = 0, 0, 0, 0
+        x = self.forward_tokens(x)                                      # [B,N,C]
+        if self.post_network is not None:
+            cls, x = self.forward_cls(x)
+            cls = AF.layer_norm(cls, self.norm.weight, self.norm.bias, self.norm.eps)
+        else:
+            cls = None
+        x = AF.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        if self.return_mean:
+            return AF.linear(x.float().mean(1).to(BF16), self.head.weight, self.head.bias)
+        x_cls = AF.linear(cls[:, 0] if cls is not None else x[:, 0], self.head.weight, self.head.bias)
+        if not self.return_dense:
+            return x_cls
+        tokens = x if cls is not None else x[:, 1:]
+        x_aux = AF.linear(tokens, self.aux_head.weight, self.aux_head.bias)
+        if not self.training:
+            return x_cls + 0.5 * x_aux.max(1)[0]
+        if self.mix_token and self.training:
+            nc = x_aux.shape[-1]
+            grid = x_aux.reshape(x_aux.shape[0], patch_h, patch_w, nc)
+            if nc % 8 == 0:
+                grid = AF.MixSwapFn.apply(grid, bbx1, bbx2, bby1, bby2)
+            else:                       # odd class counts only occur in unit-test sized heads
+                swapped = grid.clone()
+                swapped[:, bbx1:bbx2, bby1:bby2] = grid.flip(0)[:, bbx1:bbx2, bby1:bby2]
+                grid = swapped
+            x_aux = grid.reshape(grid.shape[0], patch_h * patch_w, nc)
+        return x_cls, x_aux, (bbx1, bby1, bbx2, bby2)
+
+
+def _build(layers, embed_dims, num_heads, mlp_ratios, cfg_key, **kwargs):
+    model = VOLO(layers, embed_dims=embed_dims, num_heads=num_heads, mlp_ratios=mlp_ratios,
+                 downsamples=[True, False, False, False], outlook_attention=[True, False, False, False],
+                 post_layers=["ca", "ca"], **kwargs)
+    model.default_cfg = default_cfgs[cfg_key]
+    return model
+
+
+@register_model
+def volo_d1(pretrained=False, **kwargs):
+    """VOLO-D1, 27M params (models/volo.py:697-727)"""
+    return _build([4, 4, 8, 2], [192, 384, 384, 384], [6, 12, 12, 12], [3, 3, 3, 3], "volo", **kwargs)
+
+
+@register_model
+def volo_d2(pretrained=False, **kwargs):
+    """VOLO-D2, 59M params (models/volo.py:730-750)"""
+    return _build([6, 4, 10, 4], [256, 512, 512, 512], [8, 16, 16, 16], [3, 3, 3, 3], "volo", **kwargs)
+
+
+@register_model
+def volo_d3(pretrained=False, **kwargs):
+    """VOLO-D3, 86M params (models/volo.py:753-773)"""
+    return _build([8, 8, 16, 4], [256, 512, 512, 512], [8, 16, 16, 16], [3, 3, 3, 3], "volo", **kwargs)
+
+
+@register_model
+def volo_d4(pretrained=False, **kwargs):
+    """VOLO-D4, 193M params (models/volo.py:776-796)"""
+    return _build([8, 8, 16, 4], [384, 768, 768, 768], [12, 16, 16, 16], [3, 3, 3, 3], "volo_large", **kwargs)
+
+
+@register_model
+def volo_d5(pretrained=False, **kwargs):
+    """VOLO-D5, 296M params, stem width 128 (models/volo.py:799-821)"""
+    return _build([12, 12, 20, 4], [384, 768, 768, 768], [12, 16, 16, 16], [4, 4, 4, 4], "volo_large", stem_hidden_dim=128, **kwargs)

@@ -1,0 +1,3 @@
+"""Host-side integer bookkeeping of AutoProg (schedule, layer-index maps)."""
+from .progressive import make_divisible, progressive_schedule  # noqa: F401
+from .helpers import new_idx, get_new_layer_idx, ActiveLayerMask  # noqa: F401

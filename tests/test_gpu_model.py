@@ -1,0 +1,144 @@
+"""Model-level parity on the GPU: the HIP-backed VOLO / loss modules against (a) golden vectors of
+the real reference (tests/golden/volo_full.npz, step_curve.npz) and (b) the CPU oracle on the same
+seeded inputs.  bf16 path tolerances, stated per check: full-network outputs <= 3e-2 rel-L2 per
+tensor (bf16 storage rounding, ~0.4 % per op, accumulated over the ~40 ops of these stress-test
+models whose random weights have O(1) scale; single kernels are held to 1e-2 in
+test_gpu_kernels.py), parameter gradients <= 6e-2 rel-L2 (0.15 for the MIOpen bf16 conv stem that
+sits below every block), loss values <= 1e-2 abs on the single-step fixtures and <= 3e-3 RELATIVE
+per step on the 5-step AdamW curve (losses of 5-7 on these fixtures)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from tests._golden import load, sub
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def build(variant, classes, img=64, dpr=0.0):
+    from autoprog_amd.models import create_model
+    return create_model("model_variant", variant=variant, num_classes=classes, img_size=img, drop_path_rate=dpr, stem_hidden_dim=16)
+
+
+def load_sd(model, d, prefix):
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sub(d, prefix + ".w").items()}
+    missing, unexpected = model.load_state_dict(sd, strict=True), None
+    return model
+
+
+@pytest.mark.parametrize("tag,variant,classes", [("h2_l3", "volo_h2_l3", 16), ("h2_l6", "volo_h2_l6", 12)])
+def test_volo_train_eval_vs_reference_golden(tag, variant, classes):
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    d = load("volo_full")
+    model = load_sd(build(variant, classes), d, tag).cuda().train()
+    x = torch.from_numpy(d[tag + ".x"]).cuda()
+    target = torch.from_numpy(d[tag + ".target"]).cuda()
+    np.random.seed(int(d[tag + ".np_seed"]))
+    x_cls, x_aux, bb = model(x)
+    assert list(bb) == [int(v) for v in d[tag + ".bbox"]]                 # mix-token bookkeeping: exact
+    assert rel(x_cls, d[tag + ".x_cls"]) < 3e-2, rel(x_cls, d[tag + ".x_cls"])
+    assert rel(x_aux, d[tag + ".x_aux"]) < 3e-2, rel(x_aux, d[tag + ".x_aux"])
+    loss = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=classes)((x_cls, x_aux, bb), target)
+    assert abs(float(loss.detach()) - float(d[tag + ".loss"])) < 1e-2, (float(loss.detach()), float(d[tag + ".loss"]))
+    loss.backward()
+    worst = {}
+    for name, p in model.named_parameters():
+        g = d[tag + ".g." + name]
+        if np.linalg.norm(g) < 1e-6:
+            continue
+        worst[name] = rel(p.grad, g)
+    # the conv/BN stem runs through MIOpen in bf16 and sits below every block: looser bound there
+    bad = {k: v for k, v in worst.items() if v > (0.15 if k.startswith("patch_embed.") else 6e-2)}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+    model.eval()
+    with torch.no_grad():
+        y = model(x)
+    assert rel(y, d[tag + ".eval_y"]) < 3e-2
+
+
+def test_supernet_subconfigs_vs_reference_golden():
+    d = load("volo_full")
+    model = load_sd(build("volo_h2_l6", 10), d, "super").cuda().eval()
+    x = torch.from_numpy(d["super.x"]).cuda()
+    for l in (3, 4, 5, 6):
+        model.set_sample_config(dict(layer_num=l, min_layer_num=3, max_layer_num=6))
+        with torch.no_grad():
+            y = model(x)
+        assert rel(y, d["super.eval_y_l%d" % l]) < 3e-2, l
+
+
+def test_loss_curve_vs_reference_golden():
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    d = load("step_curve")
+    model = build("volo_h2_l3", 16)
+    model.load_state_dict({k[2:]: torch.from_numpy(np.asarray(v)) for k, v in d.items() if k.startswith("w.")})
+    model = model.cuda().train()
+    x = torch.from_numpy(d["x"]).cuda()
+    target = torch.from_numpy(d["target"]).cuda()
+    decay, no_decay = [], []
+    for n, p in model.named_parameters():
+        (no_decay if (p.dim() == 1 or n.endswith(".bias") or n in ("pos_embed", "cls_token")) else decay).append(p)
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": float(d["wd"])}, {"params": no_decay, "weight_decay": 0.0}], lr=float(d["lr"]))
+    loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=16)
+    np.random.seed(int(d["np_seed"]))
+    losses = []
+    for step in range(5):
+        out = model(x)
+        assert [int(v) for v in out[2]] == [int(v) for v in d["boxes"][step]]
+        loss = loss_fn(out, target)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    diff = np.abs(np.array(losses) - d["losses"]) / d["losses"]
+    print("loss curve hip:", losses, "ref:", d["losses"].tolist(), "reldiff:", diff.tolist())
+    assert diff.max() < 3e-3, (losses, d["losses"].tolist())
+
+
+def test_d1_shapes_droppath_and_oracle_agreement():
+    """D1-width blocks (C=192/384, 6/12 heads) at small batch/resolution against the oracle with
+    injected DropPath masks and a fixed mix-token box."""
+    from autoprog_amd.models import create_model
+    torch.manual_seed(0)
+    model = create_model("model_variant", variant="volo_h12_l9", num_classes=1000, img_size=224, drop_path_rate=0.2).cuda().train()
+    B, r = 4, 64
+    x = torch.randn(B, 3, r, r, device="cuda")
+    masks = {}
+    layers = model.layers
+    total = sum(layers)
+    rng = np.random.RandomState(5)
+    for i, blk in enumerate(model.network[2]):
+        rate = blk.drop_prob
+        m1 = torch.from_numpy((rng.rand(B) < (1 - rate)).astype(np.float32))
+        m2 = torch.from_numpy((rng.rand(B) < (1 - rate)).astype(np.float32))
+        if rate > 0:
+            masks[(1, i)] = (m1, m2)
+            model.drop_path_rng.queue += [m1, m2]
+    np.random.seed(3)
+    x_cls, x_aux, bb = model(x)
+    p = {k: v.detach().double().cpu() for k, v in model.state_dict().items()}
+    np_rng = np.random.RandomState(3)
+    lam, box = R.draw_mix_box((B, r // 8, r // 8, 192), 2, 1.0, np_rng)
+    assert tuple(bb) == tuple(box)
+    arch = R.variant_arch("volo_h12_l9")
+    ref_cls, ref_aux, _ = R.volo_forward(p, x.double().cpu(), train=True, mix=(lam, box), dp_masks=masks, drop_path_rate=0.2, **arch)
+    assert rel(x_cls, ref_cls) < 3e-2, rel(x_cls, ref_cls)
+    assert rel(x_aux, ref_aux) < 3e-2, rel(x_aux, ref_aux)
+
+
+def test_product_never_imports_oracle():
+    import os
+    import re
+    import autoprog_amd
+    for root, _, files in os.walk(autoprog_amd.__path__[0]):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, re.M), (root, f)

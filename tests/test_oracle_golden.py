@@ -209,3 +209,25 @@ def test_deit_block_matches_pinned_volo_block():
     B, H, W, C = x.shape
     y = R.vit_block(x.reshape(B, H * W, C), p, "", 2, eps=1e-5).reshape(B, H, W, C)
     assert rel_err(y, d["transformer.y"]) < TOL
+
+
+def test_loss_curve_five_adamw_steps():
+    """the loss-curve pin: 5 AdamW steps of the tiny model on a fixed batch (reference run)"""
+    d = load("step_curve")
+    arch = R.variant_arch("volo_h2_l3")
+    p = {k[2:]: torch.from_numpy(v).double() for k, v in d.items() if k.startswith("w.") and v.dtype.kind == "f"}
+    train = {k: v.requires_grad_(True) for k, v in p.items() if "running_" not in k}
+    decay = [v for k, v in train.items() if not (v.dim() == 1 or k.endswith(".bias") or k in ("pos_embed", "cls_token"))]
+    no_decay = [v for k, v in train.items() if (v.dim() == 1 or k.endswith(".bias") or k in ("pos_embed", "cls_token"))]
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": float(d["wd"])}, {"params": no_decay, "weight_decay": 0.0}], lr=float(d["lr"]))
+    x = torch.from_numpy(d["x"]).double()
+    t = torch.from_numpy(d["target"]).double()
+    rng = np.random.RandomState(int(d["np_seed"]))
+    for step in range(5):
+        lam, box = R.draw_mix_box((x.shape[0], 8, 8, 32), 2, 1.0, rng)
+        assert list(box) == [int(v) for v in d["boxes"][step]]
+        loss = R.token_label_ce(R.volo_forward(p, x, train=True, mix=(lam, box), **arch), t, 0.5, 1.0)
+        assert abs(float(loss.detach()) - float(d["losses"][step])) < 2e-4, step
+        opt.zero_grad()
+        loss.backward()
+        opt.step()

@@ -26,7 +26,7 @@ OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
 
 def npy(t):
-    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+    return t.detach().cpu().numpy().copy() if torch.is_tensor(t) else np.asarray(t)
 
 
 def sd_arrays(module, prefix="w."):
