@@ -5,6 +5,8 @@ without the built .so, or calling an op without a GPU tensor, raises immediately
 """
 import ctypes
 import os
+
+import torch  # noqa: F401  (must be loaded BEFORE the extension: both must share torch's HIP runtime)
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

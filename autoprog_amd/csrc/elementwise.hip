@@ -208,12 +208,14 @@ const char* ap_error_string(int code) {
 int ap_cast_f32_bf16(const float* src, ap_bf16* dst, int64_t n, ap_stream_t stream) {
     if (!src || !dst) return AP_ERR_NULL;
     if (n <= 0) return AP_OK;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_cast_f32_bf16, dim3(grid_for(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
     return ap_check_launch();
 }
 int ap_cast_bf16_f32(const ap_bf16* src, float* dst, int64_t n, ap_stream_t stream) {
     if (!src || !dst) return AP_ERR_NULL;
     if (n <= 0) return AP_OK;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_cast_bf16_f32, dim3(grid_for(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
     return ap_check_launch();
 }
@@ -221,6 +223,7 @@ int ap_cast_transpose_f32_bf16(const float* src, ap_bf16* dst, int rows, int col
     if (!src || !dst) return AP_ERR_NULL;
     if (rows <= 0 || cols <= 0 || ld_dst < rows) return AP_ERR_SHAPE;
     dim3 grid((cols + 31) / 32, (ld_dst + 31) / 32);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_cast_transpose, grid, dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols, ld_dst);
     return ap_check_launch();
 }
@@ -228,6 +231,7 @@ int ap_row_scale(const ap_bf16* x, const float* scale, ap_bf16* y, int64_t M, in
     if (!x || !scale || !y) return AP_ERR_NULL;
     if ((C & 7) || rows_per_scale <= 0) return AP_ERR_SHAPE;
     if (M <= 0) return AP_OK;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_row_scale, dim3(grid_for(M * (C / 8))), dim3(256), 0, (hipStream_t)stream, x, scale, y, M, C / 8, rows_per_scale);
     return ap_check_launch();
 }
@@ -235,6 +239,7 @@ int ap_add_bcast(const ap_bf16* a, const ap_bf16* b, ap_bf16* y, int64_t n, int6
     if (!a || !b || !y) return AP_ERR_NULL;
     if ((n & 7) || (b_elems & 7) || b_elems <= 0 || n % b_elems) return AP_ERR_SHAPE;
     if (n == 0) return AP_OK;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_add_bcast, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, a, b, y, n / 8, b_elems / 8);
     return ap_check_launch();
 }
@@ -242,12 +247,14 @@ int ap_sum_reps_acc(const ap_bf16* x, float* out, int64_t n, int reps, ap_stream
     if (!x || !out) return AP_ERR_NULL;
     if ((n & 7) || reps <= 0) return AP_ERR_SHAPE;
     if (n == 0) return AP_OK;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_sum_reps_acc, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, x, out, n / 8, reps);
     return ap_check_launch();
 }
 int ap_mix_token_swap(const ap_bf16* x, ap_bf16* y, int B, int H, int W, int C, int r0, int r1, int c0, int c1, ap_stream_t stream) {
     if (!x || !y) return AP_ERR_NULL;
     if ((C & 7) || B <= 0 || H <= 0 || W <= 0 || x == y) return AP_ERR_SHAPE;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_mix_swap, dim3(grid_for((int64_t)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
                        x, y, B, H, W, C / 8, r0, r1, c0, c1);
     return ap_check_launch();
@@ -256,12 +263,14 @@ int ap_avgpool2_fwd(const ap_bf16* x, ap_bf16* y, int B, int H, int W, int C, ap
     if (!x || !y) return AP_ERR_NULL;
     if ((C & 7) || B <= 0 || H <= 0 || W <= 0) return AP_ERR_SHAPE;
     const int h = (H + 1) / 2, w = (W + 1) / 2;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_avgpool2_fwd, dim3(grid_for((int64_t)B * h * w * (C / 8))), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C / 8);
     return ap_check_launch();
 }
 int ap_avgpool2_bwd_acc(const ap_bf16* dpooled, ap_bf16* dx, int B, int H, int W, int C, ap_stream_t stream) {
     if (!dpooled || !dx) return AP_ERR_NULL;
     if ((C & 7) || B <= 0 || H <= 0 || W <= 0) return AP_ERR_SHAPE;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_avgpool2_bwd_acc, dim3(grid_for((int64_t)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, dpooled, dx, B, H, W, C / 8);
     return ap_check_launch();
 }
@@ -273,6 +282,7 @@ int ap_colsum_acc(const ap_bf16* A, int lda, float* out, int M, int N, ap_stream
     const int cap = (2048 + gx - 1) / gx;
     if (gy > cap) gy = cap;
     const int rows_per_block = (M + gy - 1) / gy;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_colsum_acc, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, A, lda, out, M, N, rows_per_block);
     return ap_check_launch();
 }

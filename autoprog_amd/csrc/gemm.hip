@@ -279,6 +279,7 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int ntiles = tiles_m * tiles_n;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_gemm_nt, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ntiles, ep);
     return ap_check_launch();
 }
@@ -295,6 +296,7 @@ int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* 
     if (splits < 1) splits = 1;
     const int sps = (total_steps + splits - 1) / splits;
     splits = (total_steps + sps - 1) / sps;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_gemm_tn, dim3(t1, t2, splits), dim3(256), 0, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N1, N2, sps);
     return ap_check_launch();
 }

@@ -165,6 +165,7 @@ int ap_layernorm_fwd(const ap_bf16* x, const float* gamma, const float* beta, ap
     int64_t grid = ceil_div64(rows, gpb);
     if (grid > 256 * 16) grid = 256 * 16;
     hipStream_t s = (hipStream_t)stream;
+    (void)hipGetLastError();
     if (V == 1) hipLaunchKernelGGL(k_ln_fwd<1>, dim3((int)grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
     else if (V == 2) hipLaunchKernelGGL(k_ln_fwd<2>, dim3((int)grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
     else hipLaunchKernelGGL(k_ln_fwd<4>, dim3((int)grid), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
@@ -183,6 +184,7 @@ int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, co
     if (grid > 1024) grid = 1024;           // bounds the dgamma/dbeta atomic traffic
     const size_t lds = (size_t)2 * gpb * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
+    (void)hipGetLastError();
     if (V == 1) hipLaunchKernelGGL(k_ln_bwd<1>, dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);
     else if (V == 2) hipLaunchKernelGGL(k_ln_bwd<2>, dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);
     else hipLaunchKernelGGL(k_ln_bwd<4>, dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);

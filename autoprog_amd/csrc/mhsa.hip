@@ -364,6 +364,7 @@ k_class_attn_bwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, co
 }
 
 #define MHSA_DISPATCH(KERNEL, NTV, ...)                                                          \
+    (void)hipGetLastError();                                                                     \
     switch (NTV) {                                                                               \
         case 2: hipLaunchKernelGGL(KERNEL<2>, grid, dim3(256), lds, s, __VA_ARGS__); break;      \
         case 4: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), lds, s, __VA_ARGS__); break;      \
@@ -398,6 +399,7 @@ int ap_mhsa_bwd(const ap_bf16* qkv, const ap_bf16* out, const ap_bf16* dout, con
     const dim3 grid(B * heads);
     const size_t lds = (size_t)4 * nt * 16 * AHD * sizeof(bf16_t) + (size_t)2 * nt * 16 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_mhsa_bwd, grid, dim3(256), lds, s, qkv, out, dout, lse, dqkv, N, heads, scale, nt);
     return ap_check_launch();
 }
@@ -409,6 +411,7 @@ int ap_class_attn_fwd(const ap_bf16* q, const ap_bf16* kv, ap_bf16* out, float* 
     if (hd != AHD) return AP_ERR_UNSUPPORTED;
     const size_t lds = ((size_t)((N + 63) & ~63) + 64 * 32) * sizeof(float);
     if (lds > 64 * 1024) return AP_ERR_UNSUPPORTED;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_class_attn_fwd, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, out, probs, N, heads, scale);
     return ap_check_launch();
 }
@@ -420,6 +423,7 @@ int ap_class_attn_bwd(const ap_bf16* q, const ap_bf16* kv, const float* probs, c
     if (hd != AHD) return AP_ERR_UNSUPPORTED;
     const size_t lds = ((size_t)((N + 63) & ~63) + 64 * 32) * sizeof(float);
     if (lds > 64 * 1024) return AP_ERR_UNSUPPORTED;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_class_attn_bwd, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, probs, dout, dq, dkv, N, heads, scale);
     return ap_check_launch();
 }

@@ -205,6 +205,7 @@ static int gather_launch(bool tp, const bf16_t* in, const bf16_t* logits, int ld
     if (lds_of(SR) > 160 * 1024) return AP_ERR_UNSUPPORTED;
     const int nstrips = (h + SR - 1) / SR;
     const dim3 grid((unsigned)(B * nstrips * heads));
+    (void)hipGetLastError();
     if (tp) hipLaunchKernelGGL(k_outlook_gather<true>, grid, dim3(128), lds_of(SR), s, in, logits, ldl, out, H, W, heads, scale, SR, nstrips);
     else hipLaunchKernelGGL(k_outlook_gather<false>, grid, dim3(128), lds_of(SR), s, in, logits, ldl, out, H, W, heads, scale, SR, nstrips);
     return ap_check_launch();
@@ -235,6 +236,7 @@ int ap_outlook_bwd(const ap_bf16* v, const ap_bf16* logits, int ldl, const ap_bf
     while (SRW > 1 && lds_of(SRW) > 52 * 1024) --SRW;
     if (lds_of(SRW) > 160 * 1024) return AP_ERR_UNSUPPORTED;
     const int nstrips = (h + SRW - 1) / SRW;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_outlook_dlogits, dim3((unsigned)(B * nstrips * heads)), dim3(64), lds_of(SRW), (hipStream_t)stream,
                        v, dy, logits, ldl, dlogits, H, W, heads, scale, SRW, nstrips);
     return ap_check_launch();

@@ -94,6 +94,7 @@ extern "C" int ap_soft_ce_fwd_bwd(const ap_bf16* logits, int ldx, const float* t
     const int tiles = (rows_per_batch + CE_TN - 1) / CE_TN;
     const int64_t blocks = (M / rows_per_batch) * tiles;
     const size_t lds = (size_t)CE_TN * (C | 1) * sizeof(float);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_soft_ce, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, logits, ldx, target, t_sb, t_sc,
                        t_sn, rows_per_batch, row_loss, dlogits, grad_scale, M, C, tiles);
     return ap_check_launch();

@@ -1,0 +1,94 @@
+"""Data-parallel gradient exchange for the AutoProg step (reference: ApexDDP(delay_allreduce=True)
+/ torch DDP wrappers at main_prog.py:538-550, 1412-1425 -- mean of gradients across ranks).
+
+MI355X design: one process per GPU, RCCL through
+torch.distributed (backend "nccl" on ROCm).  All parameter gradients live in ONE flat fp32 slab;
+parameters are grouped into buckets in reverse registration order (~ backward order) and a
+bucket's all-reduce is launched asynchronously from a post-accumulate-grad hook as soon as its
+last gradient is produced, so the exchange overlaps the rest of backward.  xGMI is point-to-point
+(7 links/GPU): buckets are sized large (default 32 MiB) so each collective can use every link.
+
+Elastic depth leaves skipped layers without gradients; every rank runs the same (r, l) config per
+step (reference: random.seed(epoch), main_prog.py:1861), so `finish()` reduces the remaining
+buckets in the same order on every rank (their untouched gradients are zero).
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradientBucketReducer:
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, world_size=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
+        total = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(total, dtype=torch.float32, device=ref.device)
+        # gradients become views of the slab; buckets are contiguous slab ranges
+        order = list(reversed(self.params))
+        self.buckets = []          # (start, end, [param indices in `order`])
+        off, cur_start, cur_members = 0, 0, []
+        self._bucket_of = {}
+        for i, p in enumerate(order):
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            cur_members.append(i)
+            off += n
+            if (off - cur_start) * 4 >= bucket_bytes:
+                self.buckets.append((cur_start, off, cur_members))
+                cur_start, cur_members = off, []
+        if cur_members:
+            self.buckets.append((cur_start, off, cur_members))
+        for b, (_, _, members) in enumerate(self.buckets):
+            for i in members:
+                self._bucket_of[id(order[i])] = b
+        self._pending = [len(m) for (_, _, m) in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.world > 1 else []
+
+    # ------------------------------------------------------------------ hooks
+    def _on_grad(self, p):
+        b = self._bucket_of[id(p)]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and not self._launched[b]:
+            self._launch(b)
+
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        self._launched[b] = True
+        self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    # ------------------------------------------------------------------ step API
+    def zero_grad(self):
+        """gradients stay attached to the slab (never set to None)"""
+        self.flat.zero_()
+        self._pending = [len(m) for (_, _, m) in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+
+    def finish(self):
+        """call after backward(): reduce buckets whose hooks did not all fire (skipped layers), wait
+        for every collective and turn sums into means."""
+        if self.world <= 1:
+            return
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        for h in self._handles:
+            h.wait()
+        self.flat.mul_(1.0 / self.world)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def reduce_scalar_mean(t, world_size, group=None):
+    """timm reduce_tensor (main_prog.py:1043): all-reduce(SUM)/n on a clone"""
+    rt = t.detach().clone()
+    if world_size > 1:
+        dist.all_reduce(rt, op=dist.ReduceOp.SUM, group=group)
+        rt /= world_size
+    return rt

@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Benchmark of the AutoProg VOLO-D1 224 px training step on MI355X (BASELINE.json metric
+"images/sec/GPU (fwd+bwd) VOLO-D1 224px AutoProg step").
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one synthetic batch already resident in HBM:
+forward (mix-token, DropPath 0.1) + token-label loss + backward (+ bucketed RCCL gradient
+all-reduce overlapped with backward when N>1) + AdamW update + the 4 EMA updates of
+scripts/train_autoprog.sh.  Workload = BASELINE.json configs[1]: volo_h12_l18 (== VOLO-D1),
+224x224, per-GPU batch 128, bf16 activations / fp32 master weights, token-label target [B,1000,198].
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     dominant kernel (k_gemm_nt, bound "mfma"): algorithmic FLOPs of its launches in one
+               step / their summed duration, measured with HIP events on the launch stream
+  cpu_baseline the CPU oracle (oracle/ref_cpu.py, kind "port") timed on this host on a bounded
+               sample of the same workload (smaller batch), rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def make_target(B, C, N, device, gen):
+    """token-label style soft targets [B,C,2+N]: top-5 sparse labels mixed with smoothing 0.1
+    (SURVEY.md section 8(d) row M2)."""
+    t = torch.zeros(B, C, 2 + N)
+    idx = torch.randint(0, C, (B, 5, 2 + N), generator=gen)
+    val = torch.rand(B, 5, 2 + N, generator=gen)
+    val = val / val.sum(1, keepdim=True)
+    t.scatter_(1, idx, val)
+    t = t * 0.9 + 0.1 / C
+    return t.to(device)
+
+
+def cpu_baseline(variant, res, seconds_budget, threads):
+    """time the CPU oracle (pure torch fp32 restatement of the reference) on a bounded sample"""
+    from oracle import ref_cpu as R
+    torch.set_num_threads(threads)
+    arch = R.variant_arch(variant)
+    from autoprog_amd.models import create_model
+    torch.manual_seed(42)
+    model = create_model("model_variant", variant=variant, drop_path_rate=0.1)
+    p = {k: v.detach().clone().float().requires_grad_(v.dtype.is_floating_point and "running_" not in k)
+         for k, v in model.state_dict().items()}
+    B = 8
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(B, 3, res, res, generator=g)
+    n = (res // 16) ** 2
+    target = make_target(B, 1000, n, "cpu", g)
+    rng = np.random.RandomState(42)
+
+    def step():
+        lam, box = R.draw_mix_box((B, res // 8, res // 8, arch["embed_dims"][0]), 2, 1.0, rng)
+        out = R.volo_forward(p, x, train=True, mix=(lam, box), drop_path_rate=0.1, **arch)
+        loss = R.token_label_ce(out, target, 0.5, 1.0)
+        grads = torch.autograd.grad(loss, [v for v in p.values() if v.requires_grad], allow_unused=True)
+        return float(loss.detach()), grads
+
+    step()                                   # warm-up
+    t0 = time.time()
+    n_steps = 0
+    while True:
+        step()
+        n_steps += 1
+        if time.time() - t0 > seconds_budget or n_steps >= 10:
+            break
+    dt = time.time() - t0
+    return {"value": round(B * n_steps / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "oracle/ref_cpu.py fp32 fwd+loss+bwd, %s %dpx, batch %d, %d steps in %.1fs (no optimizer)" % (variant, res, B, n_steps, dt)}
+
+
+class GemmProbe:
+    """HIP-event timing of every ap_gemm_nt launch (events recorded on the launch stream)"""
+
+    def __init__(self):
+        self.records = []
+
+    def install(self):
+        from autoprog_amd import ops
+        self._orig = ops.gemm_nt
+        probe = self
+
+        def timed(a, b, n=None, k=None, **kw):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = probe._orig(a, b, n=n, k=k, **kw)
+            e1.record()
+            nn = b.shape[0] if n is None else n
+            kk = a.shape[1] if k is None else k
+            probe.records.append((e0, e1, 2.0 * a.shape[0] * nn * kk))
+            return out
+        ops.gemm_nt = timed
+
+    def remove(self):
+        from autoprog_amd import ops
+        ops.gemm_nt = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
+        flops = sum(f for _, _, f in self.records)
+        return len(self.records), ms, flops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (scripts/train_autoprog.sh: -b 128)")
+    ap.add_argument("--res", type=int, default=224)
+    ap.add_argument("--variant", default="volo_h12_l18")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true", help="time forward+loss+backward only")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from autoprog_amd.models import create_model
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    from autoprog_amd.dist import GradientBucketReducer
+
+    torch.manual_seed(42 + rank)
+    np.random.seed(42 + rank)
+    model = create_model("model_variant", variant=args.variant, drop_path_rate=0.1).to(dev).train()
+    if world > 1:                      # identical initial weights on every rank (DDP broadcast)
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=0)
+    loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=1000)
+    decay, no_decay = [], []
+    skip = model.no_weight_decay()
+    for n_, p_ in model.named_parameters():
+        (no_decay if (p_.dim() == 1 or n_.endswith(".bias") or n_ in skip) else decay).append(p_)
+    reducer = GradientBucketReducer(list(model.parameters()), world_size=world)
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": no_decay, "weight_decay": 0.0}], lr=1.6e-3, fused=True)
+    ema_decays = [0.998, 0.9986, 0.999, 0.9996]
+    live = [t for t in model.state_dict().values() if t.dtype.is_floating_point]
+    emas = [[t.detach().clone() for t in live] for _ in ema_decays]
+
+    B, res = args.batch, args.res
+    gen = torch.Generator().manual_seed(42 + rank)
+    images = torch.randn(B, 3, res, res, generator=gen).to(dev)
+    n_tok = (res // 16) ** 2
+    target = make_target(B, 1000, n_tok, dev, gen)
+
+    def step():
+        reducer.zero_grad()
+        out = model(images)
+        loss = loss_fn(out, target)
+        loss.backward()
+        reducer.finish()
+        if not args.no_optimizer:
+            opt.step()
+            with torch.no_grad():
+                for d, ema in zip(ema_decays, emas):
+                    torch._foreach_lerp_(ema, live, 1.0 - d)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    final_loss = float(loss.detach())
+
+    roofline = None
+    if not args.no_roofline:
+        probe = GemmProbe()
+        probe.install()
+        nprobe = 3
+        for _ in range(nprobe):
+            step()
+        launches, ms, flops = probe.summary()
+        probe.remove()
+        achieved = flops / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "k_gemm_nt", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": launches // nprobe, "avg_launch_us": round(ms * 1e3 / launches, 2),
+                    "gemm_ms_per_step": round(ms / nprobe, 3), "gemm_gflop_per_step": round(flops / nprobe / 1e9, 1)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = min(os.cpu_count() or 1, 64)
+        cpu = cpu_baseline(args.variant, res, args.cpu_seconds, threads)
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = B * world * args.steps / elapsed
+        line = {"metric": "images/sec/GPU (fwd+bwd) VOLO-D1 224px AutoProg step", "value": round(value, 2), "unit": "images/sec",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "images_per_sec_per_gpu": round(value / world, 2),
+                "config": {"workload": "BASELINE.json configs[1]: %s (VOLO-D1) %dpx token-label training step" % (args.variant, res),
+                           "model": args.variant, "global_batch": B * world, "per_gpu_batch": B, "res": res, "parallelism": "dp%d" % world,
+                           "step": "fwd+loss+bwd" + ("" if args.no_optimizer else "+AdamW+4xEMA") + ("+RCCL grad all-reduce" if world > 1 else ""),
+                           "final_loss": round(final_loss, 4)},
+                "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
