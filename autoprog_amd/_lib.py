@@ -28,7 +28,7 @@ _SIGNATURES = {
     "ap_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "ap_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "ap_gemm_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, POINTER(GemmEpilogue), _P]),
-    "ap_gemm_tn_acc": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "ap_gemm_tn_acc": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "ap_colsum_acc": (_I, [_P, _I, _P, _I, _I, _P]),
     "ap_outlook_fwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "ap_outlook_bwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

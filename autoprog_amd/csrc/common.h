@@ -37,11 +37,24 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (nn.GELU default) and its derivative.  erf is evaluated with Abramowitz-Stegun
+// 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-level) on z = |x|/sqrt(2): one v_exp + one v_rcp + 5 FMAs;
+// the same exponential exp(-x^2/2) also gives the Gaussian pdf needed by the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    e = __expf(-0.5f * x * x);
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float half_tail = 0.5f * poly * t * e;          // 0.5*erfc(z)
+    cdf = x >= 0.f ? 1.0f - half_tail : half_tail;
+}
+__device__ __forceinline__ float gelu_erf(float x) { float c, e; gelu_parts(x, c, e); return x * c; }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float c, e; gelu_parts(x, c, e);
+    return fmaf(x * 0.39894228040143268f, e, c);
 }
 
 template <int WIDTH>

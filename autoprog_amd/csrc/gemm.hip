@@ -21,10 +21,11 @@
 // LDS tiles; the chunk swizzle f(row) keeps those transposed reads conflict free.  The token range
 // is split across blockIdx.z and partial tiles are added with fp32 atomics (few MB per call).
 #include "common.h"
+#include <cstdlib>
 
-#define BM 128
-#define BN 128
-#define BK 64
+#define SBM 128
+#define SBN 128
+#define SBK 64
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
@@ -38,16 +39,16 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 
 struct EpiArgs {
     const float* bias; int gelu; bf16_t* preact; const bf16_t* dgelu_of; const float* row_scale;
-    int rows_per_scale; const bf16_t* residual; int ldr;
+    int rows_per_scale; const bf16_t* residual; int ldr; int dbg;
 };
 
 __global__ void __launch_bounds__(256)
 k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
           int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
-    __shared__ __attribute__((aligned(16))) bf16_t sA[BM * BK];
-    __shared__ __attribute__((aligned(16))) bf16_t sB[BN * BK];
+    __shared__ __attribute__((aligned(16))) bf16_t sA[SBM * SBK];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[SBN * SBK];
     const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int m0 = (tile / tiles_n) * SBM, n0 = (tile % tiles_n) * SBN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, g = lane >> 4;
@@ -62,7 +63,7 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
         const int r = srow + 32 * i;
         ga[i] = A + (int64_t)min(m0 + r, M - 1) * lda + kc * 8;
         gb[i] = B + (int64_t)min(n0 + r, N - 1) * ldb + kc * 8;
-        soff[i] = r * BK + ((kc ^ (r & 7)) << 3);          // in elements
+        soff[i] = r * SBK + ((kc ^ (r & 7)) << 3);          // in elements
     }
     u32x4 ra[4], rb[4];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -82,11 +83,11 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     gload(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    for (int k0 = 0; k0 < K; k0 += SBK) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { st16(sA + soff[i], ra[i]); st16(sB + soff[i], rb[i]); }
         __syncthreads();
-        if (k0 + BK < K) gload(k0 + BK);
+        if (k0 + SBK < K) gload(k0 + SBK);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 xf[4], wf[4];
@@ -94,8 +95,8 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
             for (int t = 0; t < 4; ++t) {
                 const int ra_ = wm * 64 + t * 16 + fr;
                 const int rb_ = wn * 64 + t * 16 + fr;
-                xf[t] = as_bf16x8(ld16(sA + ra_ * BK + (((ks * 4 + g) ^ (ra_ & 7)) << 3)));
-                wf[t] = as_bf16x8(ld16(sB + rb_ * BK + (((ks * 4 + g) ^ (rb_ & 7)) << 3)));
+                xf[t] = as_bf16x8(ld16(sA + ra_ * SBK + (((ks * 4 + g) ^ (ra_ & 7)) << 3)));
+                wf[t] = as_bf16x8(ld16(sB + rb_ * SBK + (((ks * 4 + g) ^ (rb_ & 7)) << 3)));
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
@@ -172,6 +173,198 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
     }
 }
 
+// ------------------------------------------------------------ gemm_nt, persistent LDS-DMA ring
+// Main forward / input-gradient GEMM for K % 64 == 0 (every Linear of the D1..D5 and DeiT models).
+// Ablation of a non-persistent 256x128 ring kernel on the qkv shape (M 25088, N 1152, K 384; rocprof +
+// on/off builds): 12 us of 40 in the epilogue, ~3 us per tile of workgroup launch/setup with one
+// 144 KB workgroup per CU, main loop at 39 % of MFMA peak.  Hence this structure:
+//   * PERSISTENT: grid = min(tiles, #CU); a workgroup (8 waves) walks its tiles, and the K-step stream is
+//     flattened over (tile, k) so the LDS-DMA ring keeps prefetching the NEXT tile while the current
+//     tile's epilogue runs (loads overlap the epilogue; no per-tile launch cost)
+//   * 128 x TBN tile (TBN = 128, or 96 when N is a multiple of 96 but not 128: 192, 576), BK = 64,
+//     3-stage ring (96 KB) filled by global_load_lds (16 B/lane), counted s_waitcnt vmcnt + one raw
+//     s_barrier per K step; LDS image [A rows | B rows] x 64 bf16 with chunk ^= row&7 applied on the
+//     SOURCE address (the DMA writes LDS linearly)
+//   * epilogue through a separate 64 KB fp32 staging tile: accumulators -> LDS (chunk-swizzled) ->
+//     each thread owns 8 consecutive columns of a row: 16-byte coalesced loads of residual / gelu input
+//     and 16-byte coalesced stores
+template <int TBN, int WM, int WN>
+__global__ void __launch_bounds__(WM * WN * 64)
+k_gemm_nt_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
+               int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
+    constexpr int TBM = 128;
+    constexpr int STAGES = 3;
+    constexpr int STAGE = 256 * 64;                  // elements per stage: 128 A rows + 128 B-row slots
+    constexpr int NW = WM * WN;                      // waves per workgroup (4 or 8)
+    constexpr int NI = 32 / NW;                      // global_load_lds per thread per K step (32 row groups of 8 rows)
+    constexpr int MT = TBM / WM / 16, NTT = TBN / WN / 16;
+    bf16_t* ring = reinterpret_cast<bf16_t*>(ring_raw);
+    float* ctile = reinterpret_cast<float*>(ring_raw + (size_t)STAGES * STAGE * sizeof(bf16_t));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, g = lane >> 4;
+    const int nk = K >> 6;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * nk;
+
+    const bf16_t* src[NI];
+    auto set_tile_src = [&](int ti) {
+        const int tile = xcd_remap(blockIdx.x + ti * gridDim.x, ntiles);
+        const int m0 = (tile / tiles_n) * TBM, n0 = (tile % tiles_n) * TBN;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = (wave + NW * i) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            src[i] = (r < TBM) ? A + (int64_t)min(m0 + r, M - 1) * lda + c * 8
+                               : B + (int64_t)min(n0 + min(r - TBM, TBN - 1), N - 1) * ldb + c * 8;
+        }
+    };
+    int q_tile = 0, q_k = 0, q_stage = 0;            // issue cursor over the flattened (tile, k) stream
+    auto issue_next = [&]() {
+        if (q_k == 0) set_tile_src(q_tile);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + q_k * 64),
+                                             (__attribute__((address_space(3))) void*)(ring + q_stage * STAGE + (wave + NW * i) * 512), 16, 0, 0);
+        if (++q_k == nk) { q_k = 0; ++q_tile; }
+        q_stage = (q_stage == STAGES - 1) ? 0 : q_stage + 1;
+    };
+
+    f32x4 acc[NTT][MT];
+    int issued = 0;
+    for (; issued < STAGES - 1 && issued < total; ++issued) issue_next();
+    int stage = 0, kt = 0, ti = 0;
+    for (int s = 0; s < total; ++s) {
+        if (kt == 0) {
+#pragma unroll
+            for (int a = 0; a < NTT; ++a)
+#pragma unroll
+                for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // K steps issued beyond s: issued - s - 1 (0..STAGES-2); wait until only those are outstanding
+        const int ahead = issued - s - 1;
+        if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (issued < total) { issue_next(); ++issued; }
+        const bf16_t* sA = ring + stage * STAGE;
+        const bf16_t* sB = sA + TBM * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xf[MT], wf[NTT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r = wm * (TBM / WM) + i * 16 + fr;
+                xf[i] = as_bf16x8(ld16(sA + r * 64 + (((ks * 4 + g) ^ (r & 7)) << 3)));
+            }
+#pragma unroll
+            for (int i = 0; i < NTT; ++i) {
+                const int r = wn * (TBN / WN) + i * 16 + fr;
+                wf[i] = as_bf16x8(ld16(sB + r * 64 + (((ks * 4 + g) ^ (r & 7)) << 3)));
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+        stage = (stage == STAGES - 1) ? 0 : stage + 1;
+        if (++kt < nk) continue;
+        kt = 0;
+        // ------------------------------------------------------------ epilogue of tile `ti`
+        const int tile = xcd_remap(blockIdx.x + ti * gridDim.x, ntiles);
+        ++ti;
+        const int m0 = (tile / tiles_n) * TBM, n0 = (tile % tiles_n) * TBN;
+        if (ep.dbg & 1) { if (acc[0][0][0] == 12345.f) C[0] = 1; continue; }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int r = wm * (TBM / WM) + mt * 16 + fr;
+#pragma unroll
+            for (int nt = 0; nt < NTT; ++nt) {
+                const int c16 = (wn * (TBN / WN) + nt * 16) / 4 + g;
+                *reinterpret_cast<f32x4*>(ctile + r * TBN + ((c16 ^ (r & 7)) << 2)) = acc[nt][mt];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // raw barrier: the next tile's LDS-DMA stays in flight
+        constexpr int CPR = TBN / 8;                  // 8-column chunks per row
+        const bool vec_ok = ((ldc & 7) == 0) && (ep.residual == nullptr || (ep.ldr & 7) == 0);
+#pragma unroll 2
+        for (int id = tid; id < TBM * CPR; id += NW * 64) {
+            const int r = id / CPR, j = id - r * CPR;
+            const int m = m0 + r, n = n0 + 8 * j;
+            if (m >= M || n >= N) continue;
+            float v[8];
+            {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(ctile + r * TBN + (((2 * j) ^ (r & 7)) << 2));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(ctile + r * TBN + (((2 * j + 1) ^ (r & 7)) << 2));
+                v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+            }
+            const int nval = min(8, N - n);
+            const bool full = (nval == 8) && vec_ok;
+            if (ep.bias) {
+                if (nval == 8) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(ep.bias + n), b1 = *reinterpret_cast<const float4*>(ep.bias + n + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (q < nval) v[q] += ep.bias[n + q];
+                }
+            }
+            if (ep.gelu) {
+                if (ep.preact) {
+                    bf16_t* p = ep.preact + (int64_t)m * ldc + n;
+                    if (full) st16(p, pack8(v));
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) if (q < nval) p[q] = f2bf(v[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = bf2f(f2bf(v[q]));       // activation of the ROUNDED pre-activation
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]);
+            }
+            if (ep.dgelu_of) {
+                const bf16_t* hp = ep.dgelu_of + (int64_t)m * ldc + n;
+                float h[8];
+                if (full) unpack8(ld16(hp), h);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) h[q] = (q < nval) ? bf2f(hp[q]) : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] *= gelu_erf_grad(h[q]);
+            }
+            if (ep.row_scale) {
+                const float rs = ep.row_scale[m / ep.rows_per_scale];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] *= rs;
+            }
+            if (ep.residual) {
+                const bf16_t* rp = ep.residual + (int64_t)m * ep.ldr + n;
+                float h[8];
+                if (full) unpack8(ld16(rp), h);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) h[q] = (q < nval) ? bf2f(rp[q]) : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += h[q];
+            }
+            bf16_t* cp = C + (int64_t)m * ldc + n;
+            if (full) st16(cp, pack8(v));
+            else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (q < nval) cp[q] = f2bf(v[q]);
+            }
+        }
+        // the staging tile is rewritten only after the next tile's nk >= 1 K-step barriers: no barrier needed here
+    }
+}
+
 // ------------------------------------------------------------------------------------ wgrad
 #define TM 64          // tokens per step (MFMA reduction)
 __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
@@ -192,7 +385,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int row0, int col0
 
 __global__ void __launch_bounds__(256)
 k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
-          int M, int N1, int N2, int steps_per_split) {
+          int M, int N1, int N2, int steps_per_split, float* __restrict__ colsum) {
     __shared__ __attribute__((aligned(16))) bf16_t sA[TM * 128];
     __shared__ __attribute__((aligned(16))) bf16_t sB[TM * 128];
     const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
@@ -221,6 +414,15 @@ k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // optional fused bias gradient: column sums of A = A^T . 1, one extra MFMA per A fragment with an
+    // all-ones B fragment, done only by the wk==0 waves of the blockIdx.y==0 tiles
+    const bool do_colsum = (colsum != nullptr) && (blockIdx.y == 0) && (wk == 0);
+    f32x4 csum[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) csum[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+
     gload(step_begin);
     for (int step = step_begin; step < step_end; ++step) {
 #pragma unroll
@@ -245,10 +447,23 @@ k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
                     acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+            if (do_colsum) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) csum[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], ones, csum[nt], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
     const int fr = lane & 15, g = lane >> 4;
+    if (do_colsum && fr == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + nt * 16 + 4 * g + r;
+                if (n < N1) atomicAdd(colsum + n, csum[nt][r]);
+            }
+    }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -270,34 +485,62 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     if (!A || !B || !C) return AP_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0) return AP_ERR_SHAPE;
     if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N) return AP_ERR_SHAPE;
-    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0};
+    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0};
+    { const char* e = getenv("AP_GEMM_DBG"); if (e) ep.dbg = atoi(e); }
     if (epi) {
         ep.bias = epi->bias; ep.gelu = epi->gelu; ep.preact = epi->preact_out; ep.dgelu_of = epi->dgelu_of;
         ep.row_scale = epi->row_scale; ep.rows_per_scale = epi->rows_per_scale > 0 ? epi->rows_per_scale : 1;
         ep.residual = epi->residual; ep.ldr = epi->ldr;
         if (ep.residual && ep.ldr < N) return AP_ERR_SHAPE;
     }
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    const int ntiles = tiles_m * tiles_n;
     (void)hipGetLastError();
+    static int force_small = -1;
+    if (force_small < 0) { const char* e = getenv("AP_GEMM_SMALL_TILES"); force_small = (e && e[0] == '1') ? 1 : 0; }
+    if ((K & 63) == 0 && !force_small) {
+        static int n_cu = 0;
+        if (n_cu == 0) { int dev = 0; hipGetDevice(&dev); hipDeviceProp_t pr; n_cu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+        const size_t lds = (size_t)3 * 256 * 64 * sizeof(bf16_t) + (size_t)128 * 128 * sizeof(float);       // 96 KB ring + 64 KB staging
+        const bool narrow = (N % 96 == 0) && (N % 128 != 0);
+        const int tbn = narrow ? 96 : 128;
+        const int tm = (M + 127) / 128, tn = (N + tbn - 1) / tbn, nt = tm * tn;
+        const int grid = nt < n_cu ? nt : n_cu;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)k_gemm_nt_ring<128, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)k_gemm_nt_ring<96, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        (void)hipGetLastError();
+        static int cfg4 = -1;
+        if (cfg4 < 0) { const char* e = getenv("AP_GEMM_4WAVE"); cfg4 = (e && e[0] == '1') ? 1 : 0;
+            (void)hipFuncSetAttribute((const void*)k_gemm_nt_ring<128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
+        if (narrow) hipLaunchKernelGGL((k_gemm_nt_ring<96, 4, 2>), dim3(grid), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
+        else if (cfg4) hipLaunchKernelGGL((k_gemm_nt_ring<128, 2, 2>), dim3(grid), dim3(256), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
+        else hipLaunchKernelGGL((k_gemm_nt_ring<128, 2, 4>), dim3(grid), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
+        return ap_check_launch();
+    }
+    const int tiles_m = (M + SBM - 1) / SBM, tiles_n = (N + SBN - 1) / SBN;
+    const int ntiles = tiles_m * tiles_n;
     hipLaunchKernelGGL(k_gemm_nt, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ntiles, ep);
     return ap_check_launch();
 }
 
 int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* C, int ldc, int M, int N1, int N2,
-                   ap_stream_t stream) {
+                   float* colsum_A, ap_stream_t stream) {
     if (!A || !B || !C) return AP_ERR_NULL;
     if (M <= 0 || N1 <= 0 || N2 <= 0) return AP_ERR_SHAPE;
     if ((lda & 7) || (ldb & 7) || lda < N1 || ldb < N2 || ldc < N2) return AP_ERR_SHAPE;
     const int t1 = (N1 + 127) / 128, t2 = (N2 + 127) / 128;
     const int total_steps = (M + TM - 1) / TM;
-    int splits = (1024 + t1 * t2 - 1) / (t1 * t2);        // aim at ~4 blocks per CU
-    if (splits > total_steps) splits = total_steps;
+    // every split adds its 128x128 fp32 tile with atomics (~1.3 TB/s chip-wide): keep the split count
+    // near 2 workgroups per CU and at least 4 token steps per workgroup
+    int splits = (512 + t1 * t2 - 1) / (t1 * t2);
+    if (splits > total_steps / 4) splits = total_steps / 4;
     if (splits < 1) splits = 1;
     const int sps = (total_steps + splits - 1) / splits;
     splits = (total_steps + sps - 1) / sps;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_gemm_tn, dim3(t1, t2, splits), dim3(256), 0, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N1, N2, sps);
+    hipLaunchKernelGGL(k_gemm_tn, dim3(t1, t2, splits), dim3(256), 0, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N1, N2, sps, colsum_A);
     return ap_check_launch();
 }
 

@@ -46,6 +46,25 @@ class GradientBucketReducer:
         self._launched = [False] * len(self.buckets)
         self._handles = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.world > 1 else []
+        self._owned = {id(p) for p in self.params}
+
+    # ------------------------------------------------------------------ gradient sink (functional.set_grad_sink)
+    def owns(self, p):
+        return id(p) in self._owned and p.grad is not None
+
+    def param_ready(self, p):
+        if self.world > 1:
+            self._on_grad(p)
+
+    def install_sink(self):
+        """let the fused block backward passes accumulate straight into the slab (no per-parameter
+        temporaries, no autograd add kernels)"""
+        from . import functional
+        functional.set_grad_sink(self)
+
+    def uninstall_sink(self):
+        from . import functional
+        functional.set_grad_sink(None)
 
     # ------------------------------------------------------------------ hooks
     def _on_grad(self, p):
@@ -80,6 +99,7 @@ class GradientBucketReducer:
         self.flat.mul_(1.0 / self.world)
 
     def remove(self):
+        self.uninstall_sink()
         for h in self._hooks:
             h.remove()
         self._hooks = []

@@ -76,6 +76,34 @@ def _zeros_like_params(params):
     return out
 
 
+# Optional gradient sink (installed by autoprog_amd.dist.GradientBucketReducer): the block-level
+# backward passes then accumulate parameter gradients IN PLACE into param.grad (views of one flat fp32
+# slab) and signal readiness themselves, instead of returning fresh tensors for autograd to add.
+_grad_sink = None
+
+
+def set_grad_sink(sink):
+    global _grad_sink
+    _grad_sink = sink
+
+
+def _param_grad_buffers(params):
+    """-> (buffers, sink_used).  With a sink: param.grad itself; otherwise one zeroed slab."""
+    sink = _grad_sink
+    if sink is not None and all(p is None or sink.owns(p) for p in params):
+        return [p.grad if p is not None else None for p in params], True
+    return _zeros_like_params(params), False
+
+
+def _finish_param_grads(params, bufs, sink_used):
+    if not sink_used:
+        return bufs
+    for p in params:
+        if p is not None:
+            _grad_sink.param_ready(p)
+    return [None] * len(params)
+
+
 def _g2(w):
     """2-D view of a (possibly conv-shaped) weight gradient buffer"""
     return w.view(w.shape[0], -1)
@@ -84,9 +112,7 @@ def _g2(w):
 def _linear_bwd(g, x_in, w, dw, db, n=None, dgelu_of=None, need_dx=True):
     """shared backward of y = x W^T + b given g = dL/dy (bf16 [M, ld]); accumulates dw/db."""
     n = w.shape[0] if n is None else n
-    ops.gemm_tn_acc(g, x_in, _g2(dw), n1=n, n2=_g2(dw).shape[1])
-    if db is not None:
-        ops.colsum_acc(g, db, n)
+    ops.gemm_tn_acc(g, x_in, _g2(dw), n1=n, n2=_g2(dw).shape[1], colsum=db)
     if not need_dx:
         return None
     wt = bank.get_t(w)                       # [K, ld(N)]
@@ -124,7 +150,8 @@ class TransformerBlockFn(torch.autograd.Function):
          n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b) = ctx.saved_tensors
         B, N, heads, scale = ctx.cfg
         params = (n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
-        (dn1w, dn1b, dqkv_w, dqkv_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = _zeros_like_params(params)
+        bufs, sunk = _param_grad_buffers(params)
+        (dn1w, dn1b, dqkv_w, dqkv_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = bufs
         dy2 = dy.reshape(x2.shape).contiguous()
         # MLP branch
         g2 = ops.row_scale(dy2, rs2, N) if rs2 is not None else dy2
@@ -137,8 +164,7 @@ class TransformerBlockFn(torch.autograd.Function):
         dqkv = ops.mhsa_bwd(qkv, o, do, lse, B, N, heads, scale)
         dxn1 = _linear_bwd(dqkv, xn1, qkv_w, dqkv_w, dqkv_b)
         dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b)
-        return (dx.view(dy.shape), None, None, dn1w, dn1b, dqkv_w, dqkv_b, dproj_w, dproj_b, dn2w, dn2b,
-                dfc1_w, dfc1_b, dfc2_w, dfc2_b, None, None, None, None)
+        return (dx.view(dy.shape), None, None, *_finish_param_grads(params, bufs, sunk), None, None, None, None)
 
 
 # ------------------------------------------------------------------------- outlooker block
@@ -176,7 +202,8 @@ class OutlookerBlockFn(torch.autograd.Function):
         B, H, W, C, heads, scale = ctx.cfg
         T = B * H * W
         params = (n1w, n1b, v_w, v_b, attn_w, attn_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
-        (dn1w, dn1b, dv_w, dv_b, dattn_w, dattn_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = _zeros_like_params(params)
+        bufs, sunk = _param_grad_buffers(params)
+        (dn1w, dn1b, dv_w, dv_b, dattn_w, dattn_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = bufs
         dy2 = dy.reshape(T, C).contiguous()
         dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, dgelu_of=h)
         dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b)
@@ -187,8 +214,7 @@ class OutlookerBlockFn(torch.autograd.Function):
         dxn1 = _linear_bwd(dv.view(T, C), xn1, v_w, dv_w, dv_b)
         ops.avgpool2_bwd_acc(dpooled.view(B, (H + 1) // 2, (W + 1) // 2, C), dxn1.view(B, H, W, C))
         dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b)
-        return (dx.view(dy.shape), dn1w, dn1b, dv_w, dv_b, dattn_w, dattn_b, dproj_w, dproj_b, dn2w, dn2b,
-                dfc1_w, dfc1_b, dfc2_w, dfc2_b, None, None)
+        return (dx.view(dy.shape), *_finish_param_grads(params, bufs, sunk), None, None)
 
 
 # --------------------------------------------------------------------- fine-grained pieces

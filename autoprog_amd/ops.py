@@ -109,13 +109,13 @@ def gemm_nt(a, b, n=None, k=None, bias=None, gelu=False, preact_out=None, dgelu_
     return out
 
 
-def gemm_tn_acc(a, b, c, n1=None, n2=None):
-    """c[:n1, :n2] += a[:, :n1]^T @ b[:, :n2]   (c fp32, accumulated)."""
+def gemm_tn_acc(a, b, c, n1=None, n2=None, colsum=None):
+    """c[:n1, :n2] += a[:, :n1]^T @ b[:, :n2]   (c fp32, accumulated); optionally colsum[:n1] += a.sum(0)."""
     _req(a, BF16, "a"); _req(b, BF16, "b"); _req(c, torch.float32, "c")
     n1 = c.shape[0] if n1 is None else n1
     n2 = c.shape[1] if n2 is None else n2
     check(lib.ap_gemm_tn_acc(a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1], c.data_ptr(), c.shape[1], a.shape[0], n1, n2,
-                             _stream()), "ap_gemm_tn_acc")
+                             colsum.data_ptr() if colsum is not None else None, _stream()), "ap_gemm_tn_acc")
     return c
 
 

@@ -157,6 +157,7 @@ def main():
     for n_, p_ in model.named_parameters():
         (no_decay if (p_.dim() == 1 or n_.endswith(".bias") or n_ in skip) else decay).append(p_)
     reducer = GradientBucketReducer(list(model.parameters()), world_size=world)
+    reducer.install_sink()
     opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": no_decay, "weight_decay": 0.0}], lr=1.6e-3, fused=True)
     ema_decays = [0.998, 0.9986, 0.999, 0.9996]
     live = [t for t in model.state_dict().values() if t.dtype.is_floating_point]

@@ -69,9 +69,10 @@ typedef struct ap_gemm_epilogue {
 } ap_gemm_epilogue;
 int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C, int ldc,
                int M, int N, int K, const ap_gemm_epilogue* epi, ap_stream_t stream);
-/* weight gradient: C[N1,N2] += A[M,N1]^T . B[M,N2]   (fp32 accumulate into C, atomics) */
+/* weight gradient: C[N1,N2] += A[M,N1]^T . B[M,N2]   (fp32 accumulate into C, atomics);
+ * optional fused bias gradient: colsum_A[n] += sum_m A[m,n] (NULL to skip) */
 int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* C, int ldc,
-                   int M, int N1, int N2, ap_stream_t stream);
+                   int M, int N1, int N2, float* colsum_A, ap_stream_t stream);
 /* bias gradient: out[n] += sum_m A[m,n] */
 int ap_colsum_acc(const ap_bf16* A, int lda, float* out, int M, int N, ap_stream_t stream);
 

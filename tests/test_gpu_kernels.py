@@ -126,9 +126,15 @@ def test_gemm_tn_acc(ops, M, N1, N2):
     a, b = rnd(M, l1, seed=1), rnd(M, l2, seed=2)
     c0 = torch.randn(N1, N2, generator=torch.Generator().manual_seed(3))
     c = dev(c0)
-    ops.gemm_tn_acc(dev(a), dev(b), c)
+    cs0 = torch.randn(N1, generator=torch.Generator().manual_seed(4))
+    cs = dev(cs0)
+    ops.gemm_tn_acc(dev(a), dev(b), c, colsum=cs)
     ref = c0.double() + a[:, :N1].double().t() @ b[:, :N2].double()
     assert rel(c, ref) < TOL_F32
+    assert rel(cs, cs0.double() + a[:, :N1].double().sum(0)) < TOL_F32
+    c2 = dev(c0)
+    ops.gemm_tn_acc(dev(a), dev(b), c2)                      # without the fused bias gradient
+    assert rel(c2, ref) < TOL_F32
 
 
 def test_colsum(ops):
