@@ -281,13 +281,14 @@ class PatchEmbed(nn.Module):
                 nn.BatchNorm2d(hidden_dim), nn.ReLU(inplace=True))
         self.proj = nn.Conv2d(hidden_dim, embed_dim, kernel_size=patch_size // stem_stride, stride=patch_size // stem_stride)
         self.num_patches = (img_size // patch_size) * (img_size // patch_size)
+        self.compute_dtype = BF16          # torch.float32 runs the MIOpen stem un-autocast (parity debugging)
 
     def forward(self, x):
         """[B,3,r,r] -> NCHW feature map (channels_last memory, bf16)"""
         if not x.is_cuda:
             raise RuntimeError("autoprog_amd models run on the GPU only (no CPU fallback)")
         x = x.contiguous(memory_format=torch.channels_last)
-        with torch.autocast("cuda", dtype=BF16):
+        with torch.autocast("cuda", dtype=BF16, enabled=self.compute_dtype == BF16):
             if self.stem_conv:
                 x = self.conv(x)
             x = self.proj(x)
