@@ -42,11 +42,78 @@ struct EpiArgs {
     int rows_per_scale; const bf16_t* residual; int ldr; int dbg;
 };
 
+// epilogue of 8 consecutive output columns [n, n+8) of row m held in v[] (fp32 accumulators):
+// +bias; GELU (storing the pre-activation); * gelu'(h); * DropPath row scale; + residual; bf16 store.
+// All global accesses are 16-byte when the chunk is complete and the leading dimensions allow it.
+__device__ __forceinline__ void epi_chunk(float* v, int m, int n, int N, int ldc, bool vec_ok, const EpiArgs& ep, bf16_t* __restrict__ C) {
+    const int nval = min(8, N - n);
+    const bool full = (nval == 8) && vec_ok;
+    if (ep.bias) {
+        if (nval == 8) {
+            const float4 b0 = *reinterpret_cast<const float4*>(ep.bias + n), b1 = *reinterpret_cast<const float4*>(ep.bias + n + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (q < nval) v[q] += ep.bias[n + q];
+        }
+    }
+    if (ep.gelu) {
+        if (ep.preact) {
+            bf16_t* p = ep.preact + (int64_t)m * ldc + n;
+            if (full) st16(p, pack8(v));
+            else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (q < nval) p[q] = f2bf(v[q]);
+            }
+            // the activation is applied to the ROUNDED pre-activation so that backward (which reads the
+            // stored bf16 h) differentiates exactly what forward computed
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = bf2f(f2bf(v[q]));
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]);
+    }
+    if (ep.dgelu_of) {
+        const bf16_t* hp = ep.dgelu_of + (int64_t)m * ldc + n;
+        float h[8];
+        if (full) unpack8(ld16(hp), h);
+        else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) h[q] = (q < nval) ? bf2f(hp[q]) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] *= gelu_erf_grad(h[q]);
+    }
+    if (ep.row_scale) {
+        const float rs = ep.row_scale[m / ep.rows_per_scale];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] *= rs;
+    }
+    if (ep.residual) {
+        const bf16_t* rp = ep.residual + (int64_t)m * ep.ldr + n;
+        float h[8];
+        if (full) unpack8(ld16(rp), h);
+        else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) h[q] = (q < nval) ? bf2f(rp[q]) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += h[q];
+    }
+    bf16_t* cp = C + (int64_t)m * ldc + n;
+    if (full) st16(cp, pack8(v));
+    else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (q < nval) cp[q] = f2bf(v[q]);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
           int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
-    __shared__ __attribute__((aligned(16))) bf16_t sA[SBM * SBK];
-    __shared__ __attribute__((aligned(16))) bf16_t sB[SBN * SBK];
+    __shared__ __attribute__((aligned(16))) bf16_t smem_nt[(SBM + SBN) * SBK];       // 32 KB: A tile | B tile; reused by the epilogue
+    bf16_t* sA = smem_nt;
+    bf16_t* sB = smem_nt + SBM * SBK;
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int m0 = (tile / tiles_n) * SBM, n0 = (tile % tiles_n) * SBN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -108,68 +175,36 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
     }
 
     // ---------------------------------------------------------------- epilogue
-    const bool vec_ok = ((ldc & 3) == 0) && (ep.residual == nullptr || (ep.ldr & 3) == 0);
+    // two passes of 64 rows: accumulators -> fp32 [64][128] tile in LDS (16-B chunk swizzle) -> every
+    // thread finishes 8 consecutive columns of a row with 16-byte coalesced global accesses
+    float* ctile = reinterpret_cast<float*>(smem_nt);
+    const bool vec_ok = ((ldc & 7) == 0) && (ep.residual == nullptr || (ep.ldr & 7) == 0);
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wm == pass) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + fr;
-        if (m >= M) continue;
-        const float rs = ep.row_scale ? ep.row_scale[m / ep.rows_per_scale] : 1.0f;
+            for (int mt = 0; mt < 4; ++mt) {
+                const int r = mt * 16 + fr;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + nt * 16 + 4 * g;
-            if (n >= N) continue;
-            float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
-            const bool full = (n + 3 < N) && vec_ok;
-            if (ep.bias) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < N) v[r] += ep.bias[n + r];
-            }
-            if (ep.gelu) {
-                if (ep.preact) {
-                    bf16_t* p = ep.preact + (int64_t)m * ldc + n;
-                    if (full) { u32x2 o; o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]); *reinterpret_cast<u32x2*>(p) = o; }
-                    else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) if (n + r < N) p[r] = f2bf(v[r]);
-                    }
-                    // the activation is applied to the ROUNDED pre-activation so that backward
-                    // (which reads the stored bf16 h) differentiates exactly what forward computed
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = bf2f(f2bf(v[r]));
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int c16 = (wn * 64 + nt * 16) / 4 + g;
+                    *reinterpret_cast<f32x4*>(ctile + r * SBN + ((c16 ^ (r & 7)) << 2)) = acc[nt][mt];
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-            }
-            if (ep.dgelu_of) {
-                const bf16_t* hp = ep.dgelu_of + (int64_t)m * ldc + n;
-                if (full) {
-                    const u32x2 h = *reinterpret_cast<const u32x2*>(hp);
-                    v[0] *= gelu_erf_grad(bf_lo(h[0])); v[1] *= gelu_erf_grad(bf_hi(h[0]));
-                    v[2] *= gelu_erf_grad(bf_lo(h[1])); v[3] *= gelu_erf_grad(bf_hi(h[1]));
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < N) v[r] *= gelu_erf_grad(bf2f(hp[r]));
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= rs;
-            if (ep.residual) {
-                const bf16_t* rp = ep.residual + (int64_t)m * ep.ldr + n;
-                if (full) {
-                    const u32x2 h = *reinterpret_cast<const u32x2*>(rp);
-                    v[0] += bf_lo(h[0]); v[1] += bf_hi(h[0]); v[2] += bf_lo(h[1]); v[3] += bf_hi(h[1]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < N) v[r] += bf2f(rp[r]);
-                }
-            }
-            bf16_t* cp = C + (int64_t)m * ldc + n;
-            if (full) { u32x2 o; o[0] = pack_bf2(v[0], v[1]); o[1] = pack_bf2(v[2], v[3]); *reinterpret_cast<u32x2*>(cp) = o; }
-            else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < N) cp[r] = f2bf(v[r]);
             }
         }
+        __syncthreads();
+#pragma unroll 2
+        for (int id = tid; id < 64 * (SBN / 8); id += 256) {
+            const int r = id >> 4, j = id & 15;
+            const int m = m0 + pass * 64 + r, n = n0 + 8 * j;
+            if (m >= M || n >= N) continue;
+            float v[8];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(ctile + r * SBN + (((2 * j) ^ (r & 7)) << 2));
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(ctile + r * SBN + (((2 * j + 1) ^ (r & 7)) << 2));
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+            epi_chunk(v, m, n, N, ldc, vec_ok, ep, C);
+        }
+        __syncthreads();
     }
 }
 
@@ -302,64 +337,7 @@ k_gemm_nt_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(ctile + r * TBN + (((2 * j + 1) ^ (r & 7)) << 2));
                 v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
             }
-            const int nval = min(8, N - n);
-            const bool full = (nval == 8) && vec_ok;
-            if (ep.bias) {
-                if (nval == 8) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(ep.bias + n), b1 = *reinterpret_cast<const float4*>(ep.bias + n + 4);
-                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) if (q < nval) v[q] += ep.bias[n + q];
-                }
-            }
-            if (ep.gelu) {
-                if (ep.preact) {
-                    bf16_t* p = ep.preact + (int64_t)m * ldc + n;
-                    if (full) st16(p, pack8(v));
-                    else {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) if (q < nval) p[q] = f2bf(v[q]);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = bf2f(f2bf(v[q]));       // activation of the ROUNDED pre-activation
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]);
-            }
-            if (ep.dgelu_of) {
-                const bf16_t* hp = ep.dgelu_of + (int64_t)m * ldc + n;
-                float h[8];
-                if (full) unpack8(ld16(hp), h);
-                else {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) h[q] = (q < nval) ? bf2f(hp[q]) : 0.f;
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] *= gelu_erf_grad(h[q]);
-            }
-            if (ep.row_scale) {
-                const float rs = ep.row_scale[m / ep.rows_per_scale];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] *= rs;
-            }
-            if (ep.residual) {
-                const bf16_t* rp = ep.residual + (int64_t)m * ep.ldr + n;
-                float h[8];
-                if (full) unpack8(ld16(rp), h);
-                else {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) h[q] = (q < nval) ? bf2f(rp[q]) : 0.f;
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += h[q];
-            }
-            bf16_t* cp = C + (int64_t)m * ldc + n;
-            if (full) st16(cp, pack8(v));
-            else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) if (q < nval) cp[q] = f2bf(v[q]);
-            }
+            epi_chunk(v, m, n, N, ldc, vec_ok, ep, C);
         }
         // the staging tile is rewritten only after the next tile's nk >= 1 K-step barriers: no barrier needed here
     }
@@ -478,6 +456,119 @@ k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
         }
 }
 
+// --------------------------------------------------------------------- wgrad, LDS-DMA ring
+// Same reduction as k_gemm_tn for the full 64-token steps of [0, M - M%64): 8 waves (2 x 4, wave tile
+// 64 x 32), operand tiles [64 tok][128] filled by global_load_lds into a 4-stage ring (128 KB), three
+// steps in flight behind a counted s_waitcnt vmcnt and ONE raw s_barrier per step (the register-staged
+// kernel needs two barriers + 8 ds_write_b128 per step and was latency bound at ~280 TFLOP/s).
+// The LDS image is written linearly by the DMA (4 rows of 256 B per wave instruction), so the
+// transposed-read swizzle tn_swz(row) is applied to the per-lane SOURCE chunk.  Columns beyond N1/N2
+// are clamped (they only feed output rows/cols that are never stored).
+__global__ void __launch_bounds__(512)
+k_gemm_tn_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+               int steps_total, int N1, int N2, int steps_per_split, float* __restrict__ colsum) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tn_raw[];
+    constexpr int STAGES = 4;
+    constexpr int STAGE = 2 * TM * 128;              // elements: A tile then B tile
+    constexpr int NI = 4;
+    bf16_t* ring = reinterpret_cast<bf16_t*>(tn_raw);
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int step_begin = blockIdx.z * steps_per_split;
+    const int step_end = min(steps_total, step_begin + steps_per_split);
+    const int nsteps = step_end - step_begin;
+    if (nsteps <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wk = wave & 3;         // 2 x 4 waves: 64 (n1) x 32 (n2) per wave
+    // DMA sources: row group rg = wave + 8*i covers 4 token rows of the A tile (rg < 16) or the B tile
+    const bf16_t* src[NI];
+    int64_t sstride[NI];
+    const int lastA = (N1 - 1 - n0) >> 3, lastB = (N2 - 1 - k0) >> 3;        // last valid 16-B chunk of this tile
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int rg = wave + 8 * i;
+        const bool isA = rg < 16;
+        const int r = (rg & 15) * 4 + (lane >> 4);
+        int c = (lane & 15) ^ tn_swz(r);
+        c = min(c, isA ? lastA : lastB);
+        src[i] = isA ? A + (int64_t)(step_begin * TM + r) * lda + n0 + c * 8 : B + (int64_t)(step_begin * TM + r) * ldb + k0 + c * 8;
+        sstride[i] = (int64_t)TM * (isA ? lda : ldb);
+    }
+    auto issue = [&](int t, int stage) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int rg = wave + 8 * i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + t * sstride[i]),
+                                             (__attribute__((address_space(3))) void*)(ring + stage * STAGE + rg * 512), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_colsum = (colsum != nullptr) && (blockIdx.y == 0) && (wk == 0);
+    f32x4 csum[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) csum[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+
+    int issued = 0;
+    for (; issued < STAGES - 1 && issued < nsteps; ++issued) issue(issued, issued);
+    int stage = 0;
+    for (int t = 0; t < nsteps; ++t) {
+        const int ahead = issued - t - 1;            // steps in flight beyond t: 0..STAGES-2
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (issued < nsteps) { issue(issued, (stage + STAGES - 1) % STAGES); ++issued; }
+        const bf16_t* sA = ring + stage * STAGE;
+        const bf16_t* sB = sA + TM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = tr_frag(sA, ks * 32, wn * 64 + i * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) bfr[i] = tr_frag(sB, ks * 32, wk * 32 + i * 16, lane);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
+            if (do_colsum) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) csum[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], ones, csum[nt], 0, 0, 0);
+            }
+        }
+        stage = (stage == STAGES - 1) ? 0 : stage + 1;
+    }
+    const int fr = lane & 15, g = lane >> 4;
+    if (do_colsum && fr == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + nt * 16 + 4 * g + r;
+                if (n < N1) atomicAdd(colsum + n, csum[nt][r]);
+            }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int kk = k0 + wk * 32 + kt * 16 + fr;
+            if (kk >= N2) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + nt * 16 + 4 * g + r;
+                if (n < N1) atomicAdd(C + (int64_t)n * ldc + kk, acc[nt][kt][r]);
+            }
+        }
+}
+
 extern "C" {
 
 int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C, int ldc, int M, int N, int K,
@@ -495,7 +586,9 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     }
     (void)hipGetLastError();
     static int force_small = -1;
-    if (force_small < 0) { const char* e = getenv("AP_GEMM_SMALL_TILES"); force_small = (e && e[0] == '1') ? 1 : 0; }
+    // the persistent one-workgroup-per-CU ring kernel measured ~8 % slower than the multi-workgroup 128x128
+    // kernel with the same coalesced epilogue (DESIGN.md "GEMM experiments"); kept selectable for tuning
+    if (force_small < 0) { const char* e = getenv("AP_GEMM_NT_RING"); force_small = (e && e[0] == '1') ? 0 : 1; }
     if ((K & 63) == 0 && !force_small) {
         static int n_cu = 0;
         if (n_cu == 0) { int dev = 0; hipGetDevice(&dev); hipDeviceProp_t pr; n_cu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
@@ -531,17 +624,39 @@ int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* 
     if (M <= 0 || N1 <= 0 || N2 <= 0) return AP_ERR_SHAPE;
     if ((lda & 7) || (ldb & 7) || lda < N1 || ldb < N2 || ldc < N2) return AP_ERR_SHAPE;
     const int t1 = (N1 + 127) / 128, t2 = (N2 + 127) / 128;
-    const int total_steps = (M + TM - 1) / TM;
-    // every split adds its 128x128 fp32 tile with atomics (~1.3 TB/s chip-wide): keep the split count
-    // near 2 workgroups per CU and at least 4 token steps per workgroup
-    int splits = (512 + t1 * t2 - 1) / (t1 * t2);
-    if (splits > total_steps / 4) splits = total_steps / 4;
-    if (splits < 1) splits = 1;
-    const int sps = (total_steps + splits - 1) / splits;
-    splits = (total_steps + sps - 1) / sps;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(k_gemm_tn, dim3(t1, t2, splits), dim3(256), 0, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N1, N2, sps, colsum_A);
-    return ap_check_launch();
+    static int tn_old = -1;
+    if (tn_old < 0) { const char* e = getenv("AP_GEMM_TN_RING"); tn_old = (e && e[0] == '1') ? 0 : 1; }   // ring variant lost to the multi-workgroup kernel
+    const int full_steps = tn_old ? 0 : M / TM;
+    if (full_steps > 0) {
+        // ring kernel over the full 64-token steps: ~1 workgroup per CU, >= 8 steps per workgroup
+        int splits = (256 + t1 * t2 - 1) / (t1 * t2);
+        if (splits > full_steps / 8) splits = full_steps / 8;
+        if (splits < 1) splits = 1;
+        const int sps = (full_steps + splits - 1) / splits;
+        splits = (full_steps + sps - 1) / sps;
+        const size_t lds = (size_t)4 * 2 * TM * 128 * sizeof(bf16_t);
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_gemm_tn_ring, dim3(t1, t2, splits), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, full_steps, N1, N2, sps, colsum_A);
+        const int rc = ap_check_launch();
+        if (rc != AP_OK) return rc;
+    }
+    const int done = full_steps * TM;
+    if (done < M) {                                   // token tail (or everything when the ring is disabled)
+        const int Mt = M - done;
+        const int total_steps = (Mt + TM - 1) / TM;
+        int splits = (512 + t1 * t2 - 1) / (t1 * t2);
+        if (splits > total_steps / 4) splits = total_steps / 4;
+        if (splits < 1) splits = 1;
+        const int sps = (total_steps + splits - 1) / splits;
+        splits = (total_steps + sps - 1) / sps;
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_gemm_tn, dim3(t1, t2, splits), dim3(256), 0, (hipStream_t)stream, A + (int64_t)done * lda, lda, B + (int64_t)done * ldb, ldb,
+                           C, ldc, Mt, N1, N2, sps, colsum_A);
+        return ap_check_launch();
+    }
+    return AP_OK;
 }
 
 }  // extern "C"
