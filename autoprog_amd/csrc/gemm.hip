@@ -361,13 +361,37 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int row0, int col0
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// same fragment from a per-lane base offset computed once outside the token loop: the swizzle term is
+// lane-constant (it depends on q = (lane&15)>>2 and g&1 only), so every read of the loop is
+// base[t] + compile-time immediate (ks*32 rows, +4 rows for the second half)
+__device__ __forceinline__ int tr_base(int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int r1 = 8 * g + q;
+    const int j = (col0 >> 3) + (p >> 1);
+    return r1 * 128 + ((j ^ tn_swz(r1)) << 3) + (p & 1) * 4;
+}
+__device__ __forceinline__ bf16x8 tr_frag_at(const bf16_t* tile, int base, int ks) {
+    const bf16_t* a1 = tile + base + ks * 32 * 128;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1 + 4 * 128));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 __global__ void __launch_bounds__(256)
 k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
-          int M, int N1, int N2, int steps_per_split, float* __restrict__ colsum) {
+          int M, int N1, int N2, int steps_per_split, float* __restrict__ colsum, int t1, int t2, int nblocks) {
     __shared__ __attribute__((aligned(16))) bf16_t sA[TM * 128];
     __shared__ __attribute__((aligned(16))) bf16_t sB[TM * 128];
-    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-    const int step_begin = blockIdx.z * steps_per_split;
+    // XCD-aware decode: workgroups that share an XCD (and its L2) get consecutive ids, i.e. all output
+    // tiles of the SAME token split, so each token range is fetched from HBM by one L2 only
+    // (before: 347 MB of beyond-L2 traffic for 77 MB of operands on the qkv shape)
+    const int id = xcd_remap(blockIdx.x, nblocks);
+    const int bz = id / (t1 * t2), tl = id - bz * (t1 * t2);
+    const int by = tl / t1, bx = tl - by * t1;
+    const int n0 = bx * 128, k0 = by * 128;
+    const int step_begin = bz * steps_per_split;
     const int total_steps = (M + TM - 1) / TM;
     const int step_end = min(total_steps, step_begin + steps_per_split);
     if (step_begin >= step_end) return;
@@ -375,13 +399,15 @@ k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
     const int wn = wave >> 1, wk = wave & 1;
     const int srow = tid >> 4, j = tid & 15;            // 4 chunks: rows srow + 16*i, chunk j
     const bool a_ok = (n0 + j * 8) < N1, b_ok = (k0 + j * 8) < N2;
-    u32x4 ra[4], rb[4];
+    // two register sets: the loads of steps t+1 and t+2 are in flight while step t is computed
+    // (rocprof: 1.4 waves/SIMD resident, 42 % of wave cycles parked waiting for the single prefetch)
+    u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    auto gload = [&](int step) {
+    auto gload = [&](u32x4* ra, u32x4* rb, int step) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = step * TM + srow + 16 * i;
-            const bool ok = m < M;
+            const bool ok = (m < M) && (step < step_end);
             ra[i] = (ok && a_ok) ? ld16(A + (int64_t)m * lda + n0 + j * 8) : zero4;
             rb[i] = (ok && b_ok) ? ld16(B + (int64_t)m * ldb + k0 + j * 8) : zero4;
         }
@@ -394,31 +420,36 @@ k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
 
     // optional fused bias gradient: column sums of A = A^T . 1, one extra MFMA per A fragment with an
     // all-ones B fragment, done only by the wk==0 waves of the blockIdx.y==0 tiles
-    const bool do_colsum = (colsum != nullptr) && (blockIdx.y == 0) && (wk == 0);
+    const bool do_colsum = (colsum != nullptr) && (by == 0) && (wk == 0);
     f32x4 csum[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) csum[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
-    gload(step_begin);
-    for (int step = step_begin; step < step_end; ++step) {
+    int abase[4], bbase[4], woff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        abase[t] = tr_base(wn * 64 + t * 16, lane);
+        bbase[t] = tr_base(wk * 64 + t * 16, lane);
+        const int r = srow + 16 * t;
+        woff[t] = r * 128 + ((j ^ tn_swz(r)) << 3);
+    }
+    auto stage_and_compute = [&](u32x4* ra, u32x4* rb, int refill_step) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = srow + 16 * i;
-            const int off = r * 128 + ((j ^ tn_swz(r)) << 3);
-            st16(sA + off, ra[i]);
-            st16(sB + off, rb[i]);
+            st16(sA + woff[i], ra[i]);
+            st16(sB + woff[i], rb[i]);
         }
         __syncthreads();
-        if (step + 1 < step_end) gload(step + 1);
+        gload(ra, rb, refill_step);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[4], bfr[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                af[t] = tr_frag(sA, ks * 32, wn * 64 + t * 16, lane);
-                bfr[t] = tr_frag(sB, ks * 32, wk * 64 + t * 16, lane);
+                af[t] = tr_frag_at(sA, abase[t], ks);
+                bfr[t] = tr_frag_at(sB, bbase[t], ks);
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
@@ -431,6 +462,12 @@ k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
             }
         }
         __syncthreads();
+    };
+    gload(ra0, rb0, step_begin);
+    gload(ra1, rb1, step_begin + 1);
+    for (int step = step_begin; step < step_end; step += 2) {
+        stage_and_compute(ra0, rb0, step + 2);
+        if (step + 1 < step_end) stage_and_compute(ra1, rb1, step + 3);
     }
     const int fr = lane & 15, g = lane >> 4;
     if (do_colsum && fr == 0) {
@@ -646,14 +683,16 @@ int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* 
     if (done < M) {                                   // token tail (or everything when the ring is disabled)
         const int Mt = M - done;
         const int total_steps = (Mt + TM - 1) / TM;
-        int splits = (512 + t1 * t2 - 1) / (t1 * t2);
+        static int target_blocks = 0;
+        if (target_blocks == 0) { const char* e = getenv("AP_GEMM_TN_BLOCKS"); target_blocks = e ? atoi(e) : 384;      // measured optimum (atomics vs parallelism), DESIGN.md }
+        int splits = (target_blocks + t1 * t2 - 1) / (t1 * t2);
         if (splits > total_steps / 4) splits = total_steps / 4;
         if (splits < 1) splits = 1;
         const int sps = (total_steps + splits - 1) / splits;
         splits = (total_steps + sps - 1) / sps;
         (void)hipGetLastError();
-        hipLaunchKernelGGL(k_gemm_tn, dim3(t1, t2, splits), dim3(256), 0, (hipStream_t)stream, A + (int64_t)done * lda, lda, B + (int64_t)done * ldb, ldb,
-                           C, ldc, Mt, N1, N2, sps, colsum_A);
+        hipLaunchKernelGGL(k_gemm_tn, dim3(t1 * t2 * splits), dim3(256), 0, (hipStream_t)stream, A + (int64_t)done * lda, lda, B + (int64_t)done * ldb, ldb,
+                           C, ldc, Mt, N1, N2, sps, colsum_A, t1, t2, t1 * t2 * splits);
         return ap_check_launch();
     }
     return AP_OK;
