@@ -684,7 +684,7 @@ int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* 
         const int Mt = M - done;
         const int total_steps = (Mt + TM - 1) / TM;
         static int target_blocks = 0;
-        if (target_blocks == 0) { const char* e = getenv("AP_GEMM_TN_BLOCKS"); target_blocks = e ? atoi(e) : 384;      // measured optimum (atomics vs parallelism), DESIGN.md }
+        if (target_blocks == 0) { const char* e = getenv("AP_GEMM_TN_BLOCKS"); target_blocks = e ? atoi(e) : 384; /* measured optimum: atomics vs parallelism */ }
         int splits = (target_blocks + t1 * t2 - 1) / (t1 * t2);
         if (splits > total_steps / 4) splits = total_steps / 4;
         if (splits < 1) splits = 1;
