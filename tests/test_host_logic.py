@@ -1,0 +1,137 @@
+"""CPU tests of the product's host-side logic (no GPU, no kernel launches): integer bookkeeping
+against the reference golden tables (bit exact), constructor/registry API, state-dict compatibility
+with reference-produced state dicts, and the C ABI surface of the built library."""
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests._golden import load, sub
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ integer bookkeeping (bit exact)
+def test_make_divisible_and_index_maps_match_reference():
+    from autoprog_amd.prog import make_divisible, new_idx, get_new_layer_idx
+    g = load("int_tables")
+    got = np.array([[make_divisible(float(v), int(d)) for d in g["md_div"]] for v in g["md_v"]])
+    assert np.array_equal(got, g["md_out"])
+    for (prev, new), row, fresh in zip(g["ni_pairs"], g["ni_map"], g["ni_fresh"]):
+        prev, new = int(prev), int(new)
+        assert [new_idx(i, prev, new) for i in range(new)] == list(row[:new])
+        assert get_new_layer_idx(prev, new) == [int(v) for v in fresh if v >= 0]
+
+
+def test_active_layer_mask_matches_reference_set_sample_config():
+    from autoprog_amd.prog import ActiveLayerMask
+    g = load("int_tables")
+    for (l, lmin, lmax, d0, d1), mask in zip(g["ss_cfg"], g["ss_mask"]):
+        m = ActiveLayerMask(int(l), int(lmin), int(lmax))
+        flags = [int(m.is_identity(0, i)) for i in range(d0)] + [int(m.is_identity(1, i)) for i in range(d1)]
+        assert flags == [int(v) for v in mask if v >= 0], (l, lmin, lmax)
+    # SURVEY.md pinned values on h12_l18 with min 9 / max 18
+    assert sorted(ActiveLayerMask(9, 9, 18).skip[0]) == [1, 3] and sorted(ActiveLayerMask(9, 9, 18).skip[1]) == [1, 3, 5, 7, 9, 11, 13]
+    assert sorted(ActiveLayerMask(12, 9, 18).skip[1]) == [1, 3, 5, 7, 9, 11] and not ActiveLayerMask(12, 9, 18).skip[0]
+    assert sorted(ActiveLayerMask(15, 9, 18).skip[1]) == [1, 3, 5] and not any(ActiveLayerMask(18, 9, 18).skip)
+
+
+def test_model_set_sample_config_flags():
+    from autoprog_amd.models import create_model
+    m = create_model("model_variant", variant="volo_h2_l18", num_classes=8)
+    m.set_sample_config(dict(layer_num=12, min_layer_num=9, max_layer_num=18))
+    assert [int(b.is_identity_layer) for b in m.network[0]] == [0, 0, 0, 0]
+    assert [int(b.is_identity_layer) for b in m.network[2]] == [0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 0]
+
+
+def test_rand_bbox_reproduces_reference_rng_sequence():
+    from autoprog_amd.models.volo import rand_bbox
+    g = load("int_tables")
+    for (seed, grid), row in zip(g["bb_seed"], g["bb_out"]):
+        np.random.seed(int(seed))
+        lam = np.random.beta(1.0, 1.0)
+        assert lam == row[0]
+        assert list(rand_bbox((4, int(grid), int(grid), 8), lam, scale=2)) == [int(v) for v in row[1:]]
+
+
+@pytest.mark.parametrize("tag,kw", [("script", dict(aa_scale=0.5, dp_scale=0.0, re_scale=0.0, epochs=100)), ("default", {}),
+                                    ("s3", dict(num_stages=3, epochs=90, r_scale=0.6, l_scale=0.4))])
+def test_progressive_schedule_matches_reference(tag, kw):
+    from autoprog_amd.prog import progressive_schedule
+    g = load("int_tables")
+    a = types.SimpleNamespace(num_stages=4, r_scale=0.5, h_scale=1.0, l_scale=0.5, aa_scale=0.0, dp_scale=-0.5, re_scale=-0.5,
+                              resize_scale=[1.0, 1.0], aa="rand-m9-mstd0.5-inc1", drop_path=0.1, reprob=0.25, scale=[0.08, 1.0], epochs=300)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    e, r, h, l, aa, dp, re_, rs = progressive_schedule(a, r_max=224, h_max=12, l_max=18)
+    mags = [int(s.split("-")[1].lstrip("m")) if s else 0 for s in aa]
+    for nm, val in zip(("e", "r", "h", "l", "aa"), (e, r, h, l, mags)):
+        assert list(val) == [int(v) for v in g["ps_%s_%s" % (tag, nm)]], nm
+    for nm, val in zip(("dp", "re", "rs"), (dp, re_, rs)):
+        assert np.array_equal(np.array(val), g["ps_%s_%s" % (tag, nm)]), nm
+
+
+# ------------------------------------------------------------------ constructor / registry API
+def test_registry_and_parameter_counts():
+    from autoprog_amd.models import create_model, list_models
+    names = list_models()
+    for n in ["model_variant", "volo_d1", "volo_d2", "volo_d3", "volo_d4", "volo_d5", "deit_tiny_patch16_224", "deit_base_distilled_patch16_384"]:
+        assert n in names
+    # timm semantics: None-valued kwargs are dropped, drop_connect_rate aliases drop_path_rate
+    m = create_model("model_variant", variant="volo_h12_l18", pretrained=False, num_classes=None, drop_rate=0.0, drop_connect_rate=None,
+                     drop_path_rate=0.1, drop_block_rate=None, global_pool=None, bn_tf=False, bn_momentum=None, bn_eps=None, img_size=None)
+    assert sum(p.numel() for p in m.parameters()) == 26632040          # exact VOLO-D1 size
+    assert len(m.state_dict()) == 260                                   # SURVEY.md row A14 (incl. BN buffers)
+    assert m.num_classes == 1000 and m.no_weight_decay() == {"pos_embed", "cls_token"}
+    assert abs(m.network[2][13].drop_prob - 0.1) < 1e-12 and m.network[2][0].drop_prob == pytest.approx(0.1 * 4 / 17)
+    from autoprog_amd.models.volo import volo_d1, volo_d5
+    assert sum(p.numel() for p in volo_d1().parameters()) == 26632040
+    assert sum(p.numel() for p in volo_d5(img_size=448).parameters()) == 295907168  # exact VOLO-D5 size (448 px pos-embed)
+    with pytest.raises(RuntimeError):
+        create_model("no_such_model")
+
+
+def test_state_dict_keys_match_reference_checkpoints():
+    """state dicts produced by the REAL reference load strictly into the mirror modules"""
+    from autoprog_amd.models import create_model
+    d = load("volo_full")
+    for tag, variant, classes in [("h2_l3", "volo_h2_l3", 16), ("h2_l6", "volo_h2_l6", 12)]:
+        model = create_model("model_variant", variant=variant, num_classes=classes, img_size=64, stem_hidden_dim=16)
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sub(d, tag + ".w").items()}
+        res = model.load_state_dict(sd, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+
+
+def test_deit_variants_construct():
+    from autoprog_amd.models import create_model
+    m = create_model("model_variant", variant="deit_h3_l4")
+    assert sum(p.numel() for p in m.parameters()) == 2158504
+    skip = m.set_sample_config(dict(layer_num=3, min_layer_num=2, max_layer_num=4))
+    assert skip == [1]
+    t = create_model("deit_tiny_distilled_patch16_224")
+    assert t.pos_embed.shape == (1, 198, 192) and hasattr(t, "head_dist")
+
+
+def test_models_refuse_cpu_tensors():
+    from autoprog_amd.models import create_model
+    m = create_model("model_variant", variant="volo_h2_l3", num_classes=8, img_size=64, stem_hidden_dim=16)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 64, 64))
+
+
+# ------------------------------------------------------------------ C ABI surface
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from autoprog_amd._lib import LIB_PATH, EXPORTED_SYMBOLS, lib
+    header = open(os.path.join(ROOT, "include", "autoprog_hip.h")).read()
+    declared = set(re.findall(r"\b(ap_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no entry points parsed from the header"
+    assert declared == set(EXPORTED_SYMBOLS), (declared ^ set(EXPORTED_SYMBOLS))
+    raw = ctypes.CDLL(LIB_PATH)
+    for sym in declared:
+        assert hasattr(raw, sym), sym
+    assert lib.ap_abi_version() == 1
+    assert lib.ap_error_string(-2).decode().startswith("configuration not supported")
