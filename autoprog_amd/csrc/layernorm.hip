@@ -64,12 +64,15 @@ k_ln_fwd(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const fl
     }
 }
 
-template <int V>
+template <int V, int U>
 __global__ void __launch_bounds__(256)
 k_ln_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
          const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
          bf16_t* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
          int64_t rows, int C, int G) {
+    // U rows per lane group are in flight per iteration: the row loop is a dependent chain
+    // load -> shuffle reduce -> store, so memory-level parallelism has to come from unrolling rows
+    // (the U=1 version ran at ~40 % of the HBM rate with 12 sequential iterations per wave)
     extern __shared__ __attribute__((aligned(16))) float red[];     // [groups_per_block][C] x 2
     const int lane_in_group = threadIdx.x & (G - 1);
     const int groups_per_block = 256 / G;
@@ -83,20 +86,42 @@ k_ln_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const floa
 #pragma unroll
         for (int k = 0; k < 8; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; gam[i][k] = (ch < nchunks) ? gamma[8 * ch + k] : 0.f; }
     }
-    for (int64_t row = (int64_t)blockIdx.x * groups_per_block + group; row < rows; row += (int64_t)gridDim.x * groups_per_block) {
-        const float mu = mean[row], rs = rstd[row];
-        float g[V][8], xh[V][8];
-        float s1 = 0.f, s2 = 0.f;
+    const int64_t row_stride = (int64_t)gridDim.x * groups_per_block;
+    for (int64_t row0 = (int64_t)blockIdx.x * groups_per_block + group; row0 < rows; row0 += row_stride * U) {
+        u32x4 rdy[U][V], rx[U][V], rres[U][V];
+        float mu[U], rs[U];
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const int ch = lane_in_group + i * G;
-            if (ch < nchunks) {
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = row0 + u * row_stride;
+            const bool rok = row < rows;
+            mu[u] = rok ? mean[row] : 0.f;
+            rs[u] = rok ? rstd[row] : 0.f;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const int ch = lane_in_group + i * G;
+                const bool ok = rok && ch < nchunks;
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                rdy[u][i] = ok ? ld16(dy + row * C + 8 * ch) : z;
+                rx[u][i] = ok ? ld16(x + row * C + 8 * ch) : z;
+                rres[u][i] = (ok && dres != nullptr) ? ld16(dres + row * C + 8 * ch) : z;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = row0 + u * row_stride;
+            if (row >= rows) continue;
+            float g[V][8], xh[V][8];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const int ch = lane_in_group + i * G;
                 float d8[8], x8[8];
-                unpack8(ld16(dy + row * C + 8 * ch), d8);
-                unpack8(ld16(x + row * C + 8 * ch), x8);
+                unpack8(rdy[u][i], d8);
+                unpack8(rx[u][i], x8);
+                const bool ok = ch < nchunks;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    xh[i][k] = (x8[k] - mu) * rs;
+                    xh[i][k] = ok ? (x8[k] - mu[u]) * rs[u] : 0.f;
                     g[i][k] = d8[k] * gam[i][k];
                     s1 += g[i][k];
                     s2 += g[i][k] * xh[i][k];
@@ -104,22 +129,18 @@ k_ln_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const floa
                     ab[i][k] += d8[k];
                 }
             }
-        }
-        for (int o = G >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        s1 *= invC; s2 *= invC;
+            for (int o = G >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            s1 *= invC; s2 *= invC;
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const int ch = lane_in_group + i * G;
-            if (ch < nchunks) {
-                float o8[8];
-                if (dres != nullptr) unpack8(ld16(dres + row * C + 8 * ch), o8);
-                else {
+            for (int i = 0; i < V; ++i) {
+                const int ch = lane_in_group + i * G;
+                if (ch < nchunks) {
+                    float o8[8];
+                    unpack8(rres[u][i], o8);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) o8[k] = 0.f;
+                    for (int k = 0; k < 8; ++k) o8[k] += rs[u] * (g[i][k] - s1 - xh[i][k] * s2);
+                    st16(dx + row * C + 8 * ch, pack8(o8));
                 }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) o8[k] += rs * (g[i][k] - s1 - xh[i][k] * s2);
-                st16(dx + row * C + 8 * ch, pack8(o8));
             }
         }
     }
@@ -185,9 +206,9 @@ int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, co
     const size_t lds = (size_t)2 * gpb * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
-    if (V == 1) hipLaunchKernelGGL(k_ln_bwd<1>, dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);
-    else if (V == 2) hipLaunchKernelGGL(k_ln_bwd<2>, dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);
-    else hipLaunchKernelGGL(k_ln_bwd<4>, dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);
+    if (V == 1) hipLaunchKernelGGL((k_ln_bwd<1, 4>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);
+    else if (V == 2) hipLaunchKernelGGL((k_ln_bwd<2, 2>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);
+    else hipLaunchKernelGGL((k_ln_bwd<4, 1>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);
     return ap_check_launch();
 }
 

@@ -48,7 +48,7 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
 // stage rows [0,Npad) of one [N, ld] strided matrix slice (32 columns) into a swizzled LDS tile
 __device__ __forceinline__ void att_stage(bf16_t* tile, const bf16_t* src, int64_t ld, int N, int Npad) {
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    for (int idx = threadIdx.x; idx < Npad * 4; idx += 256) {
+    for (int idx = threadIdx.x; idx < Npad * 4; idx += blockDim.x) {
         const int row = idx >> 2, c = idx & 3;
         const u32x4 v = (row < N) ? ld16(src + (int64_t)row * ld + c * 8) : zero4;
         st16(tile + att_off(row, c), v);
@@ -120,7 +120,7 @@ k_mhsa_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __re
     }
 }
 
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(512)
 k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
            const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int heads, float scale, int NT) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
@@ -141,7 +141,7 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
     att_stage(Ks, base + C, ld, N, Npad);
     att_stage(Vs, base + 2 * C, ld, N, Npad);
     att_stage(Gs, gbase, C, N, Npad);
-    for (int idx = threadIdx.x; idx < Npad * 4; idx += 256) {      // Npad*4 is a multiple of 128: whole waves
+    for (int idx = threadIdx.x; idx < Npad * 4; idx += 512) {      // Npad*4 is a multiple of 128: whole waves
         const int row = idx >> 2, c = idx & 3;
         float part = 0.f;
         if (row < N) {
@@ -166,7 +166,7 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
     bf16_t* dbase = dqkv + (int64_t)b * N * ld + h * AHD;
 
     // ---- pass A: this wave owns key tile jt -> dK, dV
-    for (int jt = wave; jt < ntile; jt += 4) {
+    for (int jt = wave; jt < ntile; jt += 8) {
         const bf16x8 kf = att_row_frag(Ks, jt * 16, lane);
         const bf16x8 vf = att_row_frag(Vs, jt * 16, lane);
         f32x4 dk[2] = {z, z}, dv[2] = {z, z};
@@ -205,7 +205,7 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
         }
     }
     // ---- pass B: this wave owns query tile qt -> dQ
-    for (int qt = wave; qt < ntile; qt += 4) {
+    for (int qt = wave; qt < ntile; qt += 8) {
         const bf16x8 qf = att_row_frag(Qs, qt * 16, lane);
         const bf16x8 gf = att_row_frag(Gs, qt * 16, lane);
         const float flq = fl[qt * 16 + fr], fdq = fd[qt * 16 + fr];
@@ -400,7 +400,7 @@ int ap_mhsa_bwd(const ap_bf16* qkv, const ap_bf16* out, const ap_bf16* dout, con
     const size_t lds = (size_t)4 * nt * 16 * AHD * sizeof(bf16_t) + (size_t)2 * nt * 16 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_mhsa_bwd, grid, dim3(256), lds, s, qkv, out, dout, lse, dqkv, N, heads, scale, nt);
+    hipLaunchKernelGGL(k_mhsa_bwd, grid, dim3(512), lds, s, qkv, out, dout, lse, dqkv, N, heads, scale, nt);
     return ap_check_launch();
 }
 
