@@ -68,7 +68,7 @@ template <int V, int U>
 __global__ void __launch_bounds__(256)
 k_ln_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
          const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
-         bf16_t* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+         bf16_t* __restrict__ dx, float* __restrict__ partial,
          int64_t rows, int C, int G) {
     // U rows per lane group are in flight per iteration: the row loop is a dependent chain
     // load -> shuffle reduce -> store, so memory-level parallelism has to come from unrolling rows
@@ -156,11 +156,43 @@ k_ln_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const floa
         }
     }
     __syncthreads();
+    // per-block partials go to a workspace with plain stores; k_ln_bwd_reduce sums them.  (Atomics from
+    // ~1000 workgroups into the same 2*C floats ran at the contended-atomic rate and were 2/3 of the kernel.)
+    float* prow = partial + (int64_t)blockIdx.x * 2 * C;
     for (int c = threadIdx.x; c < C; c += 256) {
         float sg = 0.f, sb = 0.f;
         for (int gi = 0; gi < groups_per_block; ++gi) { sg += rg[gi * C + c]; sb += rb[gi * C + c]; }
-        atomicAdd(dgamma + c, sg);
-        atomicAdd(dbeta + c, sb);
+        prow[c] = sg;
+        prow[C + c] = sb;
+    }
+}
+
+// out[c] += sum_b partial[b][c] for the 2*C columns (dgamma | dbeta); 32 columns x 32 row slices per block,
+// independent loads unrolled x8 so the column sums are not a serial chain of L2 round trips
+__global__ void __launch_bounds__(1024)
+k_ln_bwd_reduce(const float* __restrict__ partial, int nblocks, int C2, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+    __shared__ float red[32][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    float s = 0.f;
+    if (c < C2) {
+        int b = ry;
+        for (; b + 7 * 32 < nblocks; b += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + u * 32) * C2 + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nblocks; b += 32) s += partial[(int64_t)b * C2 + c];
+    }
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < C2) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t += red[r][cx];
+        if (c < C) dgamma[c] += t; else dbeta[c - C] += t;
     }
 }
 
@@ -193,9 +225,17 @@ int ap_layernorm_fwd(const ap_bf16* x, const float* gamma, const float* beta, ap
     return ap_check_launch();
 }
 
+size_t ap_layernorm_bwd_workspace(int64_t rows, int C) {
+    (void)rows;
+    return (size_t)1024 * 2 * (size_t)C * sizeof(float);
+}
+
 int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* mean, const float* rstd,
-                     const ap_bf16* dres, ap_bf16* dx, float* dgamma, float* dbeta, int64_t rows, int C, ap_stream_t stream) {
-    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) return AP_ERR_NULL;
+                     const ap_bf16* dres, ap_bf16* dx, float* dgamma, float* dbeta, int64_t rows, int C,
+                     void* workspace, size_t ws_bytes, ap_stream_t stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return AP_ERR_NULL;
+    if (ws_bytes < ap_layernorm_bwd_workspace(rows, C)) return AP_ERR_SHAPE;
+    float* partial = static_cast<float*>(workspace);
     if (C <= 0 || (C & 7)) return AP_ERR_SHAPE;
     if (C > 2048) return AP_ERR_UNSUPPORTED;
     if (rows <= 0) return AP_OK;
@@ -206,9 +246,12 @@ int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, co
     const size_t lds = (size_t)2 * gpb * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
-    if (V == 1) hipLaunchKernelGGL((k_ln_bwd<1, 4>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);
-    else if (V == 2) hipLaunchKernelGGL((k_ln_bwd<2, 2>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);
-    else hipLaunchKernelGGL((k_ln_bwd<4, 1>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C, G);
+    if (V == 1) hipLaunchKernelGGL((k_ln_bwd<1, 4>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);
+    else if (V == 2) hipLaunchKernelGGL((k_ln_bwd<2, 2>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);
+    else hipLaunchKernelGGL((k_ln_bwd<4, 1>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);
+    int rc = ap_check_launch();
+    if (rc != AP_OK) return rc;
+    hipLaunchKernelGGL(k_ln_bwd_reduce, dim3((2 * C + 31) / 32), dim3(1024), 0, s, partial, (int)grid, 2 * C, dgamma, dbeta, C);
     return ap_check_launch();
 }
 

@@ -19,7 +19,10 @@
 #define OPP 81
 
 // stage pixel rows [y0, y0+rows) x cols [-1, pw-1) of one head (32 channels) into LDS, zero outside the image
-__device__ __forceinline__ void stage_patch(bf16_t* patch, const bf16_t* src, int H, int W, int C, int y0, int rows, int pw, int nthreads) {
+// LDS layout is CHUNK-major: 16-B chunk c (8 channels) of pixel pix lives at (c*npix + pix)*16 B, so lanes
+// that own neighbouring quads/windows (pixel stride 2) read 32 B apart (2-way bank conflict) instead of
+// 128 B apart (8-way with a pixel-major [pix][32] image).
+__device__ __forceinline__ void stage_patch(bf16_t* patch, const bf16_t* src, int H, int W, int C, int y0, int rows, int pw, int npix, int nthreads) {
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const int total = rows * pw * 4;
     for (int idx = threadIdx.x; idx < total; idx += nthreads) {
@@ -28,7 +31,7 @@ __device__ __forceinline__ void stage_patch(bf16_t* patch, const bf16_t* src, in
         const int y = y0 + pr, x = pc - 1;
         const bool in = (y >= 0) & (y < H) & (x >= 0) & (x < W);
         const u32x4 v = in ? ld16(src + ((int64_t)y * W + x) * C + c * 8) : zero4;
-        st16(patch + pix * OHD + c * 8, v);
+        st16(patch + (c * npix + pix) * 8, v);
     }
 }
 
@@ -69,7 +72,8 @@ k_outlook_gather(const bf16_t* __restrict__ in, const bf16_t* __restrict__ logit
     const int nwr = min(nq + 1, h - I0);
     bf16_t* patch = reinterpret_cast<bf16_t*>(smem_raw);
     float* P = reinterpret_cast<float*>(smem_raw + (((size_t)(2 * SR + 3) * pw * OHD * 2 + 15) & ~(size_t)15));
-    stage_patch(patch, in + (int64_t)b * H * W * C + head * OHD, H, W, C, y0, ph, pw, 128);
+    const int npix = (2 * SR + 3) * pw;
+    stage_patch(patch, in + (int64_t)b * H * W * C + head * OHD, H, W, C, y0, ph, pw, npix, 128);
     stage_probs(P, logits, ldl, ((int64_t)b * h + I0) * w, w, nwr * w, head, scale, 128);
     __syncthreads();
     const int ql = threadIdx.x;
@@ -105,11 +109,11 @@ k_outlook_gather(const bf16_t* __restrict__ in, const bf16_t* __restrict__ logit
                     for (int bc = 0; bc < 3; ++bc) {
                         const int bs = br * 3 + bc;
                         const float wgt = TP ? Pw[bs * OKK + a] : Pw[a * OKK + bs];
-                        const bf16_t* px = patch + ((pr0 + br) * pw + pc0 + bc) * OHD;
+                        const bf16_t* px = patch + ((pr0 + br) * pw + pc0 + bc) * 8;
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             float f[8];
-                            unpack8(ld16(px + c * 8), f);
+                            unpack8(ld16(px + c * npix * 8), f);
 #pragma unroll
                             for (int k = 0; k < 8; ++k) acc[c * 8 + k] += wgt * f[k];
                         }
@@ -142,8 +146,9 @@ k_outlook_dlogits(const bf16_t* __restrict__ v, const bf16_t* __restrict__ dy, c
     bf16_t* pg = reinterpret_cast<bf16_t*>(smem_raw + patch_bytes);
     float* P = reinterpret_cast<float*>(smem_raw + 2 * patch_bytes);
     const int64_t img = (int64_t)b * H * W * C + head * OHD;
-    stage_patch(pv, v + img, H, W, C, y0, ph, pw, 64);
-    stage_patch(pg, dy + img, H, W, C, y0, ph, pw, 64);
+    const int npix = (2 * SRW + 1) * pw;
+    stage_patch(pv, v + img, H, W, C, y0, ph, pw, npix, 64);
+    stage_patch(pg, dy + img, H, W, C, y0, ph, pw, npix, 64);
     const int nwin = nwr * w;
     const int64_t win_base = ((int64_t)b * h + I0) * w;
     stage_probs(P, logits, ldl, win_base, w, nwin, head, scale, 64);
@@ -156,19 +161,19 @@ k_outlook_dlogits(const bf16_t* __restrict__ v, const bf16_t* __restrict__ dy, c
 #pragma unroll 1
         for (int p = 0; p < OKK; ++p) {
             float g[OHD];
-            const bf16_t* gp = pg + ((pr0 + p / 3) * pw + pc0 + p % 3) * OHD;
+            const bf16_t* gp = pg + ((pr0 + p / 3) * pw + pc0 + p % 3) * 8;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) unpack8(ld16(gp + c * 8), g + c * 8);
+            for (int c = 0; c < 4; ++c) unpack8(ld16(gp + c * npix * 8), g + c * 8);
             float dP[OKK];
             float dot = 0.f;
 #pragma unroll
             for (int q = 0; q < OKK; ++q) {
-                const bf16_t* vp = pv + ((pr0 + q / 3) * pw + pc0 + q % 3) * OHD;
+                const bf16_t* vp = pv + ((pr0 + q / 3) * pw + pc0 + q % 3) * 8;
                 float s = 0.f;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float f[8];
-                    unpack8(ld16(vp + c * 8), f);
+                    unpack8(ld16(vp + c * npix * 8), f);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) s += g[c * 8 + k] * f[k];
                 }

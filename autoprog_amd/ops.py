@@ -76,9 +76,11 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta):
     C = x.shape[-1]
     rows = x.numel() // C
     dx = torch.empty_like(x)
+    ws_bytes = lib.ap_layernorm_bwd_workspace(rows, C)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     check(lib.ap_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                dres.data_ptr() if dres is not None else None, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                               rows, C, _stream()), "ap_layernorm_bwd")
+                               rows, C, ws.data_ptr(), ws_bytes, _stream()), "ap_layernorm_bwd")
     return dx
 
 

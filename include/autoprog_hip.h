@@ -48,10 +48,14 @@ int ap_cast_transpose_f32_bf16(const float* src, ap_bf16* dst, int rows, int col
 /* ---- LayerNorm (nn.LayerNorm: models/volo.py:122,131,213,221,290,297,550) ------------- */
 int ap_layernorm_fwd(const ap_bf16* x, const float* gamma, const float* beta, ap_bf16* y,
                      float* mean, float* rstd, int64_t rows, int C, float eps, ap_stream_t stream);
-/* dx = dres + d(LN)/dx ; dgamma/dbeta are ACCUMULATED (+=) with fp32 atomics */
+/* dx = dres + d(LN)/dx ; dgamma/dbeta are ACCUMULATED (+=).  `workspace` (device, caller-owned,
+ * >= ap_layernorm_bwd_workspace() bytes) holds per-workgroup partial sums for the deterministic
+ * two-pass column reduction. */
+size_t ap_layernorm_bwd_workspace(int64_t rows, int C);
 int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* mean,
                      const float* rstd, const ap_bf16* dres /*nullable*/, ap_bf16* dx,
-                     float* dgamma, float* dbeta, int64_t rows, int C, ap_stream_t stream);
+                     float* dgamma, float* dbeta, int64_t rows, int C,
+                     void* workspace, size_t ws_bytes, ap_stream_t stream);
 
 /* ---- Linear layers (nn.Linear: models/volo.py:67,68,71,156,158,180,182,253,256,258,547,553)
  * C[M,N] = epilogue( A[M,K] . B[N,K]^T )   bf16 in, fp32 MFMA accumulate, bf16 out
