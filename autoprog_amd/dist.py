@@ -52,6 +52,10 @@ class GradientBucketReducer:
     def owns(self, p):
         return id(p) in self._owned and p.grad is not None
 
+    def needs_stream_join(self):
+        """with more than one rank a ready parameter may trigger a bucket all-reduce right away"""
+        return self.world > 1
+
     def param_ready(self, p):
         if self.world > 1:
             self._on_grad(p)
@@ -89,6 +93,8 @@ class GradientBucketReducer:
     def finish(self):
         """call after backward(): reduce buckets whose hooks did not all fire (skipped layers), wait
         for every collective and turn sums into means."""
+        from . import functional
+        functional.join_wgrad_stream()          # side-stream weight gradients land before anyone reads the slab
         if self.world <= 1:
             return
         for b in range(len(self.buckets)):

@@ -97,7 +97,10 @@ def _param_grad_buffers(params):
 
 def _finish_param_grads(params, bufs, sink_used):
     if not sink_used:
+        join_wgrad_stream()              # autograd consumes these buffers on the current stream
         return bufs
+    if _grad_sink.needs_stream_join():
+        join_wgrad_stream()              # a bucket all-reduce may be launched from param_ready
     for p in params:
         if p is not None:
             _grad_sink.param_ready(p)
@@ -109,10 +112,42 @@ def _g2(w):
     return w.view(w.shape[0], -1)
 
 
+# Weight gradients do not feed the backward chain, so they are issued on a side stream and overlap the
+# input-gradient GEMMs / LayerNorm / attention kernels of the main stream (every one of these kernels is
+# latency- rather than throughput-bound, so co-scheduling two of them fills idle CUs).
+async_wgrad = True
+_side_streams = {}
+
+
+def wgrad_stream(device=None):
+    dev = torch.cuda.current_device() if device is None else device
+    st = _side_streams.get(dev)
+    if st is None:
+        st = torch.cuda.Stream(device=dev)
+        _side_streams[dev] = st
+    return st
+
+
+def join_wgrad_stream():
+    """make the current stream wait for every weight-gradient kernel issued so far"""
+    if _side_streams:
+        st = _side_streams.get(torch.cuda.current_device())
+        if st is not None:
+            torch.cuda.current_stream().wait_stream(st)
+
+
 def _linear_bwd(g, x_in, w, dw, db, n=None, dgelu_of=None, need_dx=True):
     """shared backward of y = x W^T + b given g = dL/dy (bf16 [M, ld]); accumulates dw/db."""
     n = w.shape[0] if n is None else n
-    ops.gemm_tn_acc(g, x_in, _g2(dw), n1=n, n2=_g2(dw).shape[1], colsum=db)
+    if async_wgrad:
+        side = wgrad_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.gemm_tn_acc(g, x_in, _g2(dw), n1=n, n2=_g2(dw).shape[1], colsum=db)
+        g.record_stream(side)
+        x_in.record_stream(side)
+    else:
+        ops.gemm_tn_acc(g, x_in, _g2(dw), n1=n, n2=_g2(dw).shape[1], colsum=db)
     if not need_dx:
         return None
     wt = bank.get_t(w)                       # [K, ld(N)]
@@ -270,6 +305,7 @@ class LinearFn(torch.autograd.Function):
         dw = torch.zeros_like(w)
         db = torch.zeros_like(b) if b is not None else None
         dx = _linear_bwd(g, x2, w, dw, db, n=N, need_dx=ctx.needs_input_grad[0])
+        join_wgrad_stream()
         if dx is not None:
             dx = dx[:, :x2.shape[1]] if dx.shape[1] != x2.shape[1] else dx
             dx = dx.reshape(*ctx.lead, x2.shape[1])

@@ -65,6 +65,7 @@ def test_volo_train_eval_vs_reference_golden(tag, variant, classes):
     assert (num / den) ** 0.5 < 0.12, (num / den) ** 0.5
     bad = {k: v for k, v in worst.items() if v > 0.4}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+    load_sd(model, d, tag)                  # the train forward above updated the BN running stats once more
     model.eval()
     with torch.no_grad():
         y = model(x)
