@@ -17,24 +17,33 @@
 // transposed reads.
 #include "common.h"
 
-#define AHD 32
+#define AHD 32          // head dim of the class-attention kernels below
 
-__device__ __forceinline__ int att_off(int row, int chunk) {       // element offset of a 16-B chunk
-    const int f = (0x78 >> (((row >> 2) & 3) << 1)) & 3;
-    return row * AHD + ((chunk ^ f) << 3);
+// element offset of 16-B chunk `chunk` of row `row` in a [tokens][HD] LDS tile.
+// HD=32 (64-B rows): chunk ^= f((row>>2)&3), f={0,2,3,1}; HD=64 (128-B rows): chunk ^= row&7.
+// Both are conflict-free for the ds_read_b128 row reads and for the transposed reads used here.
+template <int HD>
+__device__ __forceinline__ int att_off(int row, int chunk) {
+    if (HD == 32) {
+        const int f = (0x78 >> (((row >> 2) & 3) << 1)) & 3;
+        return row * 32 + ((chunk ^ f) << 3);
+    }
+    return row * 64 + ((chunk ^ (row & 7)) << 3);
 }
-__device__ __forceinline__ bf16x8 att_row_frag(const bf16_t* tile, int row0, int lane) {
-    // operand whose k axis is the head dim: tile row row0+(lane&15), chunk lane>>4
-    return __builtin_bit_cast(bf16x8, ld16(tile + att_off(row0 + (lane & 15), lane >> 4)));
+template <int HD>
+__device__ __forceinline__ bf16x8 att_row_frag(const bf16_t* tile, int row0, int lane, int kc = 0) {
+    // operand whose k axis is the head dim: tile row row0+(lane&15), k chunk kc*4 + lane>>4
+    return __builtin_bit_cast(bf16x8, ld16(tile + att_off<HD>(row0 + (lane & 15), kc * 4 + (lane >> 4))));
 }
+template <int HD>
 __device__ __forceinline__ bf16x8 att_tr_frag(const bf16_t* tile, int row0, int dt, int lane) {
     // operand whose k axis is the TOKEN axis in the accumulator-permuted order:
     // k = 8g+j  <->  token row0 + 16*(j>>2) + 4g + (j&3); column = dt*16 + (lane&15)
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     const int r1 = row0 + 4 * g + q, r2 = r1 + 16;
     const int ch = 2 * dt + (p >> 1), e = (p & 1) * 4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + att_off(r1, ch) + e));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + att_off(r2, ch) + e));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + att_off<HD>(r1, ch) + e));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + att_off<HD>(r2, ch) + e));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
@@ -45,42 +54,49 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// stage rows [0,Npad) of one [N, ld] strided matrix slice (32 columns) into a swizzled LDS tile
+// stage rows [0,Npad) of one [N, ld] strided matrix slice (HD columns) into a swizzled LDS tile
+template <int HD>
 __device__ __forceinline__ void att_stage(bf16_t* tile, const bf16_t* src, int64_t ld, int N, int Npad) {
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    for (int idx = threadIdx.x; idx < Npad * 4; idx += blockDim.x) {
-        const int row = idx >> 2, c = idx & 3;
+    constexpr int CH = HD / 8;
+    for (int idx = threadIdx.x; idx < Npad * CH; idx += blockDim.x) {
+        const int row = idx / CH, c = idx % CH;
         const u32x4 v = (row < N) ? ld16(src + (int64_t)row * ld + c * 8) : zero4;
-        st16(tile + att_off(row, c), v);
+        st16(tile + att_off<HD>(row, c), v);
     }
 }
 
-template <int NT>
+template <int NT, int HD>
 __global__ void __launch_bounds__(256)
 k_mhsa_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int heads, float scale) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     constexpr int Npad = NT * 16;
+    constexpr int KC = HD / 32, DT = HD / 16;
     bf16_t* Ks = smem;
-    bf16_t* Vs = smem + Npad * AHD;
+    bf16_t* Vs = smem + Npad * HD;
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int C = heads * AHD;
+    const int C = heads * HD;
     const int64_t ld = 3 * C;
-    const bf16_t* base = qkv + (int64_t)b * N * ld + h * AHD;
-    att_stage(Ks, base + C, ld, N, Npad);
-    att_stage(Vs, base + 2 * C, ld, N, Npad);
+    const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
+    att_stage<HD>(Ks, base + C, ld, N, Npad);
+    att_stage<HD>(Vs, base + 2 * C, ld, N, Npad);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
     const float c2 = scale * 1.4426950408889634f;
     const int nq = (N + 15) >> 4;
     for (int qt = wave; qt < nq; qt += 4) {
         const int qrow = min(qt * 16 + fr, N - 1);
-        const bf16x8 qf = __builtin_bit_cast(bf16x8, ld16(base + (int64_t)qrow * ld + g * 8));
+        bf16x8 qf[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) qf[kc] = __builtin_bit_cast(bf16x8, ld16(base + (int64_t)qrow * ld + kc * 32 + g * 8));
         f32x4 s[NT];
         float mx = -1.0e30f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, t * 16, lane), qf, z, 0, 0, 0);
+            s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag<HD>(Ks, t * 16, lane, kc), qf[kc], s[t], 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = t * 16 + 4 * g + r;
@@ -97,13 +113,15 @@ k_mhsa_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __re
             for (int r = 0; r < 4; ++r) { s[t][r] = exp2f(s[t][r] - mx); sum += s[t][r]; }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s2 = 0; s2 < NT / 2; ++s2) {
             const bf16x8 pf = pack_frag(s[2 * s2], s[2 * s2 + 1]);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, att_tr_frag(Vs, 32 * s2, dt, lane), o[dt], 0, 0, 0);
+            for (int dt = 0; dt < DT; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, att_tr_frag<HD>(Vs, 32 * s2, dt, lane), o[dt], 0, 0, 0);
         }
         const float inv = 1.0f / sum;
         if (g == 0 && qt * 16 + fr < N) lse[((int64_t)b * heads + h) * N + qt * 16 + fr] = (mx + log2f(sum)) * 0.6931471805599453f;
@@ -112,37 +130,39 @@ k_mhsa_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __re
             const float ir = __shfl(inv, 4 * g + r, 64);
             const int q = qt * 16 + 4 * g + r;
             if (q < N) {
-                bf16_t* op = out + ((int64_t)b * N + q) * C + h * AHD + fr;
-                op[0] = f2bf(o[0][r] * ir);
-                op[16] = f2bf(o[1][r] * ir);
+                bf16_t* op = out + ((int64_t)b * N + q) * C + h * HD + fr;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) op[dt * 16] = f2bf(o[dt][r] * ir);
             }
         }
     }
 }
 
+template <int HD>
 __global__ void __launch_bounds__(512)
 k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
            const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int heads, float scale, int NT) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    constexpr int KC = HD / 32, DT = HD / 16, CH = HD / 8;
     const int Npad = NT * 16;
     bf16_t* Qs = smem;
-    bf16_t* Ks = Qs + Npad * AHD;
-    bf16_t* Vs = Ks + Npad * AHD;
-    bf16_t* Gs = Vs + Npad * AHD;                                  // dO
-    float* fl = reinterpret_cast<float*>(Gs + Npad * AHD);         // lse * log2(e)   (+huge for padded rows)
+    bf16_t* Ks = Qs + Npad * HD;
+    bf16_t* Vs = Ks + Npad * HD;
+    bf16_t* Gs = Vs + Npad * HD;                                   // dO
+    float* fl = reinterpret_cast<float*>(Gs + Npad * HD);          // lse * log2(e)   (+huge for padded rows)
     float* fd = fl + Npad;                                         // delta = rowsum(dO * O)
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int C = heads * AHD;
+    const int C = heads * HD;
     const int64_t ld = 3 * C;
-    const bf16_t* base = qkv + (int64_t)b * N * ld + h * AHD;
-    const bf16_t* obase = out + (int64_t)b * N * C + h * AHD;
-    const bf16_t* gbase = dout + (int64_t)b * N * C + h * AHD;
-    att_stage(Qs, base, ld, N, Npad);
-    att_stage(Ks, base + C, ld, N, Npad);
-    att_stage(Vs, base + 2 * C, ld, N, Npad);
-    att_stage(Gs, gbase, C, N, Npad);
-    for (int idx = threadIdx.x; idx < Npad * 4; idx += 512) {      // Npad*4 is a multiple of 128: whole waves
-        const int row = idx >> 2, c = idx & 3;
+    const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
+    const bf16_t* obase = out + (int64_t)b * N * C + h * HD;
+    const bf16_t* gbase = dout + (int64_t)b * N * C + h * HD;
+    att_stage<HD>(Qs, base, ld, N, Npad);
+    att_stage<HD>(Ks, base + C, ld, N, Npad);
+    att_stage<HD>(Vs, base + 2 * C, ld, N, Npad);
+    att_stage<HD>(Gs, gbase, C, N, Npad);
+    for (int idx = threadIdx.x; idx < Npad * CH; idx += 512) {     // Npad*CH is a multiple of 128: whole waves
+        const int row = idx / CH, c = idx % CH;
         float part = 0.f;
         if (row < N) {
             float a[8], d[8];
@@ -151,8 +171,8 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
 #pragma unroll
             for (int k = 0; k < 8; ++k) part += a[k] * d[k];
         }
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
+#pragma unroll
+        for (int o = 1; o < CH; o <<= 1) part += __shfl_xor(part, o, 64);
         if (c == 0) {
             fd[row] = part;
             fl[row] = (row < N) ? lse[((int64_t)b * heads + h) * N + row] * 1.4426950408889634f : 1.0e30f;
@@ -163,21 +183,28 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
     const float c2 = scale * 1.4426950408889634f;
     const int ntile = (N + 15) >> 4;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    bf16_t* dbase = dqkv + (int64_t)b * N * ld + h * AHD;
+    bf16_t* dbase = dqkv + (int64_t)b * N * ld + h * HD;
 
     // ---- pass A: this wave owns key tile jt -> dK, dV
     for (int jt = wave; jt < ntile; jt += 8) {
-        const bf16x8 kf = att_row_frag(Ks, jt * 16, lane);
-        const bf16x8 vf = att_row_frag(Vs, jt * 16, lane);
-        f32x4 dk[2] = {z, z}, dv[2] = {z, z};
+        bf16x8 kf[KC], vf[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) { kf[kc] = att_row_frag<HD>(Ks, jt * 16, lane, kc); vf[kc] = att_row_frag<HD>(Vs, jt * 16, lane, kc); }
+        f32x4 dk[DT], dv[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { dk[dt] = z; dv[dt] = z; }
 #pragma unroll 1
         for (int qs = 0; qs < NT / 2; ++qs) {
             f32x4 p[2], ds[2];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int q0 = (2 * qs + hf) * 16;
-                const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Qs, q0, lane), kf, z, 0, 0, 0);
-                const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Gs, q0, lane), vf, z, 0, 0, 0);
+                f32x4 sc = z, dp = z;
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag<HD>(Qs, q0, lane, kc), kf[kc], sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag<HD>(Gs, q0, lane, kc), vf[kc], dp, 0, 0, 0);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = q0 + 4 * g + r;
@@ -189,9 +216,9 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
             const bf16x8 pf = pack_frag(p[0], p[1]);
             const bf16x8 dsf = pack_frag(ds[0], ds[1]);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, att_tr_frag(Gs, 32 * qs, dt, lane), dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, att_tr_frag(Qs, 32 * qs, dt, lane), dk[dt], 0, 0, 0);
+            for (int dt = 0; dt < DT; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, att_tr_frag<HD>(Gs, 32 * qs, dt, lane), dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, att_tr_frag<HD>(Qs, 32 * qs, dt, lane), dk[dt], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -199,25 +226,32 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
             const int key = jt * 16 + 4 * g + r;
             if (key < N) {
                 bf16_t* kp = dbase + (int64_t)key * ld + C + fr;
-                kp[0] = f2bf(dk[0][r]); kp[16] = f2bf(dk[1][r]);
-                kp[C] = f2bf(dv[0][r]); kp[C + 16] = f2bf(dv[1][r]);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) { kp[dt * 16] = f2bf(dk[dt][r]); kp[C + dt * 16] = f2bf(dv[dt][r]); }
             }
         }
     }
     // ---- pass B: this wave owns query tile qt -> dQ
     for (int qt = wave; qt < ntile; qt += 8) {
-        const bf16x8 qf = att_row_frag(Qs, qt * 16, lane);
-        const bf16x8 gf = att_row_frag(Gs, qt * 16, lane);
+        bf16x8 qf[KC], gf[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) { qf[kc] = att_row_frag<HD>(Qs, qt * 16, lane, kc); gf[kc] = att_row_frag<HD>(Gs, qt * 16, lane, kc); }
         const float flq = fl[qt * 16 + fr], fdq = fd[qt * 16 + fr];
-        f32x4 dq[2] = {z, z};
+        f32x4 dq[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dq[dt] = z;
 #pragma unroll 1
         for (int ks = 0; ks < NT / 2; ++ks) {
             f32x4 ds[2];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int k0 = (2 * ks + hf) * 16;
-                const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Ks, k0, lane), qf, z, 0, 0, 0);
-                const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag(Vs, k0, lane), gf, z, 0, 0, 0);
+                f32x4 sc = z, dp = z;
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag<HD>(Ks, k0, lane, kc), qf[kc], sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag<HD>(Vs, k0, lane, kc), gf[kc], dp, 0, 0, 0);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = k0 + 4 * g + r;
@@ -227,15 +261,16 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
             }
             const bf16x8 dsf = pack_frag(ds[0], ds[1]);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, att_tr_frag(Ks, 32 * ks, dt, lane), dq[dt], 0, 0, 0);
+            for (int dt = 0; dt < DT; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, att_tr_frag<HD>(Ks, 32 * ks, dt, lane), dq[dt], 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = qt * 16 + 4 * g + r;
             if (q < N) {
                 bf16_t* qp = dbase + (int64_t)q * ld + fr;
-                qp[0] = f2bf(dq[0][r]); qp[16] = f2bf(dq[1][r]);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) qp[dt * 16] = f2bf(dq[dt][r]);
             }
         }
     }
@@ -363,30 +398,30 @@ k_class_attn_bwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, co
     }
 }
 
-#define MHSA_DISPATCH(KERNEL, NTV, ...)                                                          \
-    (void)hipGetLastError();                                                                     \
-    switch (NTV) {                                                                               \
-        case 2: hipLaunchKernelGGL(KERNEL<2>, grid, dim3(256), lds, s, __VA_ARGS__); break;      \
-        case 4: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), lds, s, __VA_ARGS__); break;      \
-        case 6: hipLaunchKernelGGL(KERNEL<6>, grid, dim3(256), lds, s, __VA_ARGS__); break;      \
-        case 8: hipLaunchKernelGGL(KERNEL<8>, grid, dim3(256), lds, s, __VA_ARGS__); break;      \
-        case 10: hipLaunchKernelGGL(KERNEL<10>, grid, dim3(256), lds, s, __VA_ARGS__); break;    \
-        case 12: hipLaunchKernelGGL(KERNEL<12>, grid, dim3(256), lds, s, __VA_ARGS__); break;    \
-        case 14: hipLaunchKernelGGL(KERNEL<14>, grid, dim3(256), lds, s, __VA_ARGS__); break;    \
-        default: hipLaunchKernelGGL(KERNEL<16>, grid, dim3(256), lds, s, __VA_ARGS__); break;    \
-    }
+#define MHSA_FWD_CASE(NTV, HDV) case NTV: hipLaunchKernelGGL((k_mhsa_fwd<NTV, HDV>), grid, dim3(256), lds, s, qkv, out, lse, N, heads, scale); break;
+#define MHSA_FWD_SWITCH(HDV)                                                                     \
+    switch (nt) { MHSA_FWD_CASE(2, HDV) MHSA_FWD_CASE(4, HDV) MHSA_FWD_CASE(6, HDV) MHSA_FWD_CASE(8, HDV)  \
+                  MHSA_FWD_CASE(10, HDV) MHSA_FWD_CASE(12, HDV) MHSA_FWD_CASE(14, HDV)             \
+                  default: hipLaunchKernelGGL((k_mhsa_fwd<16, HDV>), grid, dim3(256), lds, s, qkv, out, lse, N, heads, scale); break; }
 
 extern "C" {
 
 int ap_mhsa_fwd(const ap_bf16* qkv, ap_bf16* out, float* lse, int B, int N, int heads, int hd, float scale, ap_stream_t stream) {
     if (!qkv || !out || !lse) return AP_ERR_NULL;
     if (B <= 0 || N <= 0 || heads <= 0) return AP_ERR_SHAPE;
-    if (hd != AHD || N > 256) return AP_ERR_UNSUPPORTED;
+    if ((hd != 32 && hd != 64) || N > 256) return AP_ERR_UNSUPPORTED;
     const int nt = 2 * ((N + 31) / 32);
     const dim3 grid(B * heads);
-    const size_t lds = (size_t)2 * nt * 16 * AHD * sizeof(bf16_t);
+    const size_t lds = (size_t)2 * nt * 16 * hd * sizeof(bf16_t);
     hipStream_t s = (hipStream_t)stream;
-    MHSA_DISPATCH(k_mhsa_fwd, nt, qkv, out, lse, N, heads, scale)
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_mhsa_fwd<14, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_mhsa_fwd<16, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_done = true;
+    }
+    (void)hipGetLastError();
+    if (hd == 32) { MHSA_FWD_SWITCH(32) } else { MHSA_FWD_SWITCH(64) }
     return ap_check_launch();
 }
 
@@ -394,13 +429,20 @@ int ap_mhsa_bwd(const ap_bf16* qkv, const ap_bf16* out, const ap_bf16* dout, con
                 int B, int N, int heads, int hd, float scale, ap_stream_t stream) {
     if (!qkv || !out || !dout || !lse || !dqkv) return AP_ERR_NULL;
     if (B <= 0 || N <= 0 || heads <= 0) return AP_ERR_SHAPE;
-    if (hd != AHD || N > 256) return AP_ERR_UNSUPPORTED;
+    if ((hd != 32 && hd != 64) || N > 256) return AP_ERR_UNSUPPORTED;
     const int nt = 2 * ((N + 31) / 32);
     const dim3 grid(B * heads);
-    const size_t lds = (size_t)4 * nt * 16 * AHD * sizeof(bf16_t) + (size_t)2 * nt * 16 * sizeof(float);
+    const size_t lds = (size_t)4 * nt * 16 * hd * sizeof(bf16_t) + (size_t)2 * nt * 16 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_mhsa_bwd<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_mhsa_bwd<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_mhsa_bwd, grid, dim3(512), lds, s, qkv, out, dout, lse, dqkv, N, heads, scale, nt);
+    if (hd == 32) hipLaunchKernelGGL(k_mhsa_bwd<32>, grid, dim3(512), lds, s, qkv, out, dout, lse, dqkv, N, heads, scale, nt);
+    else hipLaunchKernelGGL(k_mhsa_bwd<64>, grid, dim3(512), lds, s, qkv, out, dout, lse, dqkv, N, heads, scale, nt);
     return ap_check_launch();
 }
 

@@ -182,18 +182,19 @@ def test_avgpool(ops, B, H, W, C):
     assert rel(dx, base.double() + xr.grad) < TOL_BF16
 
 
-@pytest.mark.parametrize("B,N,heads", [(2, 196, 12), (3, 64, 2), (2, 100, 4), (1, 144, 12), (2, 197, 3), (2, 25, 2), (1, 256, 2), (5, 36, 1)])
-def test_mhsa(ops, B, N, heads):
-    C = heads * 32
+@pytest.mark.parametrize("B,N,heads,hd", [(2, 196, 12, 32), (3, 64, 2, 32), (2, 100, 4, 32), (1, 144, 12, 32), (2, 197, 3, 32), (2, 25, 2, 32),
+                                          (1, 256, 2, 32), (5, 36, 1, 32), (2, 197, 3, 64), (2, 64, 2, 64), (1, 256, 1, 64), (3, 50, 6, 64)])
+def test_mhsa(ops, B, N, heads, hd):
+    C = heads * hd
     qkv = rnd(B * N, 3 * C, seed=1)
     do = rnd(B * N, C, seed=2)
-    scale = 32 ** -0.5
+    scale = hd ** -0.5
     qr = qkv.double().reshape(B, N, 3 * C).requires_grad_(True)
     orf = R.mhsa_core(qr, heads)
     orf.backward(do.double().reshape(B, N, C))
     o, lse = ops.mhsa_fwd(dev(qkv), B, N, heads, scale)
     assert rel(o, orf.reshape(B * N, C)) < TOL_BF16
-    q, k, _ = qkv.double().reshape(B, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+    q, k, _ = qkv.double().reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
     lse_ref = torch.logsumexp(q @ k.transpose(-1, -2) * scale, dim=-1)
     assert float((lse.cpu().double() - lse_ref).abs().max()) < 2e-3
     dqkv = ops.mhsa_bwd(dev(qkv), o, dev(do), lse, B, N, heads, scale)

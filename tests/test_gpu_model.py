@@ -194,3 +194,34 @@ def test_gradient_sink_matches_autograd_accumulation():
         grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters()})
     for n in grads[0]:
         assert rel(grads[1][n], grads[0][n]) < 1e-3, n
+
+
+def test_deit_tiny_depth4_vs_oracle():
+    """BASELINE.json configs[0] shape (DeiT-Tiny 224, depth-4 sub-net, soft-target CE) at batch 4:
+    HIP path vs the oracle's timm-VisionTransformer restatement (head_dim 64 attention kernels)."""
+    from autoprog_amd.models import create_model
+    from autoprog_amd.loss import SoftTargetCrossEntropy
+    torch.manual_seed(0)
+    model = create_model("model_variant", variant="deit_h3_l4").cuda().train()
+    B = 4
+    x = torch.randn(B, 3, 224, 224, device="cuda")
+    target = torch.softmax(torch.randn(B, 1000, device="cuda") * 3, dim=-1)
+    y = model(x)
+    loss = SoftTargetCrossEntropy()(y, target)
+    loss.backward()
+    p = {k: v.detach().double().cpu().requires_grad_(True) for k, v in model.state_dict().items()}
+    yr = R.vit_forward(p, x.double().cpu(), depth=4, heads=3)
+    lr = R.soft_target_ce(yr, target.double().cpu())
+    lr.backward()
+    assert rel(y, yr) < 2e-2, rel(y, yr)
+    assert abs(float(loss.detach()) - float(lr.detach())) < 2e-3 * float(lr.detach())
+    errs = {n: rel(q.grad, p[n].grad) for n, q in model.named_parameters() if float(p[n].grad.norm()) > 1e-9}
+    bad = {k: v for k, v in errs.items() if v > 6e-2}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    # elastic depth: skipping block 1 == the oracle with that block removed
+    model.eval()
+    skip = model.set_sample_config(dict(layer_num=3, min_layer_num=2, max_layer_num=4))
+    with torch.no_grad():
+        ys = model(x)
+    yrs = R.vit_forward({k: v.detach() for k, v in p.items()}, x.double().cpu(), depth=4, heads=3, train=False, skip=skip)
+    assert rel(ys, yrs) < 2e-2
