@@ -137,6 +137,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # reference main_prog.py:65 sets cudnn.benchmark = True: let MIOpen MEASURE its conv solvers for the stem
+    # (its immediate-mode heuristics can pick solvers that are 100x slower on a fresh machine)
+    torch.backends.cudnn.benchmark = True
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
