@@ -225,3 +225,33 @@ def test_deit_tiny_depth4_vs_oracle():
         ys = model(x)
     yrs = R.vit_forward({k: v.detach() for k, v in p.items()}, x.double().cpu(), depth=4, heads=3, train=False, skip=skip)
     assert rel(ys, yrs) < 2e-2
+
+
+@pytest.mark.parametrize("l,r", [(9, 128), (12, 160), (15, 192)])
+def test_autoprog_stage_shapes_elastic_supernet(l, r):
+    """BASELINE.json configs[2]: the reference schedule's stage shapes (l, r) run on ONE volo_h12_l18
+    supernet through set_sample_config (elastic depth as a launch-time mask) and a resized input
+    (elastic token count + bicubic pos-embed interpolation), against the oracle with the same skip table."""
+    from autoprog_amd.models import create_model
+    torch.manual_seed(1)
+    model = create_model("model_variant", variant="volo_h12_l18", num_classes=1000, img_size=224).cuda().train()
+    mask = model.set_sample_config(dict(layer_num=l, min_layer_num=9, max_layer_num=18))
+    B = 2
+    x = torch.randn(B, 3, r, r, device="cuda")
+    np.random.seed(l)
+    x_cls, x_aux, bb = model(x)
+    assert x_aux.shape == (B, (r // 16) ** 2, 1000)
+    p = {k: v.detach().double().cpu() for k, v in model.state_dict().items()}
+    rng = np.random.RandomState(l)
+    lam, box = R.draw_mix_box((B, r // 8, r // 8, 192), 2, 1.0, rng)
+    assert tuple(bb) == tuple(box)
+    skip = R.skip_layer_table(l, 9, 18)
+    assert [sorted(s) for s in mask.skip] == [sorted(s) for s in skip]
+    arch = R.variant_arch("volo_h12_l18")
+    ref_cls, ref_aux, _ = R.volo_forward(p, x.double().cpu(), train=True, mix=(lam, box), skip=skip, **arch)
+    assert rel(x_cls, ref_cls) < 3e-2 and rel(x_aux, ref_aux) < 3e-2
+    (x_cls.float().sum() + x_aux.float().mean()).backward()
+    active = model.network[2][0].attn.qkv.weight.grad
+    skipped = model.network[2][sorted(skip[1])[0]].attn.qkv.weight.grad if skip[1] else None
+    assert active is not None and float(active.abs().sum()) > 0
+    assert skipped is None or float(skipped.abs().sum()) == 0.0          # identity layers receive no gradient
