@@ -70,6 +70,15 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
+// XCD-aware bijective remap of a linear workgroup id (MI355X deals workgroups round-robin over its 8 XCDs,
+// each with a private L2): ids that share an XCD (id % 8) are mapped to a CONTIGUOUS range of work items, so
+// neighbouring items (same image / same operand panel) hit the same L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + k;
+}
+
 static inline int ap_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? AP_OK : AP_ERR_LAUNCH;

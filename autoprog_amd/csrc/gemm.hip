@@ -29,14 +29,6 @@
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
-// XCD-aware bijective remap of the linear block id: blocks that share an XCD (id % 8) get a
-// contiguous range of tiles, so neighbouring tiles (same A row panel) hit the same L2.
-__device__ __forceinline__ int xcd_remap(int id, int n) {
-    const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
-    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-    return base + k;
-}
-
 struct EpiArgs {
     const float* bias; int gelu; bf16_t* preact; const bf16_t* dgelu_of; const float* row_scale;
     int rows_per_scale; const bf16_t* residual; int ldr; int dbg;

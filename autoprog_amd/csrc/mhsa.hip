@@ -48,6 +48,30 @@ __device__ __forceinline__ bf16x8 att_tr_frag(const bf16_t* tile, int row0, int 
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
+// Lane-constant parts of the two fragment address patterns, computed ONCE per kernel: the swizzle term
+// only depends on lane bits (row offsets used in the loops are multiples of 16 resp. 32 tokens, which do
+// not touch the swizzled row bits), so every read in the loops is base + compile-time/loop-linear offset.
+// (rocprof: ~930 VALU instructions per 16-query tile before hoisting, most of them address arithmetic.)
+template <int HD>
+__device__ __forceinline__ int att_row_base(int lane, int kc) { return att_off<HD>(lane & 15, kc * 4 + (lane >> 4)); }
+template <int HD>
+__device__ __forceinline__ bf16x8 att_row_at(const bf16_t* tile, int base, int row0) {
+    return __builtin_bit_cast(bf16x8, ld16(tile + base + row0 * HD));
+}
+template <int HD>
+__device__ __forceinline__ int att_tr_base(int lane, int dt) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    return att_off<HD>(4 * g + q, 2 * dt + (p >> 1)) + (p & 1) * 4;
+}
+template <int HD>
+__device__ __forceinline__ bf16x8 att_tr_at(const bf16_t* tile, int base, int row0) {
+    const bf16_t* a1 = tile + base + row0 * HD;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1 + 16 * HD));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
 __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
     u32x4 v;
     v[0] = pack_bf2(a[0], a[1]); v[1] = pack_bf2(a[2], a[3]); v[2] = pack_bf2(b[0], b[1]); v[3] = pack_bf2(b[2], b[3]);
@@ -74,7 +98,9 @@ k_mhsa_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __re
     constexpr int KC = HD / 32, DT = HD / 16;
     bf16_t* Ks = smem;
     bf16_t* Vs = smem + Npad * HD;
-    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    // heads of one image share 128-B lines of qkv (64 B per token and head at head_dim 32): keep them on one XCD
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = wg / heads, h = wg % heads;
     const int C = heads * HD;
     const int64_t ld = 3 * C;
     const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
@@ -84,33 +110,49 @@ k_mhsa_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
     const float c2 = scale * 1.4426950408889634f;
     const int nq = (N + 15) >> 4;
+    int kb[KC], vb[DT];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) kb[kc] = att_row_base<HD>(lane, kc);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vb[dt] = att_tr_base<HD>(lane, dt);
+    // the Q fragment of the NEXT query tile is fetched from global memory while the current tile is computed
+    bf16x8 qnext[KC];
+    {
+        const int qrow0 = min(wave * 16 + fr, N - 1);
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) qnext[kc] = __builtin_bit_cast(bf16x8, ld16(base + (int64_t)qrow0 * ld + kc * 32 + g * 8));
+    }
     for (int qt = wave; qt < nq; qt += 4) {
-        const int qrow = min(qt * 16 + fr, N - 1);
         bf16x8 qf[KC];
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) qf[kc] = __builtin_bit_cast(bf16x8, ld16(base + (int64_t)qrow * ld + kc * 32 + g * 8));
+        for (int kc = 0; kc < KC; ++kc) qf[kc] = qnext[kc];
+        {
+            const int qrow = min((qt + 4) * 16 + fr, N - 1);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) qnext[kc] = __builtin_bit_cast(bf16x8, ld16(base + (int64_t)qrow * ld + kc * 32 + g * 8));
+        }
         f32x4 s[NT];
-        float mx = -1.0e30f;
+        float mx = -1.0e30f;                         // max of the RAW scores (scale > 0)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc)
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag<HD>(Ks, t * 16, lane, kc), qf[kc], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_at<HD>(Ks, kb[kc], t * 16), qf[kc], s[t], 0, 0, 0);
+            if (t >= NT - 2) {                       // N > 16*(NT-2): only the last two key tiles can hold padding
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = t * 16 + 4 * g + r;
-                s[t][r] = (key < N) ? s[t][r] * c2 : -1.0e30f;
-                mx = fmaxf(mx, s[t][r]);
+                for (int r = 0; r < 4; ++r) if (t * 16 + 4 * g + r >= N) s[t][r] = -1.0e30f;
             }
+            mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nmx = -mx * c2;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s[t][r] = exp2f(s[t][r] - mx); sum += s[t][r]; }
+            for (int r = 0; r < 4; ++r) { s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, nmx)); sum += s[t][r]; }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         f32x4 o[DT];
@@ -121,10 +163,10 @@ k_mhsa_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __re
             const bf16x8 pf = pack_frag(s[2 * s2], s[2 * s2 + 1]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, att_tr_frag<HD>(Vs, 32 * s2, dt, lane), o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, att_tr_at<HD>(Vs, vb[dt], 32 * s2), o[dt], 0, 0, 0);
         }
         const float inv = 1.0f / sum;
-        if (g == 0 && qt * 16 + fr < N) lse[((int64_t)b * heads + h) * N + qt * 16 + fr] = (mx + log2f(sum)) * 0.6931471805599453f;
+        if (g == 0 && qt * 16 + fr < N) lse[((int64_t)b * heads + h) * N + qt * 16 + fr] = (mx * c2 + log2f(sum)) * 0.6931471805599453f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float ir = __shfl(inv, 4 * g + r, 64);
@@ -151,7 +193,8 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
     bf16_t* Gs = Vs + Npad * HD;                                   // dO
     float* fl = reinterpret_cast<float*>(Gs + Npad * HD);          // lse * log2(e)   (+huge for padded rows)
     float* fd = fl + Npad;                                         // delta = rowsum(dO * O)
-    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = wg / heads, h = wg % heads;
     const int C = heads * HD;
     const int64_t ld = 3 * C;
     const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
@@ -184,12 +227,17 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
     const int ntile = (N + 15) >> 4;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     bf16_t* dbase = dqkv + (int64_t)b * N * ld + h * HD;
+    int rb[KC], tb[DT];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) rb[kc] = att_row_base<HD>(lane, kc);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) tb[dt] = att_tr_base<HD>(lane, dt);
 
     // ---- pass A: this wave owns key tile jt -> dK, dV
     for (int jt = wave; jt < ntile; jt += 8) {
         bf16x8 kf[KC], vf[KC];
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) { kf[kc] = att_row_frag<HD>(Ks, jt * 16, lane, kc); vf[kc] = att_row_frag<HD>(Vs, jt * 16, lane, kc); }
+        for (int kc = 0; kc < KC; ++kc) { kf[kc] = att_row_at<HD>(Ks, rb[kc], jt * 16); vf[kc] = att_row_at<HD>(Vs, rb[kc], jt * 16); }
         f32x4 dk[DT], dv[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { dk[dt] = z; dv[dt] = z; }
@@ -202,23 +250,23 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
                 f32x4 sc = z, dp = z;
 #pragma unroll
                 for (int kc = 0; kc < KC; ++kc) {
-                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag<HD>(Qs, q0, lane, kc), kf[kc], sc, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag<HD>(Gs, q0, lane, kc), vf[kc], dp, 0, 0, 0);
+                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_at<HD>(Qs, rb[kc], q0), kf[kc], sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_at<HD>(Gs, rb[kc], q0), vf[kc], dp, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = q0 + 4 * g + r;
-                    const float pv = exp2f(sc[r] * c2 - fl[q]);
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -fl[q]));
                     p[hf][r] = pv;
-                    ds[hf][r] = pv * (dp[r] - fd[q]) * scale;
+                    ds[hf][r] = pv * (dp[r] - fd[q]);                 // the softmax scale is applied once to dK / dQ
                 }
             }
             const bf16x8 pf = pack_frag(p[0], p[1]);
             const bf16x8 dsf = pack_frag(ds[0], ds[1]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, att_tr_frag<HD>(Gs, 32 * qs, dt, lane), dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, att_tr_frag<HD>(Qs, 32 * qs, dt, lane), dk[dt], 0, 0, 0);
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, att_tr_at<HD>(Gs, tb[dt], 32 * qs), dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, att_tr_at<HD>(Qs, tb[dt], 32 * qs), dk[dt], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -227,7 +275,7 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
             if (key < N) {
                 bf16_t* kp = dbase + (int64_t)key * ld + C + fr;
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) { kp[dt * 16] = f2bf(dk[dt][r]); kp[C + dt * 16] = f2bf(dv[dt][r]); }
+                for (int dt = 0; dt < DT; ++dt) { kp[dt * 16] = f2bf(dk[dt][r] * scale); kp[C + dt * 16] = f2bf(dv[dt][r]); }
             }
         }
     }
@@ -235,7 +283,7 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
     for (int qt = wave; qt < ntile; qt += 8) {
         bf16x8 qf[KC], gf[KC];
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) { qf[kc] = att_row_frag<HD>(Qs, qt * 16, lane, kc); gf[kc] = att_row_frag<HD>(Gs, qt * 16, lane, kc); }
+        for (int kc = 0; kc < KC; ++kc) { qf[kc] = att_row_at<HD>(Qs, rb[kc], qt * 16); gf[kc] = att_row_at<HD>(Gs, rb[kc], qt * 16); }
         const float flq = fl[qt * 16 + fr], fdq = fd[qt * 16 + fr];
         f32x4 dq[DT];
 #pragma unroll
@@ -249,20 +297,20 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
                 f32x4 sc = z, dp = z;
 #pragma unroll
                 for (int kc = 0; kc < KC; ++kc) {
-                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag<HD>(Ks, k0, lane, kc), qf[kc], sc, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_frag<HD>(Vs, k0, lane, kc), gf[kc], dp, 0, 0, 0);
+                    sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_at<HD>(Ks, rb[kc], k0), qf[kc], sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_at<HD>(Vs, rb[kc], k0), gf[kc], dp, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = k0 + 4 * g + r;
-                    const float pv = (key < N) ? exp2f(sc[r] * c2 - flq) : 0.f;
-                    ds[hf][r] = pv * (dp[r] - fdq) * scale;
+                    // padded keys need no mask here: their K rows are zero, so they add nothing to dQ
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -flq));
+                    ds[hf][r] = pv * (dp[r] - fdq);
                 }
             }
             const bf16x8 dsf = pack_frag(ds[0], ds[1]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, att_tr_frag<HD>(Ks, 32 * ks, dt, lane), dq[dt], 0, 0, 0);
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, att_tr_at<HD>(Ks, tb[dt], 32 * ks), dq[dt], 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -270,7 +318,7 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
             if (q < N) {
                 bf16_t* qp = dbase + (int64_t)q * ld + fr;
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) qp[dt * 16] = f2bf(dq[dt][r]);
+                for (int dt = 0; dt < DT; ++dt) qp[dt * 16] = f2bf(dq[dt][r] * scale);
             }
         }
     }

@@ -61,7 +61,7 @@ k_outlook_gather(const bf16_t* __restrict__ in, const bf16_t* __restrict__ logit
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int h = (H + 1) >> 1, w = (W + 1) >> 1;
     const int C = heads * OHD;
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);     // the heads of one (image, strip) share cache lines: same XCD
     const int head = bid % heads; bid /= heads;
     const int strip = bid % nstrips;
     const int b = bid / nstrips;
@@ -133,7 +133,7 @@ k_outlook_dlogits(const bf16_t* __restrict__ v, const bf16_t* __restrict__ dy, c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int h = (H + 1) >> 1, w = (W + 1) >> 1;
     const int C = heads * OHD;
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int head = bid % heads; bid /= heads;
     const int strip = bid % nstrips;
     const int b = bid / nstrips;
