@@ -24,9 +24,11 @@ class _WeightBank:
     apex's per-call casts.  The copies are stored ON the Parameter object, so they can never
     outlive it or be confused with another parameter that reuses its address."""
 
-    @staticmethod
-    def _key(p):
-        return (p.data_ptr(), p._version, tuple(p.shape))
+    generation = 0          # bumped by optimizers that update parameters through raw pointers (optim.FlatAdamWEma)
+
+    @classmethod
+    def _key(cls, p):
+        return (p.data_ptr(), p._version, cls.generation, tuple(p.shape))
 
     @staticmethod
     def _flat(p):
@@ -36,6 +38,9 @@ class _WeightBank:
     def get(self, p):
         if not isinstance(p, torch.nn.Parameter):      # derived tensor (e.g. permuted conv weight): no caching
             return ops.cast_bf16(self._flat(p))
+        flat = getattr(p, "_ap_flat16", None)          # kept current by optim.FlatAdamWEma (no cast kernels at all)
+        if flat is not None and flat[0] == p.data_ptr():
+            return flat[1]
         ent = getattr(p, "_ap_bf16", None)
         key = self._key(p)
         if ent is None or ent[0] != key:
@@ -46,6 +51,9 @@ class _WeightBank:
     def get_t(self, p):
         if not isinstance(p, torch.nn.Parameter):
             return ops.cast_transpose_bf16(self._flat(p))
+        flat = getattr(p, "_ap_flat16", None)
+        if flat is not None and flat[0] == p.data_ptr() and flat[2] is not None:
+            return flat[2]
         ent = getattr(p, "_ap_bf16_t", None)
         key = self._key(p)
         if ent is None or ent[0] != key:

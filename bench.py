@@ -155,16 +155,11 @@ def main():
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0)
     loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=1000)
-    decay, no_decay = [], []
-    skip = model.no_weight_decay()
-    for n_, p_ in model.named_parameters():
-        (no_decay if (p_.dim() == 1 or n_.endswith(".bias") or n_ in skip) else decay).append(p_)
     reducer = GradientBucketReducer(list(model.parameters()), world_size=world)
     reducer.install_sink()
-    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": no_decay, "weight_decay": 0.0}], lr=1.6e-3, fused=True)
-    ema_decays = [0.998, 0.9986, 0.999, 0.9996]
-    live = [t for t in model.state_dict().values() if t.dtype.is_floating_point]
-    emas = [[t.detach().clone() for t in live] for _ in ema_decays]
+    from autoprog_amd.optim import FlatAdamWEma
+    ema_decays = [0.998, 0.9986, 0.999, 0.9996]            # scripts/train_autoprog.sh:5
+    opt = FlatAdamWEma(model, reducer, lr=1.6e-3, weight_decay=0.05, ema_decays=ema_decays)   # one fused kernel per step
 
     B, res = args.batch, args.res
     gen = torch.Generator().manual_seed(42 + rank)
@@ -180,9 +175,6 @@ def main():
         reducer.finish()
         if not args.no_optimizer:
             opt.step()
-            with torch.no_grad():
-                for d, ema in zip(ema_decays, emas):
-                    torch._foreach_lerp_(ema, live, 1.0 - d)
         return loss
 
     for _ in range(args.warmup):

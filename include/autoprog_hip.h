@@ -131,6 +131,21 @@ int ap_add_bcast(const ap_bf16* a, const ap_bf16* b, ap_bf16* y, int64_t n, int6
 /* out[i] += sum over reps of x[r*n + i]  (fp32 accumulate; gradient of a broadcast add) */
 int ap_sum_reps_acc(const ap_bf16* x, float* out, int64_t n, int reps, ap_stream_t stream);
 
+/* ---- fused optimizer step: AdamW (torch.optim.AdamW semantics, main_prog.py:484)
+ * + n_ema <= 4 ModelEmaV2 updates (main_prog.py:1030-1033) over one flat fp32 slab of n parameters
+ * (n % 4 == 0).  wd_mask[i] != 0 selects decoupled weight decay for element i; `ema` / `ema_decay`
+ * are HOST arrays of n_ema device pointers / decays; `step` is the 1-based update count. */
+int ap_adamw_ema_step(float* p, const float* g, float* m, float* v, const unsigned char* wd_mask, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                      float* const* ema, const float* ema_decay, int n_ema,
+                      ap_bf16* p_bf16 /* nullable: bf16 copy of the updated parameters, same offsets */,
+                      ap_stream_t stream);
+/* transpose `count` bf16 matrices of one slab in one launch: desc_dev = device array of
+ * {int64 src_off, int64 dst_off, int rows, int cols, int ld_dst, int first_tile} (32x32 tiles, first_tile
+ * = running tile prefix); dst[dst_off + c*ld_dst + r] = src[src_off + r*cols + c], pad columns zeroed */
+int ap_batched_transpose_bf16(const ap_bf16* src, ap_bf16* dst, const void* desc_dev, int count, int total_tiles,
+                              ap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -270,3 +270,50 @@ def test_errors_are_loud(ops):
         ops.layernorm_fwd(torch.zeros(4, 64, dtype=torch.bfloat16), torch.ones(64), torch.zeros(64), 1e-5)   # CPU tensor
     with pytest.raises(AutoProgHipError):
         ops.mhsa_fwd(torch.zeros(2 * 300, 96, dtype=torch.bfloat16, device="cuda"), 2, 300, 1, 32 ** -0.5)   # N > 256
+
+
+def test_fused_adamw_ema_matches_torch(ops):
+    from autoprog_amd.dist import GradientBucketReducer
+    from autoprog_amd.optim import FlatAdamWEma
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(37, 53)
+            self.ln = torch.nn.LayerNorm(53)
+            self.b = torch.nn.Linear(53, 11)
+            self.pos_embed = torch.nn.Parameter(torch.randn(1, 5, 53))
+
+        def no_weight_decay(self):
+            return {"pos_embed"}
+
+        def forward(self, x):
+            return self.b(self.ln(self.a(x) + self.pos_embed.mean(1)))
+
+    torch.manual_seed(0)
+    net, ref = Net().cuda(), Net().cuda()
+    ref.load_state_dict(net.state_dict())
+    decays = [0.998, 0.9986, 0.999, 0.9996]
+    red = GradientBucketReducer(list(net.parameters()), world_size=1)
+    opt = FlatAdamWEma(net, red, lr=1.6e-3, weight_decay=0.05, ema_decays=decays)
+    dec, nodec = [], []
+    for n, p in ref.named_parameters():
+        (nodec if (p.dim() == 1 or n.endswith(".bias") or n == "pos_embed") else dec).append(p)
+    ropt = torch.optim.AdamW([{"params": dec, "weight_decay": 0.05}, {"params": nodec, "weight_decay": 0.0}], lr=1.6e-3)
+    remas = [[p.detach().clone() for p in ref.parameters()] for _ in decays]
+    for step in range(4):
+        x = torch.randn(16, 37, device="cuda")
+        red.zero_grad()
+        net(x).pow(2).mean().backward()
+        red.finish()
+        opt.step()
+        ropt.zero_grad()
+        ref(x).pow(2).mean().backward()
+        ropt.step()
+        for d, em in zip(decays, remas):
+            torch._foreach_lerp_(em, [p.detach() for p in ref.parameters()], 1.0 - d)
+    for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+        assert torch.allclose(p, q, atol=2e-6, rtol=1e-5), n
+    sd = opt.ema_state_dict(2)
+    for (n, _), e in zip(ref.named_parameters(), remas[2]):
+        assert torch.allclose(sd[n], e, atol=2e-6, rtol=1e-5), n
