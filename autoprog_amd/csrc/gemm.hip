@@ -100,99 +100,123 @@ __device__ __forceinline__ void epi_chunk(float* v, int m, int n, int N, int ldc
     }
 }
 
-__global__ void __launch_bounds__(256)
+// Register-staged multi-workgroup kernel, templated on the block tile TM x TN and the wave grid WGM x WGN
+// (wave tile (TM/WGM) x (TN/WGN), BK = 64).  Variants are selected per shape by ap_gemm_nt.
+template <int TM, int TN, int WGM, int WGN>
+__global__ void __launch_bounds__(WGM * WGN * 64)
 k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
           int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem_nt[(SBM + SBN) * SBK];       // 32 KB: A tile | B tile; reused by the epilogue
+    constexpr int NTH = WGM * WGN * 64;
+    constexpr int MT = TM / WGM / 16, NT = TN / WGN / 16;
+    constexpr int NA = TM * 8 / NTH, NB = TN * 8 / NTH;              // 16-B chunks per thread per K step
+    constexpr int EROWS_RAW = ((TM + TN) * 32 / TN) / 16 * 16;        // rows of the fp32 staging tile that fit the LDS
+    constexpr int EROWS = EROWS_RAW < TM ? EROWS_RAW : TM;
+    constexpr int PASSES = (TM + EROWS - 1) / EROWS;
+    static_assert(TM * 8 % NTH == 0 && TN * 8 % NTH == 0, "staging split");
+    static_assert((TM / WGM) % 16 == 0 && (TN / WGN) % 16 == 0, "wave tile");
+    static_assert(EROWS >= 16 && EROWS % 16 == 0, "epilogue pass split");
+    __shared__ __attribute__((aligned(16))) bf16_t smem_nt[(TM + TN) * SBK];       // A tile | B tile; reused by the epilogue
     bf16_t* sA = smem_nt;
-    bf16_t* sB = smem_nt + SBM * SBK;
+    bf16_t* sB = smem_nt + TM * SBK;
     const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int m0 = (tile / tiles_n) * SBM, n0 = (tile % tiles_n) * SBN;
+    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int fr = lane & 15, g = lane >> 4;
 
-    // staging assignment: 4 chunks per operand per thread: rows (tid>>3)+32*i, chunk kc = tid&7
+    // staging assignment: rows (tid>>3) + (NTH/8)*i, chunk kc = tid&7
     const int srow = tid >> 3, kc = tid & 7;
-    const bf16_t* ga[4];
-    const bf16_t* gb[4];
-    int soff[4];
+    const bf16_t* ga[NA];
+    const bf16_t* gb[NB];
+    int soffa[NA], soffb[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = srow + 32 * i;
+    for (int i = 0; i < NA; ++i) {
+        const int r = srow + (NTH / 8) * i;
         ga[i] = A + (int64_t)min(m0 + r, M - 1) * lda + kc * 8;
-        gb[i] = B + (int64_t)min(n0 + r, N - 1) * ldb + kc * 8;
-        soff[i] = r * SBK + ((kc ^ (r & 7)) << 3);          // in elements
+        soffa[i] = r * SBK + ((kc ^ (r & 7)) << 3);
     }
-    u32x4 ra[4], rb[4];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int r = srow + (NTH / 8) * i;
+        gb[i] = B + (int64_t)min(n0 + r, N - 1) * ldb + kc * 8;
+        soffb[i] = r * SBK + ((kc ^ (r & 7)) << 3);
+    }
+    u32x4 ra[NA], rb[NB];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     auto gload = [&](int k0) {
         const bool ok = (k0 + kc * 8) < K;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = ok ? ld16(ga[i] + k0) : zero4;
-            rb[i] = ok ? ld16(gb[i] + k0) : zero4;
-        }
+        for (int i = 0; i < NA; ++i) ra[i] = ok ? ld16(ga[i] + k0) : zero4;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = ok ? ld16(gb[i] + k0) : zero4;
     };
 
-    f32x4 acc[4][4];     // [nt][mt]
+    f32x4 acc[NT][MT];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     gload(0);
     for (int k0 = 0; k0 < K; k0 += SBK) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { st16(sA + soff[i], ra[i]); st16(sB + soff[i], rb[i]); }
+        for (int i = 0; i < NA; ++i) st16(sA + soffa[i], ra[i]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) st16(sB + soffb[i], rb[i]);
         __syncthreads();
         if (k0 + SBK < K) gload(k0 + SBK);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 xf[4], wf[4];
+            bf16x8 xf[MT], wf[NT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int ra_ = wm * 64 + t * 16 + fr;
-                const int rb_ = wn * 64 + t * 16 + fr;
-                xf[t] = as_bf16x8(ld16(sA + ra_ * SBK + (((ks * 4 + g) ^ (ra_ & 7)) << 3)));
-                wf[t] = as_bf16x8(ld16(sB + rb_ * SBK + (((ks * 4 + g) ^ (rb_ & 7)) << 3)));
+            for (int t = 0; t < MT; ++t) {
+                const int r = wm * (TM / WGM) + t * 16 + fr;
+                xf[t] = as_bf16x8(ld16(sA + r * SBK + (((ks * 4 + g) ^ (r & 7)) << 3)));
             }
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int t = 0; t < NT; ++t) {
+                const int r = wn * (TN / WGN) + t * 16 + fr;
+                wf[t] = as_bf16x8(ld16(sB + r * SBK + (((ks * 4 + g) ^ (r & 7)) << 3)));
+            }
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
         }
         __syncthreads();
     }
 
     // ---------------------------------------------------------------- epilogue
-    // two passes of 64 rows: accumulators -> fp32 [64][128] tile in LDS (16-B chunk swizzle) -> every
+    // PASSES passes of EROWS rows: accumulators -> fp32 [EROWS][TN] tile in LDS (16-B chunk swizzle) -> every
     // thread finishes 8 consecutive columns of a row with 16-byte coalesced global accesses
     float* ctile = reinterpret_cast<float*>(smem_nt);
     const bool vec_ok = ((ldc & 7) == 0) && (ep.residual == nullptr || (ep.ldr & 7) == 0);
+    constexpr int CPR = TN / 8;
 #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-        if (wm == pass) {
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int prow0 = pass * EROWS;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int r = mt * 16 + fr;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int rt = wm * (TM / WGM) + mt * 16;                 // first row of this 16-row fragment within the tile
+            if (rt >= prow0 && rt < prow0 + EROWS) {
+                const int r = rt - prow0 + fr;
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int c16 = (wn * 64 + nt * 16) / 4 + g;
-                    *reinterpret_cast<f32x4*>(ctile + r * SBN + ((c16 ^ (r & 7)) << 2)) = acc[nt][mt];
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int c16 = (wn * (TN / WGN) + nt * 16) / 4 + g;
+                    *reinterpret_cast<f32x4*>(ctile + r * TN + ((c16 ^ (r & 7)) << 2)) = acc[nt][mt];
                 }
             }
         }
         __syncthreads();
 #pragma unroll 2
-        for (int id = tid; id < 64 * (SBN / 8); id += 256) {
-            const int r = id >> 4, j = id & 15;
-            const int m = m0 + pass * 64 + r, n = n0 + 8 * j;
-            if (m >= M || n >= N) continue;
+        for (int id = tid; id < EROWS * CPR; id += NTH) {
+            const int r = id / CPR, j = id - r * CPR;
+            const int m = m0 + prow0 + r, n = n0 + 8 * j;
+            if (prow0 + r >= TM || m >= M || n >= N) continue;
             float v[8];
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(ctile + r * SBN + (((2 * j) ^ (r & 7)) << 2));
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(ctile + r * SBN + (((2 * j + 1) ^ (r & 7)) << 2));
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(ctile + r * TN + (((2 * j) ^ (r & 7)) << 2));
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(ctile + r * TN + (((2 * j + 1) ^ (r & 7)) << 2));
             v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
             epi_chunk(v, m, n, N, ldc, vec_ok, ep, C);
         }
@@ -641,9 +665,31 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         else hipLaunchKernelGGL((k_gemm_nt_ring<128, 2, 4>), dim3(grid), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
         return ap_check_launch();
     }
-    const int tiles_m = (M + SBM - 1) / SBM, tiles_n = (N + SBN - 1) / SBN;
-    const int ntiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL(k_gemm_nt, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ntiles, ep);
+    // tile selection (measured on the VOLO-D1 shape list, tools/bench_gemm.py): AP_GEMM_NT_TILE forces a variant
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("AP_GEMM_NT_TILE"); forced = e ? atoi(e) : 0; }
+    int variant = forced;
+    if (variant == 0) {
+        // measured on the D1 shape list (tools/bench_gemm.py, AP_GEMM_NT_TILE sweep): narrow/short problems want
+        // small tiles (more workgroups, 4-6 waves/SIMD, no wasted columns at N = 192/486/576), the rest 128x128
+        if (N <= 512 && K <= 256) variant = 4;                                   // 64x64
+        else if (N <= 256 || ((N % 128 != 0) && (N % 64 == 0))) variant = 2;     // 128x64
+        else variant = 1;                                                        // 128x128
+    }
+#define NT_LAUNCH(TMv, TNv, WMv, WNv)                                                                        \
+    {                                                                                                          \
+        const int tm_ = (M + TMv - 1) / TMv, tn_ = (N + TNv - 1) / TNv, nt_ = tm_ * tn_;                       \
+        hipLaunchKernelGGL((k_gemm_nt<TMv, TNv, WMv, WNv>), dim3(nt_), dim3(WMv * WNv * 64), 0, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn_, nt_, ep); \
+    }
+    switch (variant) {
+        case 2: NT_LAUNCH(128, 64, 2, 2) break;
+        case 3: NT_LAUNCH(64, 128, 2, 2) break;
+        case 4: NT_LAUNCH(64, 64, 2, 2) break;
+        case 5: NT_LAUNCH(256, 128, 4, 2) break;
+        case 6: NT_LAUNCH(128, 128, 2, 4) break;
+        default: NT_LAUNCH(128, 128, 2, 2) break;
+    }
+#undef NT_LAUNCH
     return ap_check_launch();
 }
 
