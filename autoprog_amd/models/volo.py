@@ -52,11 +52,27 @@ class DropPathRng:
 
     def __init__(self):
         self.queue = []
+        self._pool = []
+
+    def prefetch(self, keeps, batch, device):
+        """draw the factors of a whole forward pass (one entry of `keeps` per DropPath site, in call order)
+        with three small kernels instead of three per site"""
+        if self.queue or not keeps:
+            self._pool = []
+            return
+        k = torch.tensor(keeps, dtype=torch.float32, device=device).unsqueeze(1)
+        f = (torch.rand(len(keeps), batch, device=device) + k).floor_() / k
+        self._pool = [(keeps[i], f[i]) for i in range(len(keeps))]
 
     def draw(self, batch, keep, device):
         if self.queue:
             m = self.queue.pop(0)
             return (m.to(device=device, dtype=torch.float32) / keep).contiguous()
+        if self._pool:
+            k, f = self._pool.pop(0)
+            if k == keep and f.shape[0] == batch:
+                return f
+            self._pool = []
         return ((keep + torch.rand(batch, device=device)).floor_() / keep).contiguous()
 
 
@@ -445,6 +461,14 @@ class VOLO(nn.Module):
         return x.permute(0, 2, 3, 1).to(BF16).contiguous()     # [B,H,W,C] token-major (no copy if already NHWC)
 
     def forward_tokens(self, x):
+        if self.training:
+            keeps = []
+            for stage in self.network:
+                if isinstance(stage, nn.Sequential):
+                    for blk in stage:
+                        if isinstance(blk, Transformer) and blk.drop_prob > 0.0 and not blk.is_identity_layer:
+                            keeps += [1.0 - blk.drop_prob, 1.0 - blk.drop_prob]
+            self.drop_path_rng.prefetch(keeps, x.shape[0], x.device)
         for idx, block in enumerate(self.network):
             if idx == 2:
                 x = AF.AddPosFn.apply(x, self.interpolate_pos_encoding(x))
