@@ -451,6 +451,29 @@ class MhsaFn(torch.autograd.Function):
         return ops.mhsa_bwd(qc, o, do.contiguous(), lse, B, N, heads, scale), None, None, None
 
 
+class BNReLUFn(torch.autograd.Function):
+    """BatchNorm2d (batch statistics in training, running statistics in eval) + ReLU on an NHWC bf16 tensor
+    (the stem's conv -> BN -> ReLU triples, models/volo.py:355-367)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps):
+        xc = x.contiguous()
+        y, mean, rstd = ops.bn_relu_fwd(xc, weight, bias, running_mean, running_var, training, momentum, eps)
+        ctx.save_for_backward(xc, weight, bias, mean, rstd)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, weight, bias, mean, rstd = ctx.saved_tensors
+        if not ctx.training:
+            raise AutoProgHipError("BNReLUFn backward is implemented for training mode (batch statistics) only")
+        dg = torch.zeros_like(weight)
+        db = torch.zeros_like(bias)
+        dx = ops.bn_relu_bwd(dy.contiguous(), xc, weight, bias, mean, rstd, dg, db)
+        return dx, dg, db, None, None, None, None, None
+
+
 def to_bf16(x):
     """fp32/bf16 torch tensor -> contiguous bf16 (autograd-aware torch cast: stem boundary)"""
     return x.to(BF16).contiguous()

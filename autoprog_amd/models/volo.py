@@ -300,13 +300,27 @@ class PatchEmbed(nn.Module):
         self.compute_dtype = BF16          # torch.float32 runs the MIOpen stem un-autocast (parity debugging)
 
     def forward(self, x):
-        """[B,3,r,r] -> NCHW feature map (channels_last memory, bf16)"""
+        """[B,3,r,r] -> NCHW feature map (channels_last memory, bf16).  Convolutions go through MIOpen
+        (torch.nn.functional.conv2d, bf16 channels_last); every BatchNorm+ReLU pair runs as the fused HIP
+        kernels of csrc/bnrelu.hip on the NHWC view of the conv output."""
         if not x.is_cuda:
             raise RuntimeError("autoprog_amd models run on the GPU only (no CPU fallback)")
         x = x.contiguous(memory_format=torch.channels_last)
-        with torch.autocast("cuda", dtype=BF16, enabled=self.compute_dtype == BF16):
+        fused = self.compute_dtype == BF16
+        with torch.autocast("cuda", dtype=BF16, enabled=fused):
             if self.stem_conv:
-                x = self.conv(x)
+                if fused:
+                    for i in (0, 3, 6):
+                        conv, bn = self.conv[i], self.conv[i + 1]
+                        x = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+                        x = x.contiguous(memory_format=torch.channels_last)          # no-op when MIOpen kept NHWC
+                        nhwc = AF.BNReLUFn.apply(x.permute(0, 2, 3, 1), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                 self.training, bn.momentum, bn.eps)
+                        if self.training and bn.num_batches_tracked is not None:
+                            bn.num_batches_tracked += 1
+                        x = nhwc.permute(0, 3, 1, 2)                                    # NCHW view, channels_last strides
+                else:
+                    x = self.conv(x)
             x = self.proj(x)
         return x
 

@@ -243,3 +243,38 @@ def sum_reps_acc(x, out, reps):
     _req(x, BF16, "x"); _req(out, torch.float32, "out")
     check(lib.ap_sum_reps_acc(x.data_ptr(), out.data_ptr(), out.numel(), int(reps), _stream()), "ap_sum_reps_acc")
     return out
+
+
+# ---------------------------------------------------------------------------- stem BN + ReLU
+def bn_relu_fwd(x, gamma, beta, running_mean, running_var, training, momentum, eps):
+    """x: bf16 [..., C] NHWC rows.  returns (y, mean, rstd)"""
+    _req(x, BF16, "x")
+    C = x.shape[-1]
+    T = x.numel() // C
+    y = torch.empty_like(x)
+    if training:
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    else:
+        mean = running_mean.float().contiguous()
+        rstd = torch.rsqrt(running_var.float() + eps).contiguous()
+    ws_bytes = lib.ap_bn_relu_workspace(T, C)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    check(lib.ap_bn_relu_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                             running_mean.data_ptr() if (training and running_mean is not None) else None,
+                             running_var.data_ptr() if (training and running_var is not None) else None,
+                             1 if training else 0, float(momentum), float(eps), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                             T, C, ws.data_ptr(), ws_bytes, _stream()), "ap_bn_relu_fwd")
+    return y, mean, rstd
+
+
+def bn_relu_bwd(dy, x, gamma, beta, mean, rstd, dgamma, dbeta):
+    _req(dy, BF16, "dy"); _req(x, BF16, "x")
+    C = x.shape[-1]
+    T = x.numel() // C
+    dx = torch.empty_like(x)
+    ws_bytes = lib.ap_bn_relu_workspace(T, C)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    check(lib.ap_bn_relu_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                             dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), T, C, ws.data_ptr(), ws_bytes, _stream()), "ap_bn_relu_bwd")
+    return dx

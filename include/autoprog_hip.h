@@ -131,6 +131,19 @@ int ap_add_bcast(const ap_bf16* a, const ap_bf16* b, ap_bf16* y, int64_t n, int6
 /* out[i] += sum over reps of x[r*n + i]  (fp32 accumulate; gradient of a broadcast add) */
 int ap_sum_reps_acc(const ap_bf16* x, float* out, int64_t n, int reps, ap_stream_t stream);
 
+/* ---- fused BatchNorm2d + ReLU of the conv stem on NHWC bf16 rows [T = B*H*W, C] (models/volo.py:355-367;
+ * SURVEY.md row N3).  training != 0: batch statistics (biased variance), running stats updated with
+ * `momentum` (unbiased variance) as nn.BatchNorm2d; mean/rstd are outputs saved for backward.
+ * training == 0: mean/rstd are INPUTS (running_mean, 1/sqrt(running_var+eps)).  C/8 must be a power of two. */
+size_t ap_bn_relu_workspace(int64_t T, int C);
+int ap_bn_relu_fwd(const ap_bf16* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                   int training, float momentum, float eps, ap_bf16* y, float* mean, float* rstd, int64_t T, int C,
+                   void* workspace, size_t ws_bytes, ap_stream_t stream);
+/* dx = d(relu(bn(x)))/dx . dy ; dgamma/dbeta accumulated (+=) */
+int ap_bn_relu_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* beta, const float* mean,
+                   const float* rstd, ap_bf16* dx, float* dgamma, float* dbeta, int64_t T, int C,
+                   void* workspace, size_t ws_bytes, ap_stream_t stream);
+
 /* ---- fused optimizer step: AdamW (torch.optim.AdamW semantics, main_prog.py:484)
  * + n_ema <= 4 ModelEmaV2 updates (main_prog.py:1030-1033) over one flat fp32 slab of n parameters
  * (n % 4 == 0).  wd_mask[i] != 0 selects decoupled weight decay for element i; `ema` / `ema_decay`

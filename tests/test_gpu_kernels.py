@@ -317,3 +317,32 @@ def test_fused_adamw_ema_matches_torch(ops):
     sd = opt.ema_state_dict(2)
     for (n, _), e in zip(ref.named_parameters(), remas[2]):
         assert torch.allclose(sd[n], e, atol=2e-6, rtol=1e-5), n
+
+
+@pytest.mark.parametrize("B,H,W,C", [(4, 16, 16, 64), (2, 9, 7, 16), (3, 12, 12, 128), (2, 5, 5, 8)])
+def test_bn_relu_fused(ops, B, H, W, C):
+    from autoprog_amd import functional as AF
+    x = rnd(B, H, W, C, scale=1.5, seed=1) + 0.3
+    g = torch.randn(C, generator=torch.Generator().manual_seed(2)) * 0.3 + 1
+    b = torch.randn(C, generator=torch.Generator().manual_seed(3)) * 0.3
+    dy = rnd(B, H, W, C, seed=4)
+    # reference: torch BatchNorm2d (training) + ReLU in fp64 on the NCHW view
+    bn = torch.nn.BatchNorm2d(C).double().train()
+    with torch.no_grad():
+        bn.weight.copy_(g); bn.bias.copy_(b)
+    xr = x.double().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    yr = torch.relu(bn(xr))
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    xg = dev(x).requires_grad_(True)
+    gg, bg = dev(g).requires_grad_(True), dev(b).requires_grad_(True)
+    y = AF.BNReLUFn.apply(xg, gg, bg, rm, rv, True, 0.1, 1e-5)
+    y.backward(dev(dy))
+    assert rel(y, yr.permute(0, 2, 3, 1)) < TOL_BF16
+    assert rel(xg.grad, xr.grad.permute(0, 2, 3, 1)) < 1.5e-2
+    assert rel(gg.grad, bn.weight.grad) < 5e-3 and rel(bg.grad, bn.bias.grad) < 5e-3
+    assert rel(rm, bn.running_mean) < 1e-4 and rel(rv, bn.running_var) < 1e-4
+    # eval mode with the running statistics
+    bn.eval()
+    ye = AF.BNReLUFn.apply(dev(x), dev(g), dev(b), rm, rv, False, 0.1, 1e-5)
+    assert rel(ye, torch.relu(bn(x.double().permute(0, 3, 1, 2))).permute(0, 2, 3, 1)) < TOL_BF16
