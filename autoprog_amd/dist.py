@@ -45,6 +45,7 @@ class GradientBucketReducer:
         self._pending = [len(m) for (_, _, m) in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._handles = []
+        self._seen = set()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.world > 1 else []
         self._owned = {id(p) for p in self.params}
 
@@ -72,6 +73,11 @@ class GradientBucketReducer:
 
     # ------------------------------------------------------------------ hooks
     def _on_grad(self, p):
+        # idempotent per step: autograd may still run the AccumulateGrad node (and this hook) of a parameter
+        # whose gradient the fused backward already delivered through param_ready()
+        if id(p) in self._seen:
+            return
+        self._seen.add(id(p))
         b = self._bucket_of[id(p)]
         self._pending[b] -= 1
         if self._pending[b] == 0 and not self._launched[b]:
@@ -89,6 +95,7 @@ class GradientBucketReducer:
         self._pending = [len(m) for (_, _, m) in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._handles = []
+        self._seen = set()
 
     def finish(self):
         """call after backward(): reduce buckets whose hooks did not all fire (skipped layers), wait

@@ -49,6 +49,46 @@ def _worker(rank, world, port, q):
                     acc += g / world
             for got, want in zip(results[-1], ref):
                 assert torch.allclose(got, want, atol=1e-6), (rank, step)
+        # gradient-sink protocol (functional.set_grad_sink): a fused backward writes param.grad in place, calls
+        # param_ready() and returns None to autograd -- whose AccumulateGrad hook may still fire for that
+        # parameter; a bucket must not be counted ready twice (it would launch before its other members exist)
+        red.remove()
+        red = GradientBucketReducer(list(net.parameters()), bucket_bytes=1 << 20, world_size=world)    # ONE bucket
+        assert len(red.buckets) == 1
+
+        class SinkLinear(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w):
+                ctx.save_for_backward(x, w)
+                return x @ w.t()
+
+            @staticmethod
+            def backward(ctx, dy):
+                x, w = ctx.saved_tensors
+                for hnd in red._handles:          # make a prematurely launched all-reduce deterministic: let it complete
+                    hnd.wait()
+                w.grad += dy.t() @ x
+                red.param_ready(w)
+                return dy @ w, None
+
+        lins = [net[0], net[2], net[4]]
+        torch.manual_seed(300 + rank)
+        x = torch.randn(8, 16)
+        red.zero_grad()
+        h = x
+        for i, lin in enumerate(lins):
+            h = SinkLinear.apply(h, lin.weight) + lin.bias
+            h = torch.relu(h) if i < 2 else h
+        h.pow(2).mean().backward()
+        red.finish()
+        ref = [torch.zeros_like(p) for p in net.parameters()]
+        for r in range(world):
+            torch.manual_seed(300 + r)
+            gs = torch.autograd.grad(net(torch.randn(8, 16)).pow(2).mean(), list(net.parameters()))
+            for acc, g in zip(ref, gs):
+                acc += g / world
+        for got, want in zip([p.grad for p in net.parameters()], ref):
+            assert torch.allclose(got, want, atol=1e-6), (rank, "sink")
         m = reduce_scalar_mean(torch.tensor(float(rank)), world)
         assert float(m) == pytest.approx((world - 1) / 2)
         q.put((rank, "ok"))

@@ -1,0 +1,60 @@
+"""debug: two gloo ranks on one GPU, report bucket bookkeeping"""
+import os, sys, socket
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch, torch.distributed as dist, torch.multiprocessing as mp
+from test_gpu_dp import _make, _data, _free_port
+
+def worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    from autoprog_amd.dist import GradientBucketReducer
+    model = _make()
+    model.set_sample_config(dict(layer_num=4, min_layer_num=3, max_layer_num=6))
+    red = GradientBucketReducer(list(model.parameters()), bucket_bytes=64 << 10, world_size=world)
+    red.install_sink()
+    names = {id(p): n for n, p in model.named_parameters()}
+    log = []
+    orig = red._on_grad
+    def on_grad(p):
+        import traceback
+        st = traceback.extract_stack(limit=4)
+        log.append(names[id(p)] + " <" + "/".join(f.name for f in st[:-1]) + ">")
+        orig(p)
+    red._on_grad = on_grad
+    for h in red._hooks: h.remove()
+    red._hooks = [p.register_post_accumulate_grad_hook(on_grad) for p in red.params]
+    origl = red._launch
+    def launch(b):
+        log.append("LAUNCH %d" % b)
+        origl(b)
+    red._launch = launch
+    x, t = _data(rank)
+    np.random.seed(5)
+    red.zero_grad()
+    loss = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=16)(model(x), t)
+    loss.backward()
+    log.append("FINISH")
+    red.finish()
+    torch.cuda.synchronize()
+    if rank == 0:
+        order = list(reversed(red.params))
+        for b, (s, e, m) in enumerate(red.buckets):
+            print("bucket", b, s, e, [names[id(order[i])] for i in m][:3], "...", [names[id(order[i])] for i in m][-3:])
+        print("pending", red._pending)
+        from collections import Counter
+        c = Counter(l.split(" <")[0] for l in log if not l.startswith(("LAUNCH", "FINISH")))
+        print("multi-fire:", {k: v for k, v in c.items() if v > 1})
+        print("log 2.3/2.0:", [(i, l) for i, l in enumerate(log) if l.startswith(("network.2.3.", "network.2.0.", "LAUNCH"))])
+        lo, hi = red.flat.data_ptr(), red.flat.data_ptr() + red.flat.numel() * 4
+        for n, p in model.named_parameters():
+            if not (lo <= p.grad.data_ptr() < hi):
+                print("grad left the slab:", n)
+    dist.destroy_process_group()
+
+if __name__ == "__main__":
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=worker, args=(r, 2, port)) for r in range(2)]
+    [p.start() for p in ps]; [p.join() for p in ps]
