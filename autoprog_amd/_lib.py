@@ -18,6 +18,13 @@ class GemmEpilogue(Structure):
                 ("row_scale", c_void_p), ("rows_per_scale", c_int), ("residual", c_void_p), ("ldr", c_int)]
 
 
+class TnProblem(Structure):
+    """ap_tn_problem (include/autoprog_hip.h)"""
+    _fields_ = [("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int), ("C", c_void_p), ("ldc", c_int),
+                ("M", c_int), ("N1", c_int), ("N2", c_int), ("colsum_A", c_void_p)]
+
+
+TN_MAX_GROUP = 8
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 _SIGNATURES = {
     "ap_abi_version": (c_int, []),
@@ -30,6 +37,7 @@ _SIGNATURES = {
     "ap_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, _P]),
     "ap_gemm_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, POINTER(GemmEpilogue), _P]),
     "ap_gemm_tn_acc": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
+    "ap_gemm_tn_acc_grouped": (_I, [_P, _I, _P]),
     "ap_colsum_acc": (_I, [_P, _I, _P, _I, _I, _P]),
     "ap_outlook_fwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "ap_outlook_bwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

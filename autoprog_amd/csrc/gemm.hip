@@ -22,7 +22,11 @@
 // is split across blockIdx.z and partial tiles are added with fp32 atomics (few MB per call).
 #include "common.h"
 #include <cstdlib>
+#include <cstdio>
 
+#ifndef AP_ABL
+#define AP_ABL 0
+#endif
 #define SBM 128
 #define SBN 128
 #define SBK 64
@@ -31,7 +35,7 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_b
 
 struct EpiArgs {
     const float* bias; int gelu; bf16_t* preact; const bf16_t* dgelu_of; const float* row_scale;
-    int rows_per_scale; const bf16_t* residual; int ldr; int dbg;
+    int rows_per_scale; const bf16_t* residual; int ldr; int dbg; unsigned long long* stamps;
 };
 
 // epilogue of 8 consecutive output columns [n, n+8) of row m held in v[] (fp32 accumulators):
@@ -102,7 +106,12 @@ __device__ __forceinline__ void epi_chunk(float* v, int m, int n, int N, int ldc
 
 // Register-staged multi-workgroup kernel, templated on the block tile TM x TN and the wave grid WGM x WGN
 // (wave tile (TM/WGM) x (TN/WGN), BK = 64).  Variants are selected per shape by ap_gemm_nt.
-template <int TM, int TN, int WGM, int WGN>
+__device__ __forceinline__ int key_a(int r) { return r & 7; }
+// B-tile swizzle key for the N-permuted fragment rows (see "direct epilogue" below): the 16 rows one
+// ds_read_b128 lane group touches are 8q + 4b + p (q = 0..3, p = 0..3) -> keys p | (q&1)<<2 are distinct
+__device__ __forceinline__ int key_b(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
+template <int TM, int TN, int WGM, int WGN, bool DEPI = true>
 __global__ void __launch_bounds__(WGM * WGN * 64)
 k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
           int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
@@ -139,7 +148,7 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
     for (int i = 0; i < NB; ++i) {
         const int r = srow + (NTH / 8) * i;
         gb[i] = B + (int64_t)min(n0 + r, N - 1) * ldb + kc * 8;
-        soffb[i] = r * SBK + ((kc ^ (r & 7)) << 3);
+        soffb[i] = r * SBK + ((kc ^ (DEPI ? key_b(r) : key_a(r))) << 3);
     }
     u32x4 ra[NA], rb[NB];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -164,7 +173,7 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
 #pragma unroll
         for (int i = 0; i < NB; ++i) st16(sB + soffb[i], rb[i]);
         __syncthreads();
-        if (k0 + SBK < K) gload(k0 + SBK);
+        if (k0 + SBK < K && !(ep.dbg & 2)) gload(k0 + SBK);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 xf[MT], wf[NT];
@@ -175,8 +184,18 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int r = wn * (TN / WGN) + t * 16 + fr;
-                wf[t] = as_bf16x8(ld16(sB + r * SBK + (((ks * 4 + g) ^ (r & 7)) << 3)));
+                // DEPI: fragment t of pair P = t>>1 holds weight rows 32P + 8q + 4(t&1) + p for MFMA row 4q + p, so a
+                // lane's 4 + 4 accumulator registers of the pair are 8 CONSECUTIVE output columns
+                const int r = DEPI ? wn * (TN / WGN) + 32 * (t >> 1) + 8 * (fr >> 2) + 4 * (t & 1) + (fr & 3)
+                                   : wn * (TN / WGN) + t * 16 + fr;
+                wf[t] = as_bf16x8(ld16(sB + r * SBK + (((ks * 4 + g) ^ (DEPI ? key_b(r) : key_a(r))) << 3)));
+            }
+            if (ep.dbg & 4) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) asm volatile("" ::"v"(xf[t]));
+#pragma unroll
+                for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(wf[t]));
+                continue;
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -186,12 +205,40 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
         }
         __syncthreads();
     }
+    if (ep.dbg & 1) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+        if (sacc == 12345.678f) C[0] = 1;
+        return;
+    }
 
     // ---------------------------------------------------------------- epilogue
     // PASSES passes of EROWS rows: accumulators -> fp32 [EROWS][TN] tile in LDS (16-B chunk swizzle) -> every
     // thread finishes 8 consecutive columns of a row with 16-byte coalesced global accesses
-    float* ctile = reinterpret_cast<float*>(smem_nt);
     const bool vec_ok = ((ldc & 7) == 0) && (ep.residual == nullptr || (ep.ldr & 7) == 0);
+    if constexpr (DEPI) {
+        // direct epilogue: no LDS round trip.  Lane (fr, g) owns, per fragment pair, columns 8g..8g+7 of row fr:
+        // one wave instruction stores 16 rows x 64 contiguous bytes.
+        static_assert(NT % 2 == 0, "N-permuted fragments come in pairs");
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wm * (TM / WGM) + mt * 16 + fr;
+#pragma unroll
+            for (int pr = 0; pr < NT / 2; ++pr) {
+                const int n = n0 + wn * (TN / WGN) + 32 * pr + 8 * g;
+                if (m >= M || n >= N) continue;
+                float v[8];
+                v[0] = acc[2 * pr][mt][0]; v[1] = acc[2 * pr][mt][1]; v[2] = acc[2 * pr][mt][2]; v[3] = acc[2 * pr][mt][3];
+                v[4] = acc[2 * pr + 1][mt][0]; v[5] = acc[2 * pr + 1][mt][1]; v[6] = acc[2 * pr + 1][mt][2]; v[7] = acc[2 * pr + 1][mt][3];
+                epi_chunk(v, m, n, N, ldc, vec_ok, ep, C);
+            }
+        }
+        return;
+    }
+    float* ctile = reinterpret_cast<float*>(smem_nt);
     constexpr int CPR = TN / 8;
 #pragma unroll 1
     for (int pass = 0; pass < PASSES; ++pass) {
@@ -359,6 +406,233 @@ k_gemm_nt_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------ gemm_nt, persistent 256 x (32*NTF) tiles
+// The multi-workgroup 128x128 kernel above is LDS-bound (ablation on the qkv shape, DESIGN.md: the
+// ds_write/ds_read/barrier loop alone takes 16.7 us of 36 -- 0.5 KB of fragment reads per MFMA plus
+// ds_write_b128 at ~79 B/clk).  This kernel cuts the LDS cycles per FLOP:
+//   * operands go global -> LDS by LDS-DMA (global_load_lds, 16 B/lane): no VGPR round trip, no ds_write
+//   * 8 waves as 4(M) x 2(N), wave tile 64 x (16*NTF): 0.42 KB of fragment reads per MFMA at NTF = 6
+//   * persistent (one workgroup per CU), K steps flattened over (tile, k): the DMA of the next tile's first
+//     K step is in flight while the current tile's epilogue runs; 2-stage ring, one raw s_barrier per K step
+//   * epilogue per wave through a PRIVATE fp32 LDS strip (no workgroup barrier): accumulators -> strip ->
+//     rows of 8 consecutive columns per lane -> 16-byte coalesced loads/stores (epi_chunk)
+// LDS image of a stage: [256 A rows | TBN B rows] x 64 bf16, 16-B chunk index XORed with row&7 (applied on
+// the DMA SOURCE address; the DMA writes LDS linearly).
+template <int NTF>
+__global__ void __launch_bounds__(512)
+k_gemm_nt_p(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
+            int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char p_raw[];
+    constexpr int TBM = 256, TBN = 32 * NTF, ROWS = TBM + TBN;
+    constexpr int STAGE = ROWS * 64;                 // bf16 elements per stage
+    constexpr int NI = ROWS / 64;                    // LDS-DMA instructions per wave per K step (8 rows each, 8 waves)
+    constexpr int WN_COLS = TBN / 2;                 // columns per wave
+    constexpr int STRIP = 16 * WN_COLS;              // floats per wave staging strip
+    static_assert(ROWS % 64 == 0, "stage rows split over 8 waves x 8 rows");
+    bf16_t* ring = reinterpret_cast<bf16_t*>(p_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* strip = reinterpret_cast<float*>(p_raw + (size_t)2 * STAGE * sizeof(bf16_t)) + wave * STRIP;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, g = lane >> 4;
+    const int nk = K >> 6;
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    const int total = my_tiles * nk;
+
+    // per-lane DMA source offsets (elements) of the tile being prefetched
+    uint32_t soff[NI];                               // element offsets < 2^32 (checked by the launcher)
+    auto set_tile_src = [&](int ti) {
+        const int tile = xcd_remap(blockIdx.x + ti * G, ntiles);
+        int m0 = (tile / tiles_n) * TBM, n0 = (tile % tiles_n) * TBN;
+        if (ep.dbg & 8) { m0 = 0; n0 = 0; }           // ablation: every workgroup streams the same (cache-resident) panels
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = (wave + 8 * i) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            soff[i] = (r < TBM) ? (uint32_t)min(m0 + r, M - 1) * (uint32_t)lda + c * 8
+                                : (uint32_t)min(n0 + (r - TBM), N - 1) * (uint32_t)ldb + c * 8;
+        }
+    };
+    int q_tile = 0, q_k = 0;
+    constexpr int NIA = (NI + 1) / 2;                // pieces of part A (issued first), the rest is part B
+    auto issue_part = [&](int stage, int i0, int i1) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (i < i0 || i >= i1) continue;
+            const int r0 = (wave + 8 * i) * 8;                       // wave-uniform first row of this 8-row piece
+            const bf16_t* base = (r0 < TBM) ? A : B;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + soff[i] + q_k * 64),
+                                             (__attribute__((address_space(3))) void*)(ring + stage * STAGE + r0 * 64), 16, 0, 0);
+        }
+    };
+    auto issue_a = [&](int stage) {
+        if (q_k == 0) set_tile_src(q_tile);
+        issue_part(stage, 0, NIA);
+    };
+    auto issue_b = [&](int stage) {
+        issue_part(stage, NIA, NI);
+        if (++q_k == nk) { q_k = 0; ++q_tile; }
+    };
+    auto issue = [&](int stage) { issue_a(stage); issue_b(stage); };
+
+    f32x4 acc[NTF][4];
+    bf16x8 xf0[4], wf0[NTF], xf1[4], wf1[NTF];       // two fragment sets: reads of one are interleaved with the MFMAs of the other
+    auto frags = [&](const bf16_t* st, int ks, bf16x8* xf, bf16x8* wf) {
+        const bf16_t* sA = st;
+        const bf16_t* sB = st + TBM * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = wm * 64 + i * 16 + fr;
+            xf[i] = as_bf16x8(ld16(sA + r * 64 + (((ks * 4 + g) ^ (r & 7)) << 3)));
+        }
+#pragma unroll
+        for (int i = 0; i < NTF; ++i) {
+            const int r = wn * WN_COLS + i * 16 + fr;
+            wf[i] = as_bf16x8(ld16(sB + r * 64 + (((ks * 4 + g) ^ (r & 7)) << 3)));
+        }
+    };
+    auto mfmas = [&](const bf16x8* xf, const bf16x8* wf) {
+#if (AP_ABL & 4)
+        {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, xf[t])));
+#pragma unroll
+            for (int t = 0; t < NTF; ++t) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, wf[t])));
+            return;
+        }
+#endif
+#pragma unroll
+        for (int nt = 0; nt < NTF; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+    };
+#ifdef AP_STAMP
+    unsigned long long t_start = 0, r_start = 0;
+    if (ep.stamps) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    constexpr int NRD = 4 + NTF;                     // ds_read_b128 per half step
+    constexpr int NMF = 4 * NTF;                     // MFMAs per half step
+    // prologue: two K steps in flight, first fragments in registers
+    if (total > 0) issue(0);
+    if (total > 1) {
+        issue(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (total > 0) frags(ring, 0, xf0, wf0);
+    int kt = 0, ti = 0;
+    for (int s = 0; s < total; ++s) {
+        const bf16_t* cur = ring + (s & 1) * STAGE;
+        const bf16_t* nxt = ring + ((s + 1) & 1) * STAGE;
+        if (kt == 0) {
+#pragma unroll
+            for (int a = 0; a < NTF; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // first-half fragments (issued one half step ago)
+        // ---- first half: MFMAs on set 0, the reads of set 1 slotted between them (1 read : 2 MFMAs)
+#if !(AP_ABL & 32)
+        frags(cur, 1, xf1, wf1);
+#endif
+        mfmas(xf0, wf0);
+#pragma unroll
+        for (int i = 0; i < NRD; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 2 * NRD, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave is done reading stage `cur`
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // and its pieces of step s+1 have landed
+        __builtin_amdgcn_s_barrier();                                // true for every wave: `cur` is free, `nxt` is complete
+        // ---- second half: MFMAs on set 1 with the DMA of step s+2 and the first-half reads of step s+1 between them.
+        // Past the end the DMA fetches (row-clamped, in-bounds) data nobody reads and the reads are unused: no branches here.
+        if (q_k == 0) set_tile_src(q_tile);
+        {
+            const bf16_t* sA = nxt;
+            const bf16_t* sB = nxt + TBM * 64;
+            const int dst = (s & 1) * STAGE;
+#pragma unroll
+            for (int j = 0; j < NMF; ++j) {
+#if (AP_ABL & 4)
+                if (j < 4) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, xf1[j]))); else if (j < NRD) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, wf1[j - 4])));
+#else
+                acc[j >> 2][j & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[j >> 2], xf1[j & 3], acc[j >> 2][j & 3], 0, 0, 0);
+#endif
+#if !(AP_ABL & 32)
+                if (j < 4) {
+                    const int r = wm * 64 + j * 16 + fr;
+                    xf0[j] = as_bf16x8(ld16(sA + r * 64 + ((g ^ (r & 7)) << 3)));
+                } else if (j < NRD) {
+                    const int r = wn * WN_COLS + (j - 4) * 16 + fr;
+                    wf0[j - 4] = as_bf16x8(ld16(sB + r * 64 + ((g ^ (r & 7)) << 3)));
+                }
+#endif
+#if !(AP_ABL & 16)
+                if ((j & 1) && (j >> 1) < NI) {
+                    const int i = j >> 1;
+                    const int r0 = (wave + 8 * i) * 8;
+                    const bf16_t* base = (r0 < TBM) ? A : B;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + soff[i] + q_k * 64),
+                                                     (__attribute__((address_space(3))) void*)(ring + dst + r0 * 64), 16, 0, 0);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (++q_k == nk) { q_k = 0; ++q_tile; }
+        if (++kt < nk) continue;
+        kt = 0;
+        // ------------------------------------------------------------ epilogue of tile `ti` (wave-private)
+        const int tile = xcd_remap(blockIdx.x + ti * G, ntiles);
+        ++ti;
+        const int m0 = (tile / tiles_n) * TBM + wm * 64, n0 = (tile % tiles_n) * TBN + wn * WN_COLS;
+        if (ep.dbg & 1) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int a = 0; a < NTF; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+            if (sacc == 12345.678f) C[0] = 1;
+            continue;
+        }
+        const bool vec_ok = ((ldc & 7) == 0) && (ep.residual == nullptr || (ep.ldr & 7) == 0);
+        constexpr int CPR = WN_COLS / 8;              // 8-column chunks per strip row
+        constexpr int ITEMS = 16 * CPR / 64;          // chunks per lane per 16-row strip
+        static_assert((16 * CPR) % 64 == 0, "strip chunks split evenly over the wave");
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < NTF; ++nt)
+                *reinterpret_cast<f32x4*>(strip + fr * WN_COLS + (((nt * 4 + g) ^ (fr & 7)) << 2)) = acc[nt][mt];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private strip: no barrier needed
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int id = lane + 64 * it;
+                const int r = id / CPR, j = id - r * CPR;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + r * WN_COLS + (((2 * j) ^ (r & 7)) << 2));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + r * WN_COLS + (((2 * j + 1) ^ (r & 7)) << 2));
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const int m = m0 + mt * 16 + r, n = n0 + 8 * j;
+                if (m < M && n < N) epi_chunk(v, m, n, N, ldc, vec_ok, ep, C);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // strip reads done before the next strip overwrites it
+        }
+    }
+#ifdef AP_STAMP
+    if (ep.stamps && blockIdx.x == 0 && tid == 0) {
+        ep.stamps[0] = __builtin_amdgcn_s_memtime() - t_start;
+        ep.stamps[1] = __builtin_amdgcn_s_memrealtime() - r_start;
+        ep.stamps[2] = total;
+    }
+#endif
+}
+
 // ------------------------------------------------------------------------------------ wgrad
 #define TM 64          // tokens per step (MFMA reduction)
 __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
@@ -395,15 +669,21 @@ __device__ __forceinline__ bf16x8 tr_frag_at(const bf16_t* tile, int base, int k
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ void __launch_bounds__(256)
-k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
-          int M, int N1, int N2, int steps_per_split, float* __restrict__ colsum, int t1, int t2, int nblocks) {
-    __shared__ __attribute__((aligned(16))) bf16_t sA[TM * 128];
-    __shared__ __attribute__((aligned(16))) bf16_t sB[TM * 128];
+// one weight-gradient problem of a (possibly grouped) launch
+struct TnArgs {
+    const bf16_t* A; const bf16_t* B; float* C; float* colsum;
+    int lda, ldb, ldc, M, N1, N2, steps_per_split, t1, t2, nblocks, start;
+};
+#define TN_MAX_GROUP 8
+struct TnGroup { TnArgs p[TN_MAX_GROUP]; int count; };
+
+__device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                        int M, int N1, int N2, int steps_per_split, float* __restrict__ colsum, int t1, int t2, int nblocks, int block,
+                                        bf16_t* sA, bf16_t* sB) {
     // XCD-aware decode: workgroups that share an XCD (and its L2) get consecutive ids, i.e. all output
     // tiles of the SAME token split, so each token range is fetched from HBM by one L2 only
     // (before: 347 MB of beyond-L2 traffic for 77 MB of operands on the qkv shape)
-    const int id = xcd_remap(blockIdx.x, nblocks);
+    const int id = xcd_remap(block, nblocks);
     const int bz = id / (t1 * t2), tl = id - bz * (t1 * t2);
     const int by = tl / t1, bx = tl - by * t1;
     const int n0 = bx * 128, k0 = by * 128;
@@ -495,6 +775,17 @@ k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
                 if (n < N1) atomicAdd(colsum + n, csum[nt][r]);
             }
     }
+#if (AP_ABL & 64)
+    {   // ablation: no atomics (keep the accumulators live)
+        float sacc = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) sacc += acc[nt][kt][0] + acc[nt][kt][1] + acc[nt][kt][2] + acc[nt][kt][3];
+        if (sacc == 12345.678f) C[0] = 1.f;
+        return;
+    }
+#endif
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -507,6 +798,30 @@ k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
                 if (n < N1) atomicAdd(C + (int64_t)n * ldc + kk, acc[nt][kt][r]);
             }
         }
+}
+
+__global__ void __launch_bounds__(256)
+k_gemm_tn(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+          int M, int N1, int N2, int steps_per_split, float* __restrict__ colsum, int t1, int t2, int nblocks) {
+    __shared__ __attribute__((aligned(16))) bf16_t sA[TM * 128];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[TM * 128];
+    tn_tile(A, lda, B, ldb, C, ldc, M, N1, N2, steps_per_split, colsum, t1, t2, nblocks, blockIdx.x, sA, sB);
+}
+
+// Several weight gradients in ONE launch (all Linear layers of a block): the workgroups of the launch are shared
+// between the problems, so each problem is split over fewer token ranges -> longer reduction loops and
+// (#problems)x fewer fp32 atomics than one launch per problem (atomics were 12-17 us of a 34-53 us launch).
+__global__ void __launch_bounds__(256)
+k_gemm_tn_grouped(TnGroup grp) {
+    __shared__ __attribute__((aligned(16))) bf16_t sA[TM * 128];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[TM * 128];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < TN_MAX_GROUP; ++i)
+        if (i < grp.count && (int)blockIdx.x >= grp.p[i].start) pi = i;
+    const TnArgs& a = grp.p[pi];
+    tn_tile(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N1, a.N2, a.steps_per_split, a.colsum, a.t1, a.t2, a.nblocks,
+            (int)blockIdx.x - a.start, sA, sB);
 }
 
 // --------------------------------------------------------------------- wgrad, LDS-DMA ring
@@ -629,7 +944,7 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     if (!A || !B || !C) return AP_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0) return AP_ERR_SHAPE;
     if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N) return AP_ERR_SHAPE;
-    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0};
+    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr};
     { const char* e = getenv("AP_GEMM_DBG"); if (e) ep.dbg = atoi(e); }
     if (epi) {
         ep.bias = epi->bias; ep.gelu = epi->gelu; ep.preact = epi->preact_out; ep.dgelu_of = epi->dgelu_of;
@@ -665,6 +980,51 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         else hipLaunchKernelGGL((k_gemm_nt_ring<128, 2, 4>), dim3(grid), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
         return ap_check_launch();
     }
+    // persistent 256-row-tile kernel: AP_GEMM_NT_P=0 never, 1 always (when eligible), 4/6 always with that NTF; default =
+    // where it measured faster on the VOLO-D1 list (tools/bench_gemm.py): long reductions (K >= 512) into narrow outputs
+    // (input-gradient and fc2 GEMMs), whose epilogue is a small part of the tile
+    static int use_p = -1;
+    if (use_p < 0) { const char* e = getenv("AP_GEMM_NT_P"); use_p = e ? atoi(e) : -2; }
+    const bool p_ok = (K & 63) == 0 && M >= 256 && (int64_t)M * lda < (1ll << 32) && (int64_t)N * ldb < (1ll << 32);
+    const bool p_auto = K >= 512 && N >= 256 && N <= 512 && N % 64 == 0 && M >= 8192 && !ep.gelu && !ep.dgelu_of;
+    if (p_ok && (use_p > 0 || (use_p == -2 && p_auto))) {
+        static int n_cu = 0;
+        if (n_cu == 0) { int dev = 0; hipGetDevice(&dev); hipDeviceProp_t pr; n_cu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+        const int ntf = (use_p == 4 || use_p == 6) ? use_p : ((N % 192 == 0 || N > 768) && (N % 128 != 0 || N % 192 == 0) ? 6 : 4);
+        const int tbn = 32 * ntf;
+        const int tm = (M + 255) / 256, tn = (N + tbn - 1) / tbn, nt = tm * tn;
+        const int grid = nt < n_cu ? nt : n_cu;
+        const size_t lds = (size_t)2 * (256 + tbn) * 64 * sizeof(bf16_t) + (size_t)8 * 16 * (tbn / 2) * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)k_gemm_nt_p<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_gemm_nt_p<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done = true;
+            (void)hipGetLastError();
+        }
+#ifdef AP_STAMP
+        static unsigned long long* d_stamps = nullptr;
+        if (getenv("AP_GEMM_STAMPS")) {
+            if (!d_stamps) (void)hipMalloc((void**)&d_stamps, 8 * 16 * 8);
+            (void)hipMemset(d_stamps, 0, 8 * 16 * 8);
+            ep.stamps = d_stamps;
+        }
+#endif
+        if (ntf == 6) hipLaunchKernelGGL((k_gemm_nt_p<6>), dim3(grid), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
+        else hipLaunchKernelGGL((k_gemm_nt_p<4>), dim3(grid), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
+#ifdef AP_STAMP
+        if (ep.stamps) {
+            unsigned long long h[128];
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
+            static int printed = 0;
+            if (printed++ == 3)
+                fprintf(stderr, "stamps: memtime %llu ticks, realtime %llu ticks (100 MHz) -> %.1f us, %.0f memtime ticks/us, %llu steps, %.0f ticks/step\n",
+                        h[0], h[1], h[1] / 100.0, h[0] / (h[1] / 100.0), h[2], (double)h[0] / (double)h[2]);
+        }
+#endif
+        return ap_check_launch();
+    }
     // tile selection (measured on the VOLO-D1 shape list, tools/bench_gemm.py): AP_GEMM_NT_TILE forces a variant
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("AP_GEMM_NT_TILE"); forced = e ? atoi(e) : 0; }
@@ -676,10 +1036,16 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         else if (N <= 256 || ((N % 128 != 0) && (N % 64 == 0))) variant = 2;     // 128x64
         else variant = 1;                                                        // 128x128
     }
+    // epilogue flavour: the LDS-staged one (fully coalesced 16-B rows) wins on 128x128 / 64x64 tiles, the direct one
+    // (64-B row segments, no LDS round trip) on the 128x64 tiles of the N = 576 shapes; AP_GEMM_LDS_EPI=0/1 forces one
+    static int lds_epi_env = -2;
+    if (lds_epi_env == -2) { const char* e = getenv("AP_GEMM_LDS_EPI"); lds_epi_env = e ? (e[0] == '1') : -1; }
+    const int lds_epi = lds_epi_env >= 0 ? lds_epi_env : (variant != 2);
 #define NT_LAUNCH(TMv, TNv, WMv, WNv)                                                                        \
     {                                                                                                          \
         const int tm_ = (M + TMv - 1) / TMv, tn_ = (N + TNv - 1) / TNv, nt_ = tm_ * tn_;                       \
-        hipLaunchKernelGGL((k_gemm_nt<TMv, TNv, WMv, WNv>), dim3(nt_), dim3(WMv * WNv * 64), 0, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn_, nt_, ep); \
+        if (lds_epi) hipLaunchKernelGGL((k_gemm_nt<TMv, TNv, WMv, WNv, false>), dim3(nt_), dim3(WMv * WNv * 64), 0, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn_, nt_, ep); \
+        else hipLaunchKernelGGL((k_gemm_nt<TMv, TNv, WMv, WNv, true>), dim3(nt_), dim3(WMv * WNv * 64), 0, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn_, nt_, ep); \
     }
     switch (variant) {
         case 2: NT_LAUNCH(128, 64, 2, 2) break;
@@ -687,6 +1053,9 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         case 4: NT_LAUNCH(64, 64, 2, 2) break;
         case 5: NT_LAUNCH(256, 128, 4, 2) break;
         case 6: NT_LAUNCH(128, 128, 2, 4) break;
+        case 7: NT_LAUNCH(256, 128, 2, 2) break;
+        case 8: NT_LAUNCH(128, 256, 2, 2) break;
+        case 9: NT_LAUNCH(256, 256, 2, 4) break;
         default: NT_LAUNCH(128, 128, 2, 2) break;
     }
 #undef NT_LAUNCH
@@ -734,6 +1103,43 @@ int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* 
         return ap_check_launch();
     }
     return AP_OK;
+}
+
+int ap_gemm_tn_acc_grouped(const ap_tn_problem* problems, int count, ap_stream_t stream) {
+    if (!problems) return AP_ERR_NULL;
+    if (count <= 0 || count > AP_TN_MAX_GROUP) return AP_ERR_SHAPE;
+    static int target_blocks = 0;
+    if (target_blocks == 0) { const char* e = getenv("AP_GEMM_TN_GROUP_BLOCKS"); target_blocks = e ? atoi(e) : 448; }
+    int64_t work = 0;                                   // (output tiles) x (64-token steps) over the whole group
+    for (int i = 0; i < count; ++i) {
+        const ap_tn_problem& q = problems[i];
+        if (!q.A || !q.B || !q.C) return AP_ERR_NULL;
+        if (q.M <= 0 || q.N1 <= 0 || q.N2 <= 0) return AP_ERR_SHAPE;
+        if ((q.lda & 7) || (q.ldb & 7) || q.lda < q.N1 || q.ldb < q.N2 || q.ldc < q.N2) return AP_ERR_SHAPE;
+        work += (int64_t)((q.N1 + 127) / 128) * ((q.N2 + 127) / 128) * ((q.M + TM - 1) / TM);
+    }
+    int sps_target = (int)((work + target_blocks - 1) / target_blocks);      // steps every workgroup should get
+    if (sps_target < 8) sps_target = 8;
+    TnGroup grp;
+    grp.count = count;
+    int start = 0;
+    for (int i = 0; i < count; ++i) {
+        const ap_tn_problem& q = problems[i];
+        TnArgs& a = grp.p[i];
+        const int t1 = (q.N1 + 127) / 128, t2 = (q.N2 + 127) / 128, steps = (q.M + TM - 1) / TM;
+        int splits = (steps + sps_target - 1) / sps_target;
+        if (splits < 1) splits = 1;
+        const int sps = (steps + splits - 1) / splits;
+        splits = (steps + sps - 1) / sps;
+        a.A = reinterpret_cast<const bf16_t*>(q.A); a.B = reinterpret_cast<const bf16_t*>(q.B); a.C = q.C; a.colsum = q.colsum_A;
+        a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.M = q.M; a.N1 = q.N1; a.N2 = q.N2;
+        a.steps_per_split = sps; a.t1 = t1; a.t2 = t2; a.nblocks = t1 * t2 * splits; a.start = start;
+        start += a.nblocks;
+    }
+    for (int i = count; i < TN_MAX_GROUP; ++i) { grp.p[i] = grp.p[0]; grp.p[i].start = 0x7fffffff; grp.p[i].nblocks = 0; }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_gemm_tn_grouped, dim3(start), dim3(256), 0, (hipStream_t)stream, grp);
+    return ap_check_launch();
 }
 
 }  // extern "C"

@@ -144,18 +144,50 @@ def join_wgrad_stream():
             torch.cuda.current_stream().wait_stream(st)
 
 
-def _linear_bwd(g, x_in, w, dw, db, n=None, dgelu_of=None, need_dx=True):
-    """shared backward of y = x W^T + b given g = dL/dy (bf16 [M, ld]); accumulates dw/db."""
-    n = w.shape[0] if n is None else n
+# Weight gradients of one block are collected and issued as ONE grouped launch (ops.gemm_tn_acc_grouped): the
+# launch's workgroups are shared by the block's 4-5 Linear layers, so every layer is split over fewer token
+# ranges -> longer reduction loops and several times fewer fp32 atomics than one launch per layer.
+_wgrad_batch = None
+
+
+class wgrad_batch:
+    """with wgrad_batch(): ... _linear_bwd calls ... ; the collected weight gradients launch on exit"""
+
+    def __enter__(self):
+        global _wgrad_batch
+        self.prev = _wgrad_batch
+        _wgrad_batch = []
+        return self
+
+    def __exit__(self, *exc):
+        global _wgrad_batch
+        pending, _wgrad_batch = _wgrad_batch, self.prev
+        if pending and exc[0] is None:
+            _launch_wgrads(pending)
+        return False
+
+
+def _launch_wgrads(problems):
     if async_wgrad:
         side = wgrad_stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            ops.gemm_tn_acc(g, x_in, _g2(dw), n1=n, n2=_g2(dw).shape[1], colsum=db)
-        g.record_stream(side)
-        x_in.record_stream(side)
+            ops.gemm_tn_acc_grouped(problems)
+        for a, b, _, _, _, _ in problems:
+            a.record_stream(side)
+            b.record_stream(side)
     else:
-        ops.gemm_tn_acc(g, x_in, _g2(dw), n1=n, n2=_g2(dw).shape[1], colsum=db)
+        ops.gemm_tn_acc_grouped(problems)
+
+
+def _linear_bwd(g, x_in, w, dw, db, n=None, dgelu_of=None, need_dx=True):
+    """shared backward of y = x W^T + b given g = dL/dy (bf16 [M, ld]); accumulates dw/db."""
+    n = w.shape[0] if n is None else n
+    prob = (g, x_in, _g2(dw), n, _g2(dw).shape[1], db)
+    if _wgrad_batch is not None:
+        _wgrad_batch.append(prob)
+    else:
+        _launch_wgrads([prob])
     if not need_dx:
         return None
     wt = bank.get_t(w)                       # [K, ld(N)]
@@ -196,17 +228,18 @@ class TransformerBlockFn(torch.autograd.Function):
         bufs, sunk = _param_grad_buffers(params)
         (dn1w, dn1b, dqkv_w, dqkv_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = bufs
         dy2 = dy.reshape(x2.shape).contiguous()
-        # MLP branch
-        g2 = ops.row_scale(dy2, rs2, N) if rs2 is not None else dy2
-        dh = _linear_bwd(g2, a, fc2_w, dfc2_w, dfc2_b, dgelu_of=h)
-        dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b)
-        dx1 = ops.layernorm_bwd(dxn2, x1, n2w, m2, r2, dy2, dn2w, dn2b)
-        # attention branch
-        g1 = ops.row_scale(dx1, rs1, N) if rs1 is not None else dx1
-        do = _linear_bwd(g1, o, proj_w, dproj_w, dproj_b)
-        dqkv = ops.mhsa_bwd(qkv, o, do, lse, B, N, heads, scale)
-        dxn1 = _linear_bwd(dqkv, xn1, qkv_w, dqkv_w, dqkv_b)
-        dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b)
+        with wgrad_batch():                  # the four weight gradients launch together (side stream) on exit
+            # MLP branch
+            g2 = ops.row_scale(dy2, rs2, N) if rs2 is not None else dy2
+            dh = _linear_bwd(g2, a, fc2_w, dfc2_w, dfc2_b, dgelu_of=h)
+            dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b)
+            dx1 = ops.layernorm_bwd(dxn2, x1, n2w, m2, r2, dy2, dn2w, dn2b)
+            # attention branch
+            g1 = ops.row_scale(dx1, rs1, N) if rs1 is not None else dx1
+            do = _linear_bwd(g1, o, proj_w, dproj_w, dproj_b)
+            dqkv = ops.mhsa_bwd(qkv, o, do, lse, B, N, heads, scale)
+            dxn1 = _linear_bwd(dqkv, xn1, qkv_w, dqkv_w, dqkv_b)
+            dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b)
         return (dx.view(dy.shape), None, None, *_finish_param_grads(params, bufs, sunk), None, None, None, None)
 
 
@@ -248,15 +281,16 @@ class OutlookerBlockFn(torch.autograd.Function):
         bufs, sunk = _param_grad_buffers(params)
         (dn1w, dn1b, dv_w, dv_b, dattn_w, dattn_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = bufs
         dy2 = dy.reshape(T, C).contiguous()
-        dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, dgelu_of=h)
-        dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b)
-        dx1 = ops.layernorm_bwd(dxn2, x1, n2w, m2, r2, dy2, dn2w, dn2b)
-        dyo = _linear_bwd(dx1, yo.view(T, C), proj_w, dproj_w, dproj_b)
-        dv, dlogits = ops.outlook_bwd(v.view(B, H, W, C), logits, dyo.view(B, H, W, C), heads, scale)
-        dpooled = _linear_bwd(dlogits, pooled2, attn_w, dattn_w, dattn_b, n=attn_w.shape[0])
-        dxn1 = _linear_bwd(dv.view(T, C), xn1, v_w, dv_w, dv_b)
-        ops.avgpool2_bwd_acc(dpooled.view(B, (H + 1) // 2, (W + 1) // 2, C), dxn1.view(B, H, W, C))
-        dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b)
+        with wgrad_batch():                  # the five weight gradients launch together (side stream) on exit
+            dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, dgelu_of=h)
+            dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b)
+            dx1 = ops.layernorm_bwd(dxn2, x1, n2w, m2, r2, dy2, dn2w, dn2b)
+            dyo = _linear_bwd(dx1, yo.view(T, C), proj_w, dproj_w, dproj_b)
+            dv, dlogits = ops.outlook_bwd(v.view(B, H, W, C), logits, dyo.view(B, H, W, C), heads, scale)
+            dpooled = _linear_bwd(dlogits, pooled2, attn_w, dattn_w, dattn_b, n=attn_w.shape[0])
+            dxn1 = _linear_bwd(dv.view(T, C), xn1, v_w, dv_w, dv_b)
+            ops.avgpool2_bwd_acc(dpooled.view(B, (H + 1) // 2, (W + 1) // 2, C), dxn1.view(B, H, W, C))
+            dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b)
         return (dx.view(dy.shape), *_finish_param_grads(params, bufs, sunk), None, None)
 
 

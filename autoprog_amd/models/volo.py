@@ -53,6 +53,7 @@ class DropPathRng:
     def __init__(self):
         self.queue = []
         self._pool = []
+        self._keep_cache = {}          # (keeps, device) -> device tensor: no host->device copy per step (HIP-graph capturable)
 
     def prefetch(self, keeps, batch, device):
         """draw the factors of a whole forward pass (one entry of `keeps` per DropPath site, in call order)
@@ -60,7 +61,12 @@ class DropPathRng:
         if self.queue or not keeps:
             self._pool = []
             return
-        k = torch.tensor(keeps, dtype=torch.float32, device=device).unsqueeze(1)
+        key = (tuple(keeps), str(device))
+        k = self._keep_cache.get(key)
+        if k is None:
+            if len(self._keep_cache) > 64:
+                self._keep_cache.clear()
+            k = self._keep_cache[key] = torch.tensor(keeps, dtype=torch.float32, device=device).unsqueeze(1)
         f = (torch.rand(len(keeps), batch, device=device) + k).floor_() / k
         self._pool = [(keeps[i], f[i]) for i in range(len(keeps))]
 

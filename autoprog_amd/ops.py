@@ -121,6 +121,22 @@ def gemm_tn_acc(a, b, c, n1=None, n2=None, colsum=None):
     return c
 
 
+def gemm_tn_acc_grouped(problems):
+    """problems: list of (a, b, c, n1, n2, colsum) as for gemm_tn_acc; ONE launch for the whole list (chunks of 8)."""
+    from ._lib import TnProblem, TN_MAX_GROUP
+    for i0 in range(0, len(problems), TN_MAX_GROUP):
+        chunk = problems[i0:i0 + TN_MAX_GROUP]
+        arr = (TnProblem * len(chunk))()
+        for q, (a, b, c, n1, n2, colsum) in zip(arr, chunk):
+            _req(a, BF16, "a"); _req(b, BF16, "b"); _req(c, torch.float32, "c")
+            if a.shape[0] != b.shape[0]:
+                raise ValueError("gemm_tn_acc_grouped: token counts differ")
+            q.A, q.lda, q.B, q.ldb, q.C, q.ldc = a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1], c.data_ptr(), c.shape[1]
+            q.M, q.N1, q.N2 = a.shape[0], (c.shape[0] if n1 is None else n1), (c.shape[1] if n2 is None else n2)
+            q.colsum_A = colsum.data_ptr() if colsum is not None else None
+        check(lib.ap_gemm_tn_acc_grouped(ctypes.cast(arr, ctypes.c_void_p), len(chunk), _stream()), "ap_gemm_tn_acc_grouped")
+
+
 def colsum_acc(a, out, n=None):
     _req(a, BF16, "a"); _req(out, torch.float32, "out")
     n = out.numel() if n is None else n

@@ -77,6 +77,18 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
  * optional fused bias gradient: colsum_A[n] += sum_m A[m,n] (NULL to skip) */
 int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* C, int ldc,
                    int M, int N1, int N2, float* colsum_A, ap_stream_t stream);
+/* the same for up to AP_TN_MAX_GROUP problems in ONE launch (all Linear layers of a block: the reference's autograd
+ * issues one addmm per layer, models/volo.py:67-71,156-158,180-182): the launch's workgroups are shared between the
+ * problems, so each is split over fewer token ranges and adds fewer fp32 partial tiles atomically */
+#define AP_TN_MAX_GROUP 8
+typedef struct ap_tn_problem {
+    const ap_bf16* A; int lda;      /* [M,N1] */
+    const ap_bf16* B; int ldb;      /* [M,N2] */
+    float* C; int ldc;              /* [N1,N2] += A^T . B */
+    int M, N1, N2;
+    float* colsum_A;                /* [N1] += column sums of A, or NULL */
+} ap_tn_problem;
+int ap_gemm_tn_acc_grouped(const ap_tn_problem* problems, int count, ap_stream_t stream);
 /* bias gradient: out[n] += sum_m A[m,n] */
 int ap_colsum_acc(const ap_bf16* A, int lda, float* out, int M, int N, ap_stream_t stream);
 

@@ -137,6 +137,30 @@ def test_gemm_tn_acc(ops, M, N1, N2):
     assert rel(c2, ref) < TOL_F32
 
 
+def test_gemm_tn_acc_grouped(ops):
+    """several weight gradients in one launch == the same problems one by one (shapes of a VOLO block, ragged sizes,
+    different token counts, with and without the fused bias gradient; more problems than one launch holds)"""
+    shapes = [(3136, 1152, 384, True), (3136, 384, 384, True), (3136, 1152, 384, False), (3136, 384, 1152, True),
+              (1000, 486, 192, True), (77, 32, 96, False), (4000, 192, 192, True), (130, 1000, 384, True), (500, 16, 64, True),
+              (2048, 576, 192, False)]
+    probs, refs = [], []
+    for i, (M, N1, N2, with_cs) in enumerate(shapes):
+        l1, l2 = ops.round_up(N1, 8), ops.round_up(N2, 8)
+        a, b = rnd(M, l1, seed=10 + i), rnd(M, l2, seed=40 + i)
+        c0 = torch.randn(N1, N2, generator=torch.Generator().manual_seed(70 + i))
+        cs0 = torch.randn(N1, generator=torch.Generator().manual_seed(90 + i))
+        c, cs = dev(c0), (dev(cs0) if with_cs else None)
+        probs.append((dev(a), dev(b), c, N1, N2, cs))
+        refs.append((c0.double() + a[:, :N1].double().t() @ b[:, :N2].double(), cs0.double() + a[:, :N1].double().sum(0)))
+    ops.gemm_tn_acc_grouped(probs)
+    for (a, b, c, n1, n2, cs), (rc, rcs) in zip(probs, refs):
+        assert rel(c, rc) < TOL_F32
+        if cs is not None:
+            assert rel(cs, rcs) < TOL_F32
+    with pytest.raises(Exception):
+        ops.gemm_tn_acc_grouped([(probs[0][0], probs[1][1][:100], probs[0][2], None, None, None)])      # token counts differ
+
+
 def test_colsum(ops):
     for M, N in [(1000, 192), (77, 486), (5000, 1000), (10, 16)]:
         a = rnd(M, ops.round_up(N, 8), seed=M)

@@ -76,6 +76,20 @@ def main():
             tot_t += us; tot_f += fl
             print("%-16s %7d %5d %5d %9.1f %9.1f %9.1f" % (name, M, N1, N2, us, fl / us / 1e6, 2.0 * M * (N1 + N2) / us / 1e3))
         print("TN total %.1f us, %.1f TFLOP/s" % (tot_t, tot_f / tot_t / 1e6))
+        # grouped launches: the weight gradients of one block in ONE launch (functional.wgrad_batch)
+        groups = {"transformer block (qkv, proj, fc1, fc2)": [(T2, 1152, 384), (T2, 384, 384), (T2, 1152, 384), (T2, 384, 1152)],
+                  "outlooker block (v, attn, proj, fc1, fc2)": [(T1, 192, 192), (P, 486, 192), (T1, 192, 192), (T1, 576, 192), (T1, 192, 576)]}
+        for gname, shapes in groups.items():
+            probs = []
+            fl = 0.0
+            for M, N1, N2 in shapes:
+                a = torch.randn(M, ops.round_up(N1, 8), device=dev).bfloat16()
+                b = torch.randn(M, ops.round_up(N2, 8), device=dev).bfloat16()
+                probs.append((a, b, torch.zeros(N1, N2, device=dev), N1, N2, torch.zeros(N1, device=dev)))
+                fl += 2.0 * M * N1 * N2
+            us_g = timeit(lambda: ops.gemm_tn_acc_grouped(probs))
+            us_s = timeit(lambda: [ops.gemm_tn_acc(a, b, c, n1=n1, n2=n2, colsum=cs) for a, b, c, n1, n2, cs in probs])
+            print("%-44s grouped %7.1f us (%.0f TFLOP/s)   one by one %7.1f us" % (gname, us_g, fl / us_g / 1e6, us_s))
 
 
 if __name__ == "__main__":
