@@ -980,11 +980,12 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         else hipLaunchKernelGGL((k_gemm_nt_ring<128, 2, 4>), dim3(grid), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
         return ap_check_launch();
     }
-    // persistent 256-row-tile kernel: AP_GEMM_NT_P=0 never, 1 always (when eligible), 4/6 always with that NTF; default =
-    // where it measured faster on the VOLO-D1 list (tools/bench_gemm.py): long reductions (K >= 512) into narrow outputs
-    // (input-gradient and fc2 GEMMs), whose epilogue is a small part of the tile
-    static int use_p = -1;
-    if (use_p < 0) { const char* e = getenv("AP_GEMM_NT_P"); use_p = e ? atoi(e) : -2; }
+    // persistent 256-row-tile kernel (k_gemm_nt_p): AP_GEMM_NT_P=1 always (when eligible), 4/6 always with that NTF, -2 where it
+    // measured faster STANDALONE on the VOLO-D1 list (long reductions into narrow outputs: 30 vs 37 us on the dfc1 / dqkv
+    // shapes); default 0 = never: inside the training step the same launches measured 39.5 us (a 256-workgroup x 160 KB launch
+    // cannot start on a CU until the previous kernel has drained from it) and the step was 0.1 ms slower with it.
+    static int use_p = -100;
+    if (use_p == -100) { const char* e = getenv("AP_GEMM_NT_P"); use_p = e ? atoi(e) : 0; }
     const bool p_ok = (K & 63) == 0 && M >= 256 && (int64_t)M * lda < (1ll << 32) && (int64_t)N * ldb < (1ll << 32);
     const bool p_auto = K >= 512 && N >= 256 && N <= 512 && N % 64 == 0 && M >= 8192 && !ep.gelu && !ep.dgelu_of;
     if (p_ok && (use_p > 0 || (use_p == -2 && p_auto))) {
@@ -1108,18 +1109,39 @@ int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* 
 int ap_gemm_tn_acc_grouped(const ap_tn_problem* problems, int count, ap_stream_t stream) {
     if (!problems) return AP_ERR_NULL;
     if (count <= 0 || count > AP_TN_MAX_GROUP) return AP_ERR_SHAPE;
-    static int target_blocks = 0;
-    if (target_blocks == 0) { const char* e = getenv("AP_GEMM_TN_GROUP_BLOCKS"); target_blocks = e ? atoi(e) : 448; }
-    int64_t work = 0;                                   // (output tiles) x (64-token steps) over the whole group
+    // Two 256-thread workgroups are resident per CU: the launch should fill that single wave of workgroups as fully as
+    // possible but never spill into a second one (measured on the D1 blocks: 450 workgroups 125 us, 540 -> 175 us).
+    static int capacity = 0;
+    if (capacity == 0) {
+        const char* e = getenv("AP_GEMM_TN_GROUP_BLOCKS");
+        if (e) capacity = atoi(e);
+        else { int dev = 0; hipGetDevice(&dev); hipDeviceProp_t pr; capacity = 2 * ((hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256); }
+    }
+    int max_steps = 1;
     for (int i = 0; i < count; ++i) {
         const ap_tn_problem& q = problems[i];
         if (!q.A || !q.B || !q.C) return AP_ERR_NULL;
         if (q.M <= 0 || q.N1 <= 0 || q.N2 <= 0) return AP_ERR_SHAPE;
         if ((q.lda & 7) || (q.ldb & 7) || q.lda < q.N1 || q.ldb < q.N2 || q.ldc < q.N2) return AP_ERR_SHAPE;
-        work += (int64_t)((q.N1 + 127) / 128) * ((q.N2 + 127) / 128) * ((q.M + TM - 1) / TM);
+        const int steps = (q.M + TM - 1) / TM;
+        if (steps > max_steps) max_steps = steps;
     }
-    int sps_target = (int)((work + target_blocks - 1) / target_blocks);      // steps every workgroup should get
-    if (sps_target < 8) sps_target = 8;
+    auto blocks_at = [&](int sps) {
+        int64_t nb = 0;
+        for (int i = 0; i < count; ++i) {
+            const ap_tn_problem& q = problems[i];
+            const int steps = (q.M + TM - 1) / TM;
+            nb += (int64_t)((q.N1 + 127) / 128) * ((q.N2 + 127) / 128) * ((steps + sps - 1) / sps);
+        }
+        return nb;
+    };
+    // smallest steps-per-workgroup (>= 8) whose block count fits the resident capacity (binary search: blocks_at is monotone)
+    int lo = 8, hi = max_steps > 8 ? max_steps : 8;
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if (blocks_at(mid) <= capacity) hi = mid; else lo = mid + 1;
+    }
+    const int sps_target = lo;
     TnGroup grp;
     grp.count = count;
     int start = 0;

@@ -9,6 +9,8 @@ fp32 parameter gradients.
 """
 import math
 
+import os
+
 import torch
 
 from . import ops
@@ -120,10 +122,12 @@ def _g2(w):
     return w.view(w.shape[0], -1)
 
 
-# Weight gradients do not feed the backward chain, so they are issued on a side stream and overlap the
-# input-gradient GEMMs / LayerNorm / attention kernels of the main stream (every one of these kernels is
-# latency- rather than throughput-bound, so co-scheduling two of them fills idle CUs).
-async_wgrad = True
+# Weight gradients do not feed the backward chain, so they CAN be issued on a side stream and overlap the
+# input-gradient GEMMs / LayerNorm / attention kernels of the main stream.  That paid (23.1 -> 22.0 ms/step) while
+# every layer's weight gradient was its own under-filled launch; with one grouped launch per block (wgrad_batch,
+# 450-512 workgroups = every CU twice) the side stream only adds contention: 19.55 ms/step vs 19.22 on one stream
+# (same box, back to back).  Default: one stream; AP_ASYNC_WGRAD=1 switches the side stream on.
+async_wgrad = os.environ.get("AP_ASYNC_WGRAD", "0") == "1"
 _side_streams = {}
 
 
