@@ -6,12 +6,12 @@
 // a 2x2 pixel quad (2i..2i+1, 2j..2j+1) receives exactly 9 (window, slot) contributions from the
 // windows (i,j),(i,j+1),(i+1,j),(i+1,j+1).  HBM-bound: V + logits + Y, each touched once.
 //
-// Work decomposition: workgroup = (image, head, strip of quad rows); one lane per quad, 32 fp32
-// accumulators per output pixel; the head's V strip (+halo, zero padded) is staged once in LDS as
-// [rows][2w+1][32] bf16 and the strip's softmax matrices as fp32 [window][9][9] (row stride 81 dwords
-// = odd -> conflict-free across lanes).  The same kernel run with TRANSPOSED probabilities on dY
-// yields dV (the fold backward is an unfold of dY and vice versa).
-// dlogits uses one lane per window: dP = <dY[src p], V[src q]>, dA = s*P*(dP - sum_q P*dP).
+// Work decomposition: workgroup = (image, head, strip of window rows); the head's V strip (+halo, zero
+// padded) is staged once in LDS (chunk-major bf16) and the strip's softmax matrices as fp32
+// [window][9][9]; one lane per (output pixel, 8-channel chunk), pixels taken by parity class.  The same
+// kernel run with TRANSPOSED probabilities on dY yields dV (the fold backward is an unfold of dY and vice
+// versa).  dlogits uses one lane per (window, row p): dP = <dY[src p], V[src q]>,
+// dA = s*P*(dP - sum_q P*dP).
 #include "common.h"
 
 #define OHD 32          // head dim handled by these kernels
@@ -54,8 +54,15 @@ __device__ __forceinline__ void stage_probs(float* P, const bf16_t* logits, int 
     }
 }
 
+// chunk stride (in pixels) of the CHUNK-major patch image, padded so the four chunks of a pixel start 16 banks apart
+__device__ __host__ __forceinline__ int pad_npix(int npix) { return npix + ((4 - (npix & 15)) & 15); }
+
+#define OGT 256         // threads per workgroup of the two kernels below
+// One lane per (output pixel, 8-channel chunk): 16x the lanes of the former one-lane-per-quad mapping (which left
+// ~2 waves per SIMD on the whole chip with a 2600-FMA serial loop each).  Pixels are processed by PARITY CLASS
+// (y&1, x&1): a class has a uniform number of contributing windows (1, 2, 2, 4), so a wave never diverges.
 template <bool TP>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(OGT)
 k_outlook_gather(const bf16_t* __restrict__ in, const bf16_t* __restrict__ logits, int ldl, bf16_t* __restrict__ out,
                  int H, int W, int heads, float scale, int SR, int nstrips) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -70,64 +77,59 @@ k_outlook_gather(const bf16_t* __restrict__ in, const bf16_t* __restrict__ logit
     const int pw = 2 * w + 1, ph = 2 * nq + 3;
     const int y0 = 2 * I0 - 1;
     const int nwr = min(nq + 1, h - I0);
+    const int npix = pad_npix((2 * SR + 3) * pw);
     bf16_t* patch = reinterpret_cast<bf16_t*>(smem_raw);
-    float* P = reinterpret_cast<float*>(smem_raw + (((size_t)(2 * SR + 3) * pw * OHD * 2 + 15) & ~(size_t)15));
-    const int npix = (2 * SR + 3) * pw;
-    stage_patch(patch, in + (int64_t)b * H * W * C + head * OHD, H, W, C, y0, ph, pw, npix, 128);
-    stage_probs(P, logits, ldl, ((int64_t)b * h + I0) * w, w, nwr * w, head, scale, 128);
+    float* P = reinterpret_cast<float*>(smem_raw + (size_t)npix * OHD * 2);
+    stage_patch(patch, in + (int64_t)b * H * W * C + head * OHD, H, W, C, y0, ph, pw, npix, OGT);
+    stage_probs(P, logits, ldl, ((int64_t)b * h + I0) * w, w, nwr * w, head, scale, OGT);
     __syncthreads();
-    const int ql = threadIdx.x;
-    if (ql >= nq * w) return;
-    const int qi = ql / w, j = ql - qi * w;
-    const int i = I0 + qi;
 #pragma unroll 1
-    for (int pix = 0; pix < 4; ++pix) {
-        const int dy = pix >> 1, dx = pix & 1;
-        const int y = 2 * i + dy, x = 2 * j + dx;
-        if (y >= H || x >= W) continue;
-        float acc[OHD];
-#pragma unroll
-        for (int k = 0; k < OHD; ++k) acc[k] = 0.f;
-        // (window row, slot row) options for this pixel row; same for columns
+    for (int cls = 0; cls < 4; ++cls) {
+        const int dy = cls >> 1, dx = cls & 1;
+        // pixels (2i+dy, 2j+dx), i in [I0, I0+nq), j in [0, w), inside the image
+        const int ncols = (W - dx + 1) >> 1;
+        const int nrows = min(nq, (H - dy + 1) / 2 - I0);
         const int nro = dy ? 2 : 1, nco = dx ? 2 : 1;
-#pragma unroll 1
-        for (int ro = 0; ro < nro; ++ro) {
-            const int wi = dy ? (ro ? i + 1 : i) : i;
-            const int ar = dy ? (ro ? 0 : 2) : 1;
-            if (wi >= h) continue;
-#pragma unroll 1
-            for (int co = 0; co < nco; ++co) {
-                const int wj = dx ? (co ? j + 1 : j) : j;
-                const int ac = dx ? (co ? 0 : 2) : 1;
-                if (wj >= w) continue;
-                const int a = ar * 3 + ac;
-                const float* Pw = P + ((wi - I0) * w + wj) * OPP;
-                const int pr0 = 2 * wi - 1 - y0, pc0 = 2 * wj;      // patch coords of the window's slot (0,0)
-#pragma unroll 1
-                for (int br = 0; br < 3; ++br) {
+        for (int item = threadIdx.x; item < nrows * ncols * 4; item += OGT) {
+            const int c = item & 3, pq = item >> 2;
+            const int qi = pq / ncols, j = pq - qi * ncols;
+            const int i = I0 + qi;
+            const int y = 2 * i + dy, x = 2 * j + dx;
+            float acc[8];
 #pragma unroll
-                    for (int bc = 0; bc < 3; ++bc) {
-                        const int bs = br * 3 + bc;
-                        const float wgt = TP ? Pw[bs * OKK + a] : Pw[a * OKK + bs];
-                        const bf16_t* px = patch + ((pr0 + br) * pw + pc0 + bc) * 8;
+            for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+            for (int ro = 0; ro < nro; ++ro) {
+                const int wi = dy ? (ro ? i + 1 : i) : i;
+                const int ar = dy ? (ro ? 0 : 2) : 1;
+                if (wi >= h) continue;
+                for (int co = 0; co < nco; ++co) {
+                    const int wj = dx ? (co ? j + 1 : j) : j;
+                    const int ac = dx ? (co ? 0 : 2) : 1;
+                    if (wj >= w) continue;
+                    const int a = ar * 3 + ac;
+                    const float* Pw = P + ((wi - I0) * w + wj) * OPP;
+                    const bf16_t* px0 = patch + (c * npix + (2 * wi - 1 - y0) * pw + 2 * wj) * 8;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
+                    for (int br = 0; br < 3; ++br) {
+#pragma unroll
+                        for (int bc = 0; bc < 3; ++bc) {
+                            const int bs = br * 3 + bc;
+                            const float wgt = TP ? Pw[bs * OKK + a] : Pw[a * OKK + bs];
                             float f[8];
-                            unpack8(ld16(px + c * npix * 8), f);
+                            unpack8(ld16(px0 + (br * pw + bc) * 8), f);
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) acc[c * 8 + k] += wgt * f[k];
+                            for (int k = 0; k < 8; ++k) acc[k] += wgt * f[k];
                         }
                     }
                 }
             }
+            st16(out + (((int64_t)b * H + y) * W + x) * C + head * OHD + c * 8, pack8(acc));
         }
-        bf16_t* op = out + (((int64_t)b * H + y) * W + x) * C + head * OHD;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) st16(op + c * 8, pack8(acc + c * 8));
     }
 }
 
-__global__ void __launch_bounds__(64)
+// dlogits: one lane per (window, row p of its 9x9 matrix): dP[q] = <dY[src p], V[src q]>, dA[p,:] = s*P[p,:]*(dP - <P[p,:], dP>)
+__global__ void __launch_bounds__(OGT)
 k_outlook_dlogits(const bf16_t* __restrict__ v, const bf16_t* __restrict__ dy, const bf16_t* __restrict__ logits, int ldl,
                   bf16_t* __restrict__ dlogits, int H, int W, int heads, float scale, int SRW, int nstrips) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -141,57 +143,55 @@ k_outlook_dlogits(const bf16_t* __restrict__ v, const bf16_t* __restrict__ dy, c
     const int nwr = min(SRW, h - I0);
     const int pw = 2 * w + 1, ph = 2 * nwr + 1;
     const int y0 = 2 * I0 - 1;
-    const size_t patch_bytes = ((size_t)(2 * SRW + 1) * pw * OHD * 2 + 15) & ~(size_t)15;
+    const int npix = pad_npix((2 * SRW + 1) * pw);
+    const size_t patch_bytes = (size_t)npix * OHD * 2;
     bf16_t* pv = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* pg = reinterpret_cast<bf16_t*>(smem_raw + patch_bytes);
     float* P = reinterpret_cast<float*>(smem_raw + 2 * patch_bytes);
     const int64_t img = (int64_t)b * H * W * C + head * OHD;
-    const int npix = (2 * SRW + 1) * pw;
-    stage_patch(pv, v + img, H, W, C, y0, ph, pw, npix, 64);
-    stage_patch(pg, dy + img, H, W, C, y0, ph, pw, npix, 64);
+    stage_patch(pv, v + img, H, W, C, y0, ph, pw, npix, OGT);
+    stage_patch(pg, dy + img, H, W, C, y0, ph, pw, npix, OGT);
     const int nwin = nwr * w;
     const int64_t win_base = ((int64_t)b * h + I0) * w;
-    stage_probs(P, logits, ldl, win_base, w, nwin, head, scale, 64);
+    stage_probs(P, logits, ldl, win_base, w, nwin, head, scale, OGT);
     __syncthreads();
-    const int wl = threadIdx.x;
-    if (wl < nwin) {
+    for (int item = threadIdx.x; item < nwin * OKK; item += OGT) {
+        const int wl = item / OKK, p = item - wl * OKK;
         const int wi = wl / w, wj = wl - wi * w;
         const int pr0 = 2 * wi, pc0 = 2 * wj;        // patch coords of slot (0,0): y = 2(I0+wi)-1 -> row 2wi
-        float* Pw = P + wl * OPP;
-#pragma unroll 1
-        for (int p = 0; p < OKK; ++p) {
-            float g[OHD];
-            const bf16_t* gp = pg + ((pr0 + p / 3) * pw + pc0 + p % 3) * 8;
+        float* Prow = P + wl * OPP + p * OKK;
+        float g[OHD];
+        const bf16_t* gp = pg + ((pr0 + p / 3) * pw + pc0 + p % 3) * 8;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) unpack8(ld16(gp + c * npix * 8), g + c * 8);
-            float dP[OKK];
-            float dot = 0.f;
+        for (int c = 0; c < 4; ++c) unpack8(ld16(gp + c * npix * 8), g + c * 8);
+        float dP[OKK], pr[OKK];
+        float dot = 0.f;
 #pragma unroll
-            for (int q = 0; q < OKK; ++q) {
-                const bf16_t* vp = pv + ((pr0 + q / 3) * pw + pc0 + q % 3) * 8;
-                float s = 0.f;
+        for (int q = 0; q < OKK; ++q) {
+            const bf16_t* vp = pv + ((pr0 + q / 3) * pw + pc0 + q % 3) * 8;
+            float s = 0.f;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float f[8];
-                    unpack8(ld16(vp + c * npix * 8), f);
+            for (int c = 0; c < 4; ++c) {
+                float f[8];
+                unpack8(ld16(vp + c * npix * 8), f);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) s += g[c * 8 + k] * f[k];
-                }
-                dP[q] = s;
-                dot += Pw[p * OKK + q] * s;
+                for (int k = 0; k < 8; ++k) s += g[c * 8 + k] * f[k];
             }
-#pragma unroll
-            for (int q = 0; q < OKK; ++q) Pw[p * OKK + q] = scale * Pw[p * OKK + q] * (dP[q] - dot);
+            dP[q] = s;
+            pr[q] = Prow[q];
+            dot += pr[q] * s;
         }
+#pragma unroll
+        for (int q = 0; q < OKK; ++q) Prow[q] = scale * pr[q] * (dP[q] - dot);
     }
     __syncthreads();
-    for (int r = threadIdx.x; r < nwin * OPP; r += 64) {
+    for (int r = threadIdx.x; r < nwin * OPP; r += OGT) {
         const int wl2 = r / OPP, e = r - wl2 * OPP;
         dlogits[(win_base + wl2) * ldl + head * OPP + e] = f2bf(P[r]);
     }
     if (head == 0) {                                 // zero the padding columns once per window
         const int padc = ldl - heads * OPP;
-        for (int r = threadIdx.x; r < nwin * padc; r += 64) {
+        for (int r = threadIdx.x; r < nwin * padc; r += OGT) {
             const int wl2 = r / padc, e = r - wl2 * padc;
             dlogits[(win_base + wl2) * ldl + heads * OPP + e] = 0;
         }
@@ -201,18 +201,18 @@ k_outlook_dlogits(const bf16_t* __restrict__ v, const bf16_t* __restrict__ dy, c
 static int gather_launch(bool tp, const bf16_t* in, const bf16_t* logits, int ldl, bf16_t* out, int B, int H, int W, int heads,
                          float scale, hipStream_t s) {
     const int h = (H + 1) / 2, w = (W + 1) / 2;
-    if (w > 128) return AP_ERR_UNSUPPORTED;
-    int SR = 128 / w; if (SR > h) SR = h; if (SR < 1) SR = 1;
     const int pw = 2 * w + 1;
-    // keep >= 2 workgroups per CU resident: shrink the strip until LDS <= 72 KB
-    auto lds_of = [&](int sr) { return (((size_t)(2 * sr + 3) * pw * OHD * 2 + 15) & ~(size_t)15) + (size_t)(sr + 1) * w * OPP * 4; };
-    while (SR > 1 && lds_of(SR) > 72 * 1024) --SR;
+    // strips of SR window rows: a strip re-stages 3 halo pixel rows and one halo window row, so taller strips waste
+    // less; 4 rows keep ~3000 workgroups x 256 lanes in flight at 28x28 / B = 128 and 3 workgroups per CU (LDS)
+    auto lds_of = [&](int sr) { return (size_t)pad_npix((2 * sr + 3) * pw) * OHD * 2 + (size_t)(sr + 1) * w * OPP * 4; };
+    int SR = 4; if (SR > h) SR = h;
+    while (SR > 1 && lds_of(SR) > 52 * 1024) --SR;
     if (lds_of(SR) > 160 * 1024) return AP_ERR_UNSUPPORTED;
     const int nstrips = (h + SR - 1) / SR;
     const dim3 grid((unsigned)(B * nstrips * heads));
     (void)hipGetLastError();
-    if (tp) hipLaunchKernelGGL(k_outlook_gather<true>, grid, dim3(128), lds_of(SR), s, in, logits, ldl, out, H, W, heads, scale, SR, nstrips);
-    else hipLaunchKernelGGL(k_outlook_gather<false>, grid, dim3(128), lds_of(SR), s, in, logits, ldl, out, H, W, heads, scale, SR, nstrips);
+    if (tp) hipLaunchKernelGGL(k_outlook_gather<true>, grid, dim3(OGT), lds_of(SR), s, in, logits, ldl, out, H, W, heads, scale, SR, nstrips);
+    else hipLaunchKernelGGL(k_outlook_gather<false>, grid, dim3(OGT), lds_of(SR), s, in, logits, ldl, out, H, W, heads, scale, SR, nstrips);
     return ap_check_launch();
 }
 
@@ -234,15 +234,14 @@ int ap_outlook_bwd(const ap_bf16* v, const ap_bf16* logits, int ldl, const ap_bf
     int rc = gather_launch(true, dy, logits, ldl, dv, B, H, W, heads, scale, (hipStream_t)stream);
     if (rc != AP_OK) return rc;
     const int h = (H + 1) / 2, w = (W + 1) / 2;
-    if (w > 64) return AP_ERR_UNSUPPORTED;
-    int SRW = 64 / w; if (SRW > h) SRW = h; if (SRW < 1) SRW = 1;
     const int pw = 2 * w + 1;
-    auto lds_of = [&](int sr) { return 2 * (((size_t)(2 * sr + 1) * pw * OHD * 2 + 15) & ~(size_t)15) + (size_t)sr * w * OPP * 4; };
+    auto lds_of = [&](int sr) { return 2 * ((size_t)pad_npix((2 * sr + 1) * pw) * OHD * 2) + (size_t)sr * w * OPP * 4; };
+    int SRW = 4; if (SRW > h) SRW = h;
     while (SRW > 1 && lds_of(SRW) > 52 * 1024) --SRW;
     if (lds_of(SRW) > 160 * 1024) return AP_ERR_UNSUPPORTED;
     const int nstrips = (h + SRW - 1) / SRW;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_outlook_dlogits, dim3((unsigned)(B * nstrips * heads)), dim3(64), lds_of(SRW), (hipStream_t)stream,
+    hipLaunchKernelGGL(k_outlook_dlogits, dim3((unsigned)(B * nstrips * heads)), dim3(OGT), lds_of(SRW), (hipStream_t)stream,
                        v, dy, logits, ldl, dlogits, H, W, heads, scale, SRW, nstrips);
     return ap_check_launch();
 }
