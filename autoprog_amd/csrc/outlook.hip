@@ -13,7 +13,14 @@
 // versa).  dlogits uses one lane per (window, row p): dP = <dY[src p], V[src q]>,
 // dA = s*P*(dP - sum_q P*dP).
 #include "common.h"
+#include <cstdlib>
 
+// acc += a.lo*b.lo + a.hi*b.hi on packed bf16 pairs, fp32 accumulate.  Inline asm: hipcc (ROCm 7.2) miscompiles
+// __builtin_amdgcn_fdot2_f32_bf16 on elements of a 4 x u32 vector (every call reads element 0; tools/probe/dot2.hip)
+__device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float acc) {
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+    return acc;
+}
 #define OHD 32          // head dim handled by these kernels
 #define OKK 9           // 3x3 slots
 #define OPP 81
@@ -160,10 +167,11 @@ k_outlook_dlogits(const bf16_t* __restrict__ v, const bf16_t* __restrict__ dy, c
         const int wi = wl / w, wj = wl - wi * w;
         const int pr0 = 2 * wi, pc0 = 2 * wj;        // patch coords of slot (0,0): y = 2(I0+wi)-1 -> row 2wi
         float* Prow = P + wl * OPP + p * OKK;
-        float g[OHD];
+        // <dY[src p], V[src q]> over 32 channels as 16 v_dot2c_f32_bf16 on the packed bf16 pairs (no unpacking)
+        u32x4 g[4];
         const bf16_t* gp = pg + ((pr0 + p / 3) * pw + pc0 + p % 3) * 8;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) unpack8(ld16(gp + c * npix * 8), g + c * 8);
+        for (int c = 0; c < 4; ++c) g[c] = ld16(gp + c * npix * 8);
         float dP[OKK], pr[OKK];
         float dot = 0.f;
 #pragma unroll
@@ -172,10 +180,9 @@ k_outlook_dlogits(const bf16_t* __restrict__ v, const bf16_t* __restrict__ dy, c
             float s = 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float f[8];
-                unpack8(ld16(vp + c * npix * 8), f);
+                const u32x4 f = ld16(vp + c * npix * 8);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) s += g[c * 8 + k] * f[k];
+                for (int k = 0; k < 4; ++k) s = dot2_bf16(g[c][k], f[k], s);
             }
             dP[q] = s;
             pr[q] = Prow[q];
@@ -205,8 +212,10 @@ static int gather_launch(bool tp, const bf16_t* in, const bf16_t* logits, int ld
     // strips of SR window rows: a strip re-stages 3 halo pixel rows and one halo window row, so taller strips waste
     // less; 4 rows keep ~3000 workgroups x 256 lanes in flight at 28x28 / B = 128 and 3 workgroups per CU (LDS)
     auto lds_of = [&](int sr) { return (size_t)pad_npix((2 * sr + 3) * pw) * OHD * 2 + (size_t)(sr + 1) * w * OPP * 4; };
-    int SR = 4; if (SR > h) SR = h;
-    while (SR > 1 && lds_of(SR) > 52 * 1024) --SR;
+    static int sr_env = -1;
+    if (sr_env < 0) { const char* e = getenv("AP_OUTLOOK_SR"); sr_env = e ? atoi(e) : 0; }
+    int SR = sr_env > 0 ? sr_env : 4; if (SR > h) SR = h;
+    while (SR > 1 && lds_of(SR) > 78 * 1024) --SR;
     if (lds_of(SR) > 160 * 1024) return AP_ERR_UNSUPPORTED;
     const int nstrips = (h + SR - 1) / SR;
     const dim3 grid((unsigned)(B * nstrips * heads));
@@ -236,8 +245,10 @@ int ap_outlook_bwd(const ap_bf16* v, const ap_bf16* logits, int ldl, const ap_bf
     const int h = (H + 1) / 2, w = (W + 1) / 2;
     const int pw = 2 * w + 1;
     auto lds_of = [&](int sr) { return 2 * ((size_t)pad_npix((2 * sr + 1) * pw) * OHD * 2) + (size_t)sr * w * OPP * 4; };
-    int SRW = 4; if (SRW > h) SRW = h;
-    while (SRW > 1 && lds_of(SRW) > 52 * 1024) --SRW;
+    static int srw_env = -1;
+    if (srw_env < 0) { const char* e = getenv("AP_OUTLOOK_SRW"); srw_env = e ? atoi(e) : 0; }
+    int SRW = srw_env > 0 ? srw_env : 4; if (SRW > h) SRW = h;
+    while (SRW > 1 && lds_of(SRW) > 78 * 1024) --SRW;
     if (lds_of(SRW) > 160 * 1024) return AP_ERR_UNSUPPORTED;
     const int nstrips = (h + SRW - 1) / SRW;
     (void)hipGetLastError();
