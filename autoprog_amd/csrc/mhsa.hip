@@ -253,12 +253,14 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
                     sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_at<HD>(Qs, rb[kc], q0), kf[kc], sc, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_at<HD>(Gs, rb[kc], q0), vf[kc], dp, 0, 0, 0);
                 }
+                // the lane's 4 query rows q0+4g..+3 are consecutive: one 16-byte LDS read each for lse and delta
+                const f32x4 fl4 = *reinterpret_cast<const f32x4*>(fl + q0 + 4 * g);
+                const f32x4 fd4 = *reinterpret_cast<const f32x4*>(fd + q0 + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int q = q0 + 4 * g + r;
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -fl[q]));
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -fl4[r]));
                     p[hf][r] = pv;
-                    ds[hf][r] = pv * (dp[r] - fd[q]);                 // the softmax scale is applied once to dK / dQ
+                    ds[hf][r] = pv * (dp[r] - fd4[r]);                // the softmax scale is applied once to dK / dQ
                 }
             }
             const bf16x8 pf = pack_frag(p[0], p[1]);

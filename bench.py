@@ -85,6 +85,7 @@ class GemmProbe:
 
     def __init__(self):
         self.records = []
+        self.bytes = 0.0
 
     def install(self):
         from autoprog_amd import ops
@@ -100,6 +101,9 @@ class GemmProbe:
             nn = b.shape[0] if n is None else n
             kk = a.shape[1] if k is None else k
             probe.records.append((e0, e1, 2.0 * a.shape[0] * nn * kk))
+            # algorithmic bytes: A + B + C once, plus the epilogue operands this call reads / writes
+            extra = sum(1 for k2 in ("residual", "dgelu_of", "preact_out") if kw.get(k2) is not None)
+            probe.bytes += 2.0 * (a.shape[0] * kk + nn * kk + a.shape[0] * nn * (1 + extra))
             return out
         ops.gemm_nt = timed
 
@@ -207,8 +211,17 @@ def main():
         launches, ms, flops = probe.summary()
         probe.remove()
         achieved = flops / (ms * 1e-3) / 1e12
+        # HBM bytes per launch come from a separate rocprofv3 --pmc pass (tools/collect_profiles.sh writes the file below
+        # from FETCH_SIZE / WRITE_SIZE with the gfx950 correction of MI355X_MICROARCH.md); null when that file is absent
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "gemm_nt_traffic.json")) as fh:
+                traffic = json.load(fh).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         roofline = {"bound": "mfma", "kernel": "k_gemm_nt", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(probe.bytes / max(launches, 1)),
                     "launches_per_step": launches // nprobe, "avg_launch_us": round(ms * 1e3 / launches, 2),
                     "gemm_ms_per_step": round(ms / nprobe, 3), "gemm_gflop_per_step": round(flops / nprobe / 1e9, 1)}
 
