@@ -6,15 +6,19 @@
 #   gpurun_out/gemm_nt_traffic.json   HBM bytes per k_gemm_nt launch from FETCH_SIZE/WRITE_SIZE (gfx950 correction applied)
 # Copy them into profiles/ afterwards.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+if [ -z "$PMC_ONLY" ]; then
 python3 bench.py 2> gpurun_out/r01_bench.err | tail -1 > gpurun_out/r01_bench_n1.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/_kt -o run -- python3 bench.py --steps 7 --warmup 3 --no-cpu-baseline > gpurun_out/_kt.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/_kt -o run -- python3 bench.py --steps 7 --warmup 3 --no-cpu-baseline > gpurun_out/_kt.log 2>&1
 f=$(find gpurun_out/_kt -name "*kernel_trace.csv" | head -1)
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 7 --warmup 3 --no-cpu-baseline ; dispatches after the 6th k_soft_ce (warm-up dropped)"; python3 tools/prof_summary.py $f --after k_soft_ce 6; } > gpurun_out/r01_kernel_stats.txt
 rm -rf gpurun_out/_kt
+fi
 i=0
-for grp in "FETCH_SIZE WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
+# FETCH_SIZE and WRITE_SIZE are derived metrics that do not fit one pass together ("exceeds the capabilities of the hardware",
+# after which rocprofv3 aborts and hangs): one pass each, every pass under a hard timeout
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d gpurun_out/_pmc/p$i -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/_pmc$i.log 2>&1
+  timeout 240 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/_pmc/p$i -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/_pmc$i.log 2>&1
 done
 { echo "# rocprofv3 --pmc <one group per pass> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline ; per-dispatch averages"
   echo "# FETCH_SIZE/WRITE_SIZE are in KB; gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md): double it."
@@ -36,4 +40,4 @@ if n:
                "source": "profiles/r01_pmc_counters.txt"}, open("gpurun_out/gemm_nt_traffic.json", "w"))
 PY
 rm -rf gpurun_out/_pmc
-cat gpurun_out/r01_bench_n1.json; head -12 gpurun_out/r01_kernel_stats.txt | cut -c1-150; cat gpurun_out/gemm_nt_traffic.json
+grep -A9 'k_gemm_nt<128, 128' gpurun_out/r01_pmc_counters.txt | head -12; cat gpurun_out/gemm_nt_traffic.json
