@@ -304,15 +304,15 @@ class LayerNormFn(torch.autograd.Function):
     def forward(ctx, x, w, b, eps):
         xc = x.contiguous()
         y, m, r = ops.layernorm_fwd(xc, w, b, eps)
-        ctx.save_for_backward(xc, w, m, r)
+        ctx.save_for_backward(xc, w, b, m, r)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xc, w, m, r = ctx.saved_tensors
-        dw = torch.zeros_like(w)
-        db = torch.zeros_like(w)
-        dx = ops.layernorm_bwd(dy.contiguous(), xc, w, m, r, None, dw, db)
+        xc, w, b, m, r = ctx.saved_tensors
+        bufs, sunk = _param_grad_buffers((w, b))      # with a gradient sink: accumulate straight into param.grad
+        dx = ops.layernorm_bwd(dy.contiguous(), xc, w, m, r, None, bufs[0], bufs[1])
+        dw, db = _finish_param_grads((w, b), bufs, sunk)
         return dx, dw, db, None
 
 
@@ -348,10 +348,9 @@ class LinearFn(torch.autograd.Function):
             cdf = 0.5 * (1.0 + torch.erf(hf * 0.7071067811865476))
             pdf = torch.exp(-0.5 * hf * hf) * 0.3989422804014327
             g = (g.float() * (cdf + hf * pdf)).to(BF16)
-        dw = torch.zeros_like(w)
-        db = torch.zeros_like(b) if b is not None else None
-        dx = _linear_bwd(g, x2, w, dw, db, n=N, need_dx=ctx.needs_input_grad[0])
-        join_wgrad_stream()
+        bufs, sunk = _param_grad_buffers((w, b))      # with a gradient sink (and w, b real parameters): param.grad itself
+        dx = _linear_bwd(g, x2, w, bufs[0], bufs[1], n=N, need_dx=ctx.needs_input_grad[0])
+        dw, db = _finish_param_grads((w, b), bufs, sunk)
         if dx is not None:
             dx = dx[:, :x2.shape[1]] if dx.shape[1] != x2.shape[1] else dx
             dx = dx.reshape(*ctx.lead, x2.shape[1])
