@@ -7,6 +7,7 @@
 // Rows are grid-strided so every lane keeps the same channels and accumulates dgamma/dbeta in
 // registers; those are reduced through LDS per block and added with fp32 atomics.
 #include "common.h"
+#include <cstdlib>
 
 template <int V, int U>
 __global__ void __launch_bounds__(256)
@@ -300,7 +301,9 @@ int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, co
     int V; const int G = pick_group_wide(C, &V);
     const int gpb = 256 / G;
     int64_t grid = ceil_div64(rows, gpb);
-    if (grid > 1024) grid = 1024;           // bounds the dgamma/dbeta atomic traffic
+    static int grid_cap = 0;
+    if (grid_cap == 0) { const char* e = getenv("AP_LN_BWD_GRID"); grid_cap = e ? atoi(e) : 768; if (grid_cap < 1 || grid_cap > 1024) grid_cap = 768; }   // 3 blocks per CU measured best (20.7 vs 23.5 us at 1024)
+    if (grid > grid_cap) grid = grid_cap;   // bounds the dgamma/dbeta partial rows (workspace holds 1024)
     const size_t lds = (size_t)2 * 4 * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
