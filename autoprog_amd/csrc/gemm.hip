@@ -1057,6 +1057,8 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         case 7: NT_LAUNCH(256, 128, 2, 2) break;
         case 8: NT_LAUNCH(128, 256, 2, 2) break;
         case 9: NT_LAUNCH(256, 256, 2, 4) break;
+        case 10: NT_LAUNCH(128, 192, 2, 2) break;
+        case 11: NT_LAUNCH(64, 192, 2, 2) break;
         default: NT_LAUNCH(128, 128, 2, 2) break;
     }
 #undef NT_LAUNCH

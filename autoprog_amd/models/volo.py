@@ -311,8 +311,9 @@ class PatchEmbed(nn.Module):
         kernels of csrc/bnrelu.hip on the NHWC view of the conv output."""
         if not x.is_cuda:
             raise RuntimeError("autoprog_amd models run on the GPU only (no CPU fallback)")
-        x = x.contiguous(memory_format=torch.channels_last)
         fused = self.compute_dtype == BF16
+        # one pass: NCHW fp32 -> NHWC(channels_last) in the compute dtype (autocast would otherwise cast a second time)
+        x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
         with torch.autocast("cuda", dtype=BF16, enabled=fused):
             if self.stem_conv:
                 if fused:
