@@ -6,6 +6,8 @@ the fp32/fp64 oracle evaluated on the bf16-rounded inputs (expected ~3e-3 = bf16
 the output); fp32-accumulated weight gradients <= 3e-3; integer/bookkeeping ops exact.
 """
 import math
+import os
+import sys
 
 import pytest
 import torch
@@ -370,3 +372,17 @@ def test_bn_relu_fused(ops, B, H, W, C):
     bn.eval()
     ye = AF.BNReLUFn.apply(dev(x), dev(g), dev(b), rm, rv, False, 0.1, 1e-5)
     assert rel(ye, torch.relu(bn(x.double().permute(0, 3, 1, 2))).permute(0, 2, 3, 1)) < TOL_BF16
+
+
+@pytest.mark.parametrize("env", [{"AP_GEMM_NT_P": "1"}, {"AP_GEMM_NT_P": "4"}, {"AP_GEMM_NT_RING": "1"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"},
+                                 {"AP_GEMM_TN_RING": "1"}, {"AP_ASYNC_WGRAD": "1"}])
+def test_experimental_kernel_paths_stay_parity_green(env):
+    """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:
+    re-run the GEMM / block tests in a child process with the switch set (the switches are read once per process)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sel = "gemm and not experimental" if "WGRAD" not in next(iter(env)) else "vs_reference_golden or grad_sink"
+    files = ["tests/test_gpu_kernels.py"] if "WGRAD" not in next(iter(env)) else ["tests/test_gpu_blocks.py", "tests/test_gpu_model.py"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", sel] + files, cwd=root, env=dict(os.environ, **env),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
