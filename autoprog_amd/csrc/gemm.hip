@@ -271,6 +271,74 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
     }
 }
 
+// ------------------------------------------------------------ gemm_nt for very few rows (M <= 256)
+// The class-attention blocks and the heads work on ONE token per image (M = batch = 128).  As 128x128 tiles these are
+// 3-9 workgroups walking K serially, one exposed memory latency per 64-deep step: 19-51 us inside the training step for
+// 0.04-0.1 GFLOP.  Here: 64x32 output tile per workgroup (24-72 workgroups), the 8 waves split K into 32-deep chunks, each
+// wave loads its MFMA fragments straight from global memory with up to three chunks in flight, partial sums meet in LDS.
+#define SK_STRIDE 36        // floats per LDS row of a wave's 64x32 partial tile (16-B aligned, spreads the banks)
+__global__ void __launch_bounds__(512)
+k_gemm_nt_skinny(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
+                 int M, int N, int K, EpiArgs ep) {
+    extern __shared__ __attribute__((aligned(16))) float sk_part[];          // [8 waves][64][SK_STRIDE]
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+    const int nch = K >> 5;
+    const bf16_t* arow[4];
+    const bf16_t* brow[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) arow[t] = A + (int64_t)min(m0 + t * 16 + fr, M - 1) * lda + g * 8;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) brow[t] = B + (int64_t)min(n0 + t * 16 + fr, N - 1) * ldb + g * 8;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    for (int c0 = wave; c0 < nch; c0 += 24) {          // rounds of up to 3 chunks per wave, chunks interleaved over the waves
+        u32x4 xa[3][4], wb[3][2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ch = c0 + 8 * r;
+            const bool ok = ch < nch;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xa[r][t] = ok ? ld16(arow[t] + ch * 32) : zero4;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) wb[r][t] = ok ? ld16(brow[t] + ch * 32) : zero4;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wb[r][nt]), as_bf16x8(xa[r][mt]), acc[nt][mt], 0, 0, 0);
+    }
+    float* mine = sk_part + wave * 64 * SK_STRIDE;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            *reinterpret_cast<f32x4*>(mine + (mt * 16 + fr) * SK_STRIDE + nt * 16 + 4 * g) = acc[nt][mt];
+    __syncthreads();
+    if (tid < 256) {
+        const int r = tid >> 2, j = tid & 3;
+        const int m = m0 + r, n = n0 + 8 * j;
+        if (m < M && n < N) {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float* p = sk_part + (w * 64 + r) * SK_STRIDE + 8 * j;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+                v[0] += lo[0]; v[1] += lo[1]; v[2] += lo[2]; v[3] += lo[3]; v[4] += hi[0]; v[5] += hi[1]; v[6] += hi[2]; v[7] += hi[3];
+            }
+            const bool vec_ok = ((ldc & 7) == 0) && (ep.residual == nullptr || (ep.ldr & 7) == 0);
+            epi_chunk(v, m, n, N, ldc, vec_ok, ep, C);
+        }
+    }
+}
+
 // ------------------------------------------------------------ gemm_nt, persistent LDS-DMA ring
 // Main forward / input-gradient GEMM for K % 64 == 0 (every Linear of the D1..D5 and DeiT models).
 // Ablation of a non-persistent 256x128 ring kernel on the qkv shape (M 25088, N 1152, K 384; rocprof +
@@ -953,6 +1021,15 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         if (ep.residual && ep.ldr < N) return AP_ERR_SHAPE;
     }
     (void)hipGetLastError();
+    static int skinny = -1;
+    if (skinny < 0) { const char* e = getenv("AP_GEMM_NT_NO_SKINNY"); skinny = (e && e[0] == '1') ? 0 : 1; }
+    if (skinny && M <= 256 && (K & 31) == 0) {
+        const size_t lds = (size_t)8 * 64 * SK_STRIDE * sizeof(float);
+        static bool sk_attr = false;
+        if (!sk_attr) { (void)hipFuncSetAttribute((const void*)k_gemm_nt_skinny, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); sk_attr = true; (void)hipGetLastError(); }
+        hipLaunchKernelGGL(k_gemm_nt_skinny, dim3((N + 31) / 32, (M + 63) / 64), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, ep);
+        return ap_check_launch();
+    }
     static int force_small = -1;
     // the persistent one-workgroup-per-CU ring kernel measured ~8 % slower than the multi-workgroup 128x128
     // kernel with the same coalesced epilogue (DESIGN.md "GEMM experiments"); kept selectable for tuning
@@ -1033,7 +1110,13 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     if (variant == 0) {
         // measured on the D1 shape list (tools/bench_gemm.py, AP_GEMM_NT_TILE sweep): narrow/short problems want
         // small tiles (more workgroups, 4-6 waves/SIMD, no wasted columns at N = 192/486/576), the rest 128x128
-        if (N <= 512 && K <= 256) variant = 4;                                   // 64x64
+        static int allow192 = -1;
+        if (allow192 < 0) { const char* e = getenv("AP_GEMM_NT_192"); allow192 = (e && e[0] == '1') ? 1 : 0; }
+        // 128x192 tiles (wave tile 64x96: 17 % fewer LDS bytes per FLOP, direct epilogue), AP_GEMM_NT_192=1: faster with
+        // cache-warm operands (33.9 vs 37.2 us on the dfc1 shape when the same buffers are reused back to back) but the training
+        // step, whose operands come from HBM, is 0.3 ms SLOWER with them -> off by default
+        if (allow192 && N % 192 == 0 && N >= 384 && M >= 4096 && !ep.gelu && !ep.dgelu_of && !ep.residual && K >= 384) variant = 10;
+        else if (N <= 512 && K <= 256) variant = 4;                              // 64x64
         else if (N <= 256 || ((N % 128 != 0) && (N % 64 == 0))) variant = 2;     // 128x64
         else variant = 1;                                                        // 128x128
     }
@@ -1041,7 +1124,7 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     // (64-B row segments, no LDS round trip) on the 128x64 tiles of the N = 576 shapes; AP_GEMM_LDS_EPI=0/1 forces one
     static int lds_epi_env = -2;
     if (lds_epi_env == -2) { const char* e = getenv("AP_GEMM_LDS_EPI"); lds_epi_env = e ? (e[0] == '1') : -1; }
-    const int lds_epi = lds_epi_env >= 0 ? lds_epi_env : (variant != 2);
+    const int lds_epi = lds_epi_env >= 0 ? lds_epi_env : (variant != 2 && variant != 10);
 #define NT_LAUNCH(TMv, TNv, WMv, WNv)                                                                        \
     {                                                                                                          \
         const int tm_ = (M + TMv - 1) / TMv, tn_ = (N + TNv - 1) / TNv, nt_ = tm_ * tn_;                       \

@@ -85,6 +85,7 @@ class GemmProbe:
 
     def __init__(self):
         self.records = []
+        self.keys = []
         self.bytes = 0.0
 
     def install(self):
@@ -101,6 +102,7 @@ class GemmProbe:
             nn = b.shape[0] if n is None else n
             kk = a.shape[1] if k is None else k
             probe.records.append((e0, e1, 2.0 * a.shape[0] * nn * kk))
+            probe.keys.append((a.shape[0], nn, kk, "+".join(k2 for k2 in ("bias", "gelu", "dgelu_of", "row_scale", "residual") if kw.get(k2) is not None and kw.get(k2) is not False) or "plain"))
             # algorithmic bytes: A + B + C once, plus the epilogue operands this call reads / writes
             extra = sum(1 for k2 in ("residual", "dgelu_of", "preact_out") if kw.get(k2) is not None)
             probe.bytes += 2.0 * (a.shape[0] * kk + nn * kk + a.shape[0] * nn * (1 + extra))
@@ -110,6 +112,18 @@ class GemmProbe:
     def remove(self):
         from autoprog_amd import ops
         ops.gemm_nt = self._orig
+
+    def table(self):
+        """per-shape HIP-event times INSIDE the training step (AP_GEMM_TABLE=1): the ground truth for tile-variant choices --
+        back-to-back microbenchmarks on one buffer set run cache-warm and rank the variants differently"""
+        torch.cuda.synchronize()
+        agg = {}
+        for (e0, e1, fl), key in zip(self.records, self.keys):
+            t = agg.setdefault(key, [0, 0.0, 0.0])
+            t[0] += 1; t[1] += e0.elapsed_time(e1) * 1e3; t[2] += fl
+        lines = ["%7d %5d %5d %-28s x%-4d %8.1f us  %7.1f TFLOP/s" % (k[0], k[1], k[2], k[3], v[0], v[1] / v[0], v[2] / v[1] / 1e6)
+                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])]
+        return "\n".join(lines)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -209,6 +223,8 @@ def main():
         for _ in range(nprobe):
             step()
         launches, ms, flops = probe.summary()
+        if rank == 0 and os.environ.get("AP_GEMM_TABLE") == "1":
+            print(probe.table(), file=sys.stderr, flush=True)
         probe.remove()
         achieved = flops / (ms * 1e-3) / 1e12
         # HBM bytes per launch come from a separate rocprofv3 --pmc pass (tools/collect_profiles.sh writes the file below

@@ -96,21 +96,24 @@ def test_gemm_nt_plain_and_bias(ops, M, N, K):
     assert rel(out[:, :N], ref + bias.double()) < TOL_BF16
 
 
-def test_gemm_nt_epilogues(ops):
-    M, N, K, rps = 392, 576, 192, 196
+@pytest.mark.parametrize("M,N,K", [(392, 576, 192), (128, 1152, 384), (1, 384, 384), (200, 200, 1152), (256, 32, 32)])
+def test_gemm_nt_epilogues(ops, M, N, K):
+    """second to fifth shapes: the few-rows kernel (M <= 256: class-attention blocks, cls heads)"""
+    rps = max(1, M // 2)
     a, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
     bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
     res = rnd(M, N, seed=4)
-    rs = torch.tensor([0.0, 1.0 / 0.9])
+    rs = torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9])
     lin = a.double() @ w.double().t() + bias.double()
     # gelu with pre-activation side output
+    assert N % 8 == 0
     h = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     out = ops.gemm_nt(dev(a), dev(w), bias=dev(bias), gelu=True, preact_out=h)
     assert rel(h, lin) < TOL_BF16
     assert rel(out, R.gelu(h.double().cpu())) < TOL_BF16          # activation of the ROUNDED pre-activation
     # residual + row scale (DropPath)
     out = ops.gemm_nt(dev(a), dev(w), bias=dev(bias), row_scale=dev(rs), rows_per_scale=rps, residual=dev(res))
-    ref = lin * rs.double().repeat_interleave(rps)[:, None] + res.double()
+    ref = lin * rs.double().repeat_interleave(rps)[:M, None] + res.double()
     assert rel(out, ref) < TOL_BF16
     assert torch.equal(out[:rps].cpu(), res[:rps])               # dropped samples pass the residual through exactly
     # dgelu epilogue

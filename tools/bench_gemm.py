@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the C-ABI GEMMs on the VOLO-D1 shapes (B=128, 224 px): TFLOP/s and GB/s per shape.
 Run on the GPU box:  python tools/bench_gemm.py [nt|tn|all]"""
+import os
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,6 +19,23 @@ NT = [  # (name, M, N, K, epilogue)
 TN = [("out.v/proj", T1, 192, 192), ("out.attn", P, 486, 192), ("out.fc1", T1, 576, 192), ("out.fc2", T1, 192, 576),
       ("down", P, 384, 768), ("tr.qkv", T2, 1152, 384), ("tr.proj", T2, 384, 384), ("tr.fc1", T2, 1152, 384),
       ("tr.fc2", T2, 384, 1152), ("aux_head", T2, 1000, 384)]
+
+
+COLD = os.environ.get("AP_BENCH_COLD", "1") != "0"     # rotate over > 600 MB of operand copies (Infinity Cache is 256 MiB);
+                                                         # AP_BENCH_COLD=0 reuses ONE buffer set (cache-warm: flatters kernels that
+                                                         # stream more bytes -- tile choices made that way lost in the real step)
+
+
+def rotating(make, nbytes):
+    """make() -> (fn taking no args); returns a function cycling over enough independent buffer sets"""
+    n = max(1, int(600e6 // max(nbytes, 1)) + 1) if COLD else 1
+    fns = [make() for _ in range(min(n, 24))]
+    state = {"i": 0}
+
+    def call():
+        fns[state["i"] % len(fns)]()
+        state["i"] += 1
+    return call
 
 
 def timeit(fn, iters=20):
@@ -42,24 +60,27 @@ def main():
         for name, M, N, K, epi in NT:
             ld = ops.round_up(N, 8)
             kp = ops.round_up(K, 8)
-            a = torch.randn(M, kp, device=dev).bfloat16()
             w = (torch.randn(N, kp, device=dev) * K ** -0.5).bfloat16()
-            out = torch.empty(M, ld, device=dev, dtype=torch.bfloat16)
-            kw = {}
-            nbytes = 2.0 * (M * K + N * K + M * N)
-            if epi in ("bias", "gelu", "res"):
-                kw["bias"] = torch.randn(N, device=dev)
-            if epi == "gelu":
-                kw["gelu"] = True
-                kw["preact_out"] = torch.empty(M, ld, device=dev, dtype=torch.bfloat16)
-                nbytes += 2.0 * M * N
-            if epi == "res":
-                kw["residual"] = torch.randn(M, ld, device=dev).bfloat16()
-                nbytes += 2.0 * M * N
-            if epi == "dgelu":
-                kw["dgelu_of"] = torch.randn(M, ld, device=dev).bfloat16()
-                nbytes += 2.0 * M * N
-            us = timeit(lambda: ops.gemm_nt(a, w, n=N, k=kp, out=out, **kw))
+            bias = torch.randn(N, device=dev)
+            nbytes = 2.0 * (M * K + N * K + M * N) + (2.0 * M * N if epi in ("gelu", "res", "dgelu") else 0.0)
+
+            def make():
+                a = torch.randn(M, kp, device=dev).bfloat16()
+                out = torch.empty(M, ld, device=dev, dtype=torch.bfloat16)
+                kw = {}
+                if epi in ("bias", "gelu", "res"):
+                    kw["bias"] = bias
+                if epi == "gelu":
+                    kw["gelu"] = True
+                    kw["preact_out"] = torch.empty(M, ld, device=dev, dtype=torch.bfloat16)
+                if epi == "res":
+                    kw["residual"] = torch.randn(M, ld, device=dev).bfloat16()
+                    kw["row_scale"] = torch.rand(M // 196 + 1, device=dev)
+                    kw["rows_per_scale"] = 196
+                if epi == "dgelu":
+                    kw["dgelu_of"] = torch.randn(M, ld, device=dev).bfloat16()
+                return lambda: ops.gemm_nt(a, w, n=N, k=kp, out=out, **kw)
+            us = timeit(rotating(make, nbytes))
             fl = 2.0 * M * N * K
             tot_t += us; tot_f += fl
             print("%-16s %7d %5d %5d %9.1f %9.1f %9.1f" % (name, M, N, K, us, fl / us / 1e6, nbytes / us / 1e3))
