@@ -111,7 +111,7 @@ __device__ __forceinline__ int key_a(int r) { return r & 7; }
 // ds_read_b128 lane group touches are 8q + 4b + p (q = 0..3, p = 0..3) -> keys p | (q&1)<<2 are distinct
 __device__ __forceinline__ int key_b(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
-template <int TM, int TN, int WGM, int WGN, bool DEPI = true>
+template <int TM, int TN, int WGM, int WGN, bool DEPI = true, int PF = 1>
 __global__ void __launch_bounds__(WGM * WGN * 64)
 k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
           int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
@@ -150,9 +150,12 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
         gb[i] = B + (int64_t)min(n0 + r, N - 1) * ldb + kc * 8;
         soffb[i] = r * SBK + ((kc ^ (DEPI ? key_b(r) : key_a(r))) << 3);
     }
-    u32x4 ra[NA], rb[NB];
+    // PF register sets: the global loads of the next PF K steps are in flight while one step is computed.  PF = 2 was tried on
+    // the small tiles (K = 192..576, 3..9 steps) and LOST inside the training step (fc1+gelu of the outlooker 96 -> 111 us,
+    // 192x576 plain 40.6 -> 45.3): the extra 16-32 VGPRs cost a wave per SIMD and latency was not the limit.  Default 1.
+    u32x4 ra0[NA], rb0[NB], ra1[PF > 1 ? NA : 1], rb1[PF > 1 ? NB : 1];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    auto gload = [&](int k0) {
+    auto gload = [&](u32x4* ra, u32x4* rb, int k0) {
         const bool ok = (k0 + kc * 8) < K;
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = ok ? ld16(ga[i] + k0) : zero4;
@@ -166,14 +169,14 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
-    for (int k0 = 0; k0 < K; k0 += SBK) {
+    // one K step: registers -> LDS, refill the same register set with step `refill_k`, MFMAs
+    auto step = [&](u32x4* ra, u32x4* rb, int refill_k) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) st16(sA + soffa[i], ra[i]);
 #pragma unroll
         for (int i = 0; i < NB; ++i) st16(sB + soffb[i], rb[i]);
         __syncthreads();
-        if (k0 + SBK < K && !(ep.dbg & 2)) gload(k0 + SBK);
+        if (refill_k < K) gload(ra, rb, refill_k);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 xf[MT], wf[NT];
@@ -190,13 +193,6 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
                                    : wn * (TN / WGN) + t * 16 + fr;
                 wf[t] = as_bf16x8(ld16(sB + r * SBK + (((ks * 4 + g) ^ (DEPI ? key_b(r) : key_a(r))) << 3)));
             }
-            if (ep.dbg & 4) {
-#pragma unroll
-                for (int t = 0; t < MT; ++t) asm volatile("" ::"v"(xf[t]));
-#pragma unroll
-                for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(wf[t]));
-                continue;
-            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -204,6 +200,16 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
         }
         __syncthreads();
+    };
+    gload(ra0, rb0, 0);
+    if constexpr (PF > 1) {
+        if (SBK < K) gload(ra1, rb1, SBK);
+        for (int k0 = 0; k0 < K; k0 += 2 * SBK) {
+            step(ra0, rb0, k0 + 2 * SBK);
+            if (k0 + SBK < K) step(ra1, rb1, k0 + 3 * SBK);
+        }
+    } else {
+        for (int k0 = 0; k0 < K; k0 += SBK) step(ra0, rb0, k0 + SBK);
     }
     if (ep.dbg & 1) {
         float sacc = 0.f;
