@@ -1130,7 +1130,30 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     // (64-B row segments, no LDS round trip) on the 128x64 tiles of the N = 576 shapes; AP_GEMM_LDS_EPI=0/1 forces one
     static int lds_epi_env = -2;
     if (lds_epi_env == -2) { const char* e = getenv("AP_GEMM_LDS_EPI"); lds_epi_env = e ? (e[0] == '1') : -1; }
-    const int lds_epi = lds_epi_env >= 0 ? lds_epi_env : (variant != 2 && variant != 10);
+    // tuning aid: AP_GEMM_NT_RULE="N,K,variant[,lds_epi];N,K,variant;..." overrides the choice for exact (N, K) pairs, so that a
+    // candidate can be timed INSIDE the training step (bench.py AP_GEMM_TABLE=1) instead of in a cache-warm microbenchmark
+    int rule_epi = -1;
+    {
+        static int nrules = -1;
+        static int rules[16][4];
+        if (nrules < 0) {
+            nrules = 0;
+            const char* e = getenv("AP_GEMM_NT_RULE");
+            while (e && *e && nrules < 16) {
+                int n_ = 0, k_ = 0, v_ = 0, l_ = -1, used = 0;
+                const int got = sscanf(e, "%d,%d,%d%n", &n_, &k_, &v_, &used);
+                if (got < 3) break;
+                e += used;
+                if (*e == ',') { int u2 = 0; if (sscanf(e, ",%d%n", &l_, &u2) == 1) e += u2; }
+                rules[nrules][0] = n_; rules[nrules][1] = k_; rules[nrules][2] = v_; rules[nrules][3] = l_;
+                ++nrules;
+                if (*e == ';') ++e;
+            }
+        }
+        for (int i = 0; i < nrules; ++i)
+            if (rules[i][0] == N && rules[i][1] == K && forced == 0) { variant = rules[i][2]; rule_epi = rules[i][3]; }
+    }
+    const int lds_epi = rule_epi >= 0 ? rule_epi : (lds_epi_env >= 0 ? lds_epi_env : (variant != 2 && variant != 10));
 #define NT_LAUNCH(TMv, TNv, WMv, WNv)                                                                        \
     {                                                                                                          \
         const int tm_ = (M + TMv - 1) / TMv, tn_ = (N + TNv - 1) / TNv, nt_ = tm_ * tn_;                       \
