@@ -227,6 +227,30 @@ def test_deit_tiny_depth4_vs_oracle():
     assert rel(ys, yrs) < 2e-2
 
 
+def test_deit_base_width_vs_oracle():
+    """BASELINE.json configs[3] kernel shapes (DeiT-Base width: 768 channels, 12 heads of 64, 197 tokens) on a 2-block
+    network at batch 2: forward, loss and every parameter gradient vs the oracle."""
+    from autoprog_amd.models import create_model
+    from autoprog_amd.loss import SoftTargetCrossEntropy
+    torch.manual_seed(1)
+    model = create_model("model_variant", variant="deit_h12_l2").cuda().train()
+    B = 2
+    x = torch.randn(B, 3, 224, 224, device="cuda")
+    target = torch.softmax(torch.randn(B, 1000, device="cuda") * 3, dim=-1)
+    y = model(x)
+    loss = SoftTargetCrossEntropy()(y, target)
+    loss.backward()
+    p = {k: v.detach().double().cpu().requires_grad_(True) for k, v in model.state_dict().items()}
+    yr = R.vit_forward(p, x.double().cpu(), depth=2, heads=12)
+    lr = R.soft_target_ce(yr, target.double().cpu())
+    lr.backward()
+    assert rel(y, yr) < 2e-2, rel(y, yr)
+    assert abs(float(loss.detach()) - float(lr.detach())) < 2e-3 * float(lr.detach())
+    errs = {n: rel(q.grad, p[n].grad) for n, q in model.named_parameters() if float(p[n].grad.norm()) > 1e-9}
+    bad = {k: v for k, v in errs.items() if v > 6e-2}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+
+
 @pytest.mark.parametrize("l,r", [(9, 128), (12, 160), (15, 192)])
 def test_autoprog_stage_shapes_elastic_supernet(l, r):
     """BASELINE.json configs[2]: the reference schedule's stage shapes (l, r) run on ONE volo_h12_l18
