@@ -599,6 +599,7 @@ k_gemm_nt_p(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
     __builtin_amdgcn_s_barrier();
     if (total > 0) frags(ring, 0, xf0, wf0);
     int kt = 0, ti = 0;
+    bool stores_in_flight = false;                   // the previous step ended with an unguarded (full-tile) epilogue
     for (int s = 0; s < total; ++s) {
         const bf16_t* cur = ring + (s & 1) * STAGE;
         const bf16_t* nxt = ring + ((s + 1) & 1) * STAGE;
@@ -622,7 +623,12 @@ k_gemm_nt_p(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
         __builtin_amdgcn_sched_group_barrier(0x008, NMF - 2 * NRD, 0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave is done reading stage `cur`
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // and its pieces of step s+1 have landed
+        // ... and its pieces of step s+1 have landed.  They are OLDER than the >= 12 global stores of a full-tile epilogue the
+        // previous step may have issued (counters retire in order), so after such an epilogue only "all but the 12 youngest"
+        // is waited for: the stores drain in the background instead of stalling the first step of every tile.
+        if (stores_in_flight) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stores_in_flight = false;
         __builtin_amdgcn_s_barrier();                                // true for every wave: `cur` is free, `nxt` is complete
         // ---- second half: MFMAs on set 1 with the DMA of step s+2 and the first-half reads of step s+1 between them.
         // Past the end the DMA fetches (row-clamped, in-bounds) data nobody reads and the reads are unused: no branches here.
@@ -697,6 +703,7 @@ k_gemm_nt_p(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // strip reads done before the next strip overwrites it
         }
+        stores_in_flight = vec_ok && (m0 + 64 <= M) && (n0 + WN_COLS <= N);     // every lane stored all its 4 * ITEMS chunks
     }
 #ifdef AP_STAMP
     if (ep.stamps && blockIdx.x == 0 && tid == 0) {
