@@ -153,14 +153,21 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # AP_DIST_BACKEND=gloo (testing only): lets several ranks share one GPU to exercise the multi-rank code path where
+    # RCCL cannot run (it refuses two ranks on one device); the driver's runs use the default, nccl (= RCCL on ROCm)
+    backend = os.environ.get("AP_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # reference main_prog.py:65 sets cudnn.benchmark = True: let MIOpen MEASURE its conv solvers for the stem
     # (its immediate-mode heuristics can pick solvers that are 100x slower on a fresh machine)
     torch.backends.cudnn.benchmark = True
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from autoprog_amd.models import create_model
     from autoprog_amd.loss import TokenLabelCrossEntropy

@@ -95,3 +95,22 @@ def test_two_rank_gradient_mean_on_one_gpu():
         assert err < 2e-2, (n, err)          # fp32 atomics order + bf16 activations: not bitwise
     skipped = [n for n in ref if float(ref[n].abs().sum()) == 0.0 and n.startswith("network.")]
     assert skipped, "the elastic config should leave some layers without gradients"
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's multi-rank path (torch.distributed.run launch, barriers, max-over-ranks timing, one JSON line from rank 0)
+    with two gloo ranks sharing the GPU (RCCL refuses that; the driver's real runs use nccl)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=root, env=dict(os.environ, AP_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 32 and out["cpu_baseline"] is None
+    assert 0 < out["config"]["final_loss"] < 20
