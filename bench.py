@@ -222,6 +222,23 @@ def main():
         elapsed = float(tmax.item())
     final_loss = float(loss.detach())
 
+    # SURVEY.md section 8(d) M1 asks for the optimizer + EMA share separately: time a few fwd+loss+bwd-only steps as well
+    # (reported under config, never part of `value`)
+    fwd_bwd_ms = None
+    if not args.no_optimizer:
+        def step_nb():
+            reducer.zero_grad()
+            loss_fn(model(images), target).backward()
+            reducer.finish()
+        n_extra = max(1, min(5, args.steps))
+        step_nb()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_extra):
+            step_nb()
+        torch.cuda.synchronize()
+        fwd_bwd_ms = (time.perf_counter() - t1) / n_extra * 1e3
+
     roofline = None
     if not args.no_roofline:
         probe = GemmProbe()
@@ -263,7 +280,8 @@ def main():
                 "config": {"workload": "BASELINE.json configs[1]: %s (VOLO-D1) %dpx token-label training step" % (args.variant, res),
                            "model": args.variant, "global_batch": B * world, "per_gpu_batch": B, "res": res, "parallelism": "dp%d" % world,
                            "step": "fwd+loss+bwd" + ("" if args.no_optimizer else "+AdamW+4xEMA") + ("+RCCL grad all-reduce" if world > 1 else ""),
-                           "final_loss": round(final_loss, 4)},
+                           "final_loss": round(final_loss, 4),
+                           "fwd_loss_bwd_only_ms_per_step": None if fwd_bwd_ms is None else round(fwd_bwd_ms, 3)},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if world > 1:

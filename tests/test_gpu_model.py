@@ -227,6 +227,27 @@ def test_deit_tiny_depth4_vs_oracle():
     assert rel(ys, yrs) < 2e-2
 
 
+def test_deit_distilled_contract():
+    """DistilledVisionTransformer (models/deit.py:20-59): 198 tokens, train returns (x, x_dist), eval their mean; gradients
+    reach the distillation token, its position embedding and head_dist."""
+    from autoprog_amd.models import create_model
+    torch.manual_seed(2)
+    model = create_model("deit_tiny_distilled_patch16_224", num_classes=16).cuda().train()
+    x = torch.randn(2, 3, 224, 224, device="cuda")
+    y, yd = model(x)
+    assert y.shape == (2, 16) and yd.shape == (2, 16) and model.pos_embed.shape[1] == 198
+    (y.float().square().mean() + yd.float().square().mean()).backward()
+    for n in ("dist_token", "pos_embed", "head_dist.weight", "head.weight", "blocks.0.attn.qkv.weight"):
+        g = dict(model.named_parameters())[n].grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0, n
+    model.eval()
+    with torch.no_grad():
+        ye = model(x)
+        model.train()
+        y2, yd2 = model(x)                    # drop_path_rate 0: train and eval forward are the same function
+    assert rel(ye, (y2.float() + yd2.float()) / 2) < 1e-2
+
+
 def test_deit_base_width_vs_oracle():
     """BASELINE.json configs[3] kernel shapes (DeiT-Base width: 768 channels, 12 heads of 64, 197 tokens) on a 2-block
     network at batch 2: forward, loss and every parameter gradient vs the oracle."""
