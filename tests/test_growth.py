@@ -62,3 +62,34 @@ def test_subnet_layer_map_agrees_with_elastic_mask():
             sub, sup = split_depth(l), split_depth(lmax)
             m = subnet_layer_map({0: sub[0], 2: sub[1]}, {0: sup[0], 2: sup[1]}, lmin)
             assert m[0] == mask.kept_layers(0, sup[0]) and m[2] == mask.kept_layers(1, sup[1]), (lmin, lmax, l)
+
+
+def test_search_helpers_match_reference():
+    """no_repeats / get_divisor / sample_configs against the reference's own functions (cut out of main_prog.py and run by
+    tools/gen_golden_growth.py); search_space / converge_speed: behaviour checks (inline code in the reference, unpinned)"""
+    import json
+    import random
+    from autoprog_amd.prog import search as S
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "search.json")))
+    for n, f, want in rec["get_divisor"]:
+        assert S.get_divisor(n, f) == want, (n, f)
+    for v, want in rec["no_repeats"]:
+        assert S.no_repeats(v) == want
+    for seed, cfgs in rec["sample_configs"]:
+        random.seed(seed)
+        for want in cfgs:
+            got = S.sample_configs([12, 15, 18], [160, 192, 224], mode="random")
+            assert [got[0], got[1], got[2]] == want
+    assert list(S.sample_configs([9, 12], [128, 160], mode="smallest")) == rec["sample_smallest"]
+    # stage 0: first / middle / last; later stages: a window from the current point, depth one step ahead
+    r_list, h_list, l_list = [128, 160, 192, 224], [12, 12, 12, 12], [9, 12, 15, 18]
+    assert S.search_space(0, r_list, h_list, l_list, 128, 12, 9) == ([128, 192, 224], [12], [9, 15, 18])
+    assert S.search_space(1, r_list, h_list, l_list, 160, 12, 12) == ([160, 192], [12], [15, 18])
+    assert S.search_space(2, r_list, h_list, l_list, 224, 12, 18) == ([224], [12], [18])
+    # loss = 2 * t^-0.5 exactly -> w = 0.5 and every candidate scores the same; a candidate below the curve wins
+    t = {"a": 1.0, "b": 2.0, "c": 4.0}
+    loss = {k: 2.0 * v ** -0.5 for k, v in t.items()}
+    w, scores, order = S.converge_speed(loss, t)
+    assert abs(w - 0.5) < 1e-6 and max(scores.values()) - min(scores.values()) < 1e-6
+    loss["b"] *= 0.9
+    assert S.converge_speed(loss, t)[2][0] == "b"

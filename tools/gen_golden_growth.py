@@ -46,6 +46,27 @@ def main():
         ns.helpers.load_super(sub, sup, base_layer=base, model_name="volo")
         for k, v in sub.state_dict().items():
             out["%s/%s" % (name, k)] = np.asarray(fingerprint(v), dtype=np.float64)
+    # search helpers of main_prog.py: the file cannot be imported (timm / tlt / apex), so the three self-contained functions are
+    # cut out with ast and executed as they are
+    import ast
+    import json
+    import random
+    src = open(os.path.join(os.environ.get("AUTOPROG_REFERENCE", "/root/reference"), "main_prog.py")).read()
+    ns_fn = {"random": random}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("get_divisor", "no_repeats", "sample_configs"):
+            exec(compile(ast.Module(body=[node], type_ignores=[]), "main_prog.py", "exec"), ns_fn)
+    rec = {"get_divisor": [[n, f, ns_fn["get_divisor"](n, f)] for n in (1, 2, 4, 6, 8, 12, 16) for f in (0.0, 0.1, 0.26, 0.5, 0.51, 0.77, 1.0)],
+           "no_repeats": [[v, ns_fn["no_repeats"](list(v))] for v in ([128, 128, 160, 192, 192, 224], [12, 12, 12], [], [3, 1, 3, 2, 1])],
+           "sample_configs": []}
+    for seed in range(6):
+        random.seed(seed)
+        l_list, r_list = [12, 15, 18], [160, 192, 224]
+        cfgs = [ns_fn["sample_configs"](l_list, r_list, mode="random") for _ in range(5)]
+        rec["sample_configs"].append([seed, [[c[0], c[1], c[2]] for c in cfgs]])
+    rec["sample_smallest"] = list(ns_fn["sample_configs"]([9, 12], [128, 160], mode="smallest"))
+    with open(os.path.join(ROOT, "tests", "golden", "search.json"), "w") as fh:
+        json.dump(rec, fh)
     path = os.path.join(ROOT, "tests", "golden", "growth.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, len(out), "fingerprints,", os.path.getsize(path), "bytes")
