@@ -152,7 +152,8 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
     }
     // PF register sets: the global loads of the next PF K steps are in flight while one step is computed.  PF = 2 was tried on
     // the small tiles (K = 192..576, 3..9 steps) and LOST inside the training step (fc1+gelu of the outlooker 96 -> 111 us,
-    // 192x576 plain 40.6 -> 45.3): the extra 16-32 VGPRs cost a wave per SIMD and latency was not the limit.  Default 1.
+    // 192x576 plain 40.6 -> 45.3), and on the 128x128 tile (38.9 -> 64.6 us on the dfc1 shape): the extra 16-32 VGPRs cost a
+    // wave (or two) per SIMD, and three co-resident workgroups already keep three K steps of loads in flight.  Default 1.
     u32x4 ra0[NA], rb0[NB], ra1[PF > 1 ? NA : 1], rb1[PF > 1 ? NB : 1];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     auto gload = [&](u32x4* ra, u32x4* rb, int k0) {
