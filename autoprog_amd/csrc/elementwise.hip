@@ -76,18 +76,31 @@ __global__ void k_add_bcast(const bf16_t* __restrict__ a, const bf16_t* __restri
         st16(y + 8 * i, pack8(fa));
     }
 }
+// out[i] += sum_r x[r][i]: the repetitions are split over blockIdx.y (16 per workgroup, 8 loads in flight per thread) and the
+// partial sums meet in fp32 atomics -- one thread walking all 128 repetitions serially took 61 us for 19 MB
+#define SR_CHUNK 16
 __global__ void k_sum_reps_acc(const bf16_t* __restrict__ x, float* __restrict__ out, int64_t nv, int reps) {
+    const int r0 = blockIdx.y * SR_CHUNK, r1 = min(reps, r0 + SR_CHUNK);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int r = 0; r < reps; ++r) {
-            float f[8];
-            unpack8(ld16(x + 8 * (r * nv + i)), f);
+        for (int r = r0; r < r1; r += 8) {
+            u32x4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += f[j];
+            for (int u = 0; u < 8; ++u) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                v[u] = (r + u < r1) ? ld16(x + 8 * ((int64_t)(r + u) * nv + i)) : z;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float f[8];
+                unpack8(v[u], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += f[j];
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) out[8 * i + j] += acc[j];
+        for (int j = 0; j < 8; ++j) atomicAdd(out + 8 * i + j, acc[j]);
     }
 }
 
@@ -248,7 +261,7 @@ int ap_sum_reps_acc(const ap_bf16* x, float* out, int64_t n, int reps, ap_stream
     if ((n & 7) || reps <= 0) return AP_ERR_SHAPE;
     if (n == 0) return AP_OK;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_sum_reps_acc, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, x, out, n / 8, reps);
+    hipLaunchKernelGGL(k_sum_reps_acc, dim3(grid_for(n / 8), (reps + SR_CHUNK - 1) / SR_CHUNK), dim3(256), 0, (hipStream_t)stream, x, out, n / 8, reps);
     return ap_check_launch();
 }
 int ap_mix_token_swap(const ap_bf16* x, ap_bf16* y, int B, int H, int W, int C, int r0, int r1, int c0, int c1, ap_stream_t stream) {
