@@ -389,3 +389,42 @@ def test_experimental_kernel_paths_stay_parity_green(env):
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", sel] + files, cwd=root, env=dict(os.environ, **env),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+
+
+def test_c_abi_error_codes_and_empty_inputs(ops):
+    """the raw C ABI: negative codes instead of exceptions or crashes for null pointers (-4), shape / stride violations (-1),
+    configurations the gfx950 kernels do not cover (-2); empty problems are accepted where the header says so"""
+    import ctypes
+    from autoprog_amd._lib import lib, TnProblem
+    x = torch.zeros(64, 64, dtype=torch.bfloat16, device="cuda")
+    f = torch.zeros(64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: t.data_ptr()
+    eps = ctypes.c_float(1e-5)
+    assert lib.ap_error_string(-1) and lib.ap_error_string(-2) and lib.ap_error_string(-4) and lib.ap_error_string(0) == b"ok"
+    # LayerNorm
+    assert lib.ap_layernorm_fwd(None, P(f), P(f), P(x), P(f), P(f), 64, 64, eps, st) == -4
+    assert lib.ap_layernorm_fwd(P(x), P(f), P(f), P(x), P(f), P(f), 64, 60, eps, st) == -1          # C not a multiple of 8
+    assert lib.ap_layernorm_fwd(P(x), P(f), P(f), P(x), P(f), P(f), 1, 4096, eps, st) == -2          # C > 2048
+    assert lib.ap_layernorm_fwd(P(x), P(f), P(f), P(x), P(f), P(f), 0, 64, eps, st) == 0             # no rows: nothing to do
+    # GEMMs
+    assert lib.ap_gemm_nt(P(x), 64, None, 64, P(x), 64, 64, 64, 64, None, st) == -4
+    assert lib.ap_gemm_nt(P(x), 64, P(x), 64, P(x), 64, 64, 64, 60, None, st) == -1                  # K not a multiple of 8
+    assert lib.ap_gemm_nt(P(x), 32, P(x), 64, P(x), 64, 64, 64, 64, None, st) == -1                  # lda < K
+    assert lib.ap_gemm_nt(P(x), 64, P(x), 64, P(x), 64, 0, 64, 64, None, st) == -1                   # empty M is a caller error here
+    c = torch.zeros(64, 64, device="cuda")
+    assert lib.ap_gemm_tn_acc(P(x), 64, P(x), 64, P(c), 32, 64, 64, 64, None, st) == -1              # ldc < N2
+    assert lib.ap_gemm_tn_acc_grouped(None, 1, st) == -4
+    arr = (TnProblem * 1)()
+    arr[0].A, arr[0].lda, arr[0].B, arr[0].ldb, arr[0].C, arr[0].ldc = P(x), 64, P(x), 64, P(c), 64
+    arr[0].M, arr[0].N1, arr[0].N2, arr[0].colsum_A = 64, 64, 64, None
+    assert lib.ap_gemm_tn_acc_grouped(ctypes.cast(arr, ctypes.c_void_p), 0, st) == -1               # empty group
+    assert lib.ap_gemm_tn_acc_grouped(ctypes.cast(arr, ctypes.c_void_p), 9, st) == -1               # > AP_TN_MAX_GROUP
+    assert lib.ap_gemm_tn_acc_grouped(ctypes.cast(arr, ctypes.c_void_p), 1, st) == 0
+    # attention
+    q = torch.zeros(2 * 16, 3 * 48, dtype=torch.bfloat16, device="cuda")
+    assert lib.ap_mhsa_fwd(P(q), P(q), P(f), 2, 16, 1, 48, ctypes.c_float(0.1), st) == -2               # head_dim 48
+    assert lib.ap_mhsa_fwd(P(q), P(q), P(f), 1, 300, 1, 32, ctypes.c_float(0.1), st) == -2              # more than 256 tokens
+    assert lib.ap_mhsa_fwd(P(q), None, P(f), 2, 16, 1, 32, ctypes.c_float(0.1), st) == -4
+    assert lib.ap_outlook_fwd(P(x), P(x), 88, P(x), 1, 8, 8, 1, 16, ctypes.c_float(0.25), st) == -2     # outlook head_dim != 32
+    torch.cuda.synchronize()                                                                          # nothing above may have faulted
