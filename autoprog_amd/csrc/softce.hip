@@ -26,8 +26,20 @@ k_soft_ce(const bf16_t* __restrict__ logits, int ldx, const float* __restrict__ 
     {
         const int tn = threadIdx.x & (CE_TN - 1), cl = threadIdx.x / CE_TN;     // 16 classes per pass
         const float* tb = target + b * t_sb + (int64_t)(n0 + tn) * t_sn;
-        for (int c = cl; c < C; c += 256 / CE_TN) {
-            if (tn < ntok) tt[tn * Cp + c] = tb[(int64_t)c * t_sc];
+        // 8 independent loads in flight per thread (the one-load-per-iteration loop waited a full memory latency 63 times)
+        constexpr int CSTEP = 256 / CE_TN;
+        for (int c0 = cl; c0 < C; c0 += 8 * CSTEP) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u * CSTEP;
+                v[u] = (tn < ntok && c < C) ? tb[(int64_t)c * t_sc] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u * CSTEP;
+                if (tn < ntok && c < C) tt[tn * Cp + c] = v[u];
+            }
         }
     }
     __syncthreads();
