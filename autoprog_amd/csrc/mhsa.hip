@@ -78,15 +78,32 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// stage rows [0,Npad) of one [N, ld] strided matrix slice (HD columns) into a swizzled LDS tile
-template <int HD>
-__device__ __forceinline__ void att_stage(bf16_t* tile, const bf16_t* src, int64_t ld, int N, int Npad) {
+// Stage NTILES token-major operands ([N, HD] slices with row stride ld[i]) into their LDS tiles.  ALL global loads of a thread
+// (up to MAXIT iterations x NTILES tiles) are issued before the first LDS store: the former one-load-then-store loop, called
+// once per tile, exposed a full memory latency per iteration (8 of them in the backward kernel).
+template <int HD, int NTILES, int MAXIT>
+__device__ __forceinline__ void att_stage_n(bf16_t* const* tiles, const bf16_t* const* srcs, const int64_t* lds, int N, int Npad) {
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     constexpr int CH = HD / 8;
-    for (int idx = threadIdx.x; idx < Npad * CH; idx += blockDim.x) {
-        const int row = idx / CH, c = idx % CH;
-        const u32x4 v = (row < N) ? ld16(src + (int64_t)row * ld + c * 8) : zero4;
-        st16(tile + att_off<HD>(row, c), v);
+    const int total = Npad * CH;
+    for (int idx0 = threadIdx.x; idx0 < total; idx0 += MAXIT * blockDim.x) {
+        u32x4 v[MAXIT][NTILES];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int idx = idx0 + it * blockDim.x;
+            const int row = idx / CH, c = idx % CH;
+#pragma unroll
+            for (int t = 0; t < NTILES; ++t) v[it][t] = (idx < total && row < N) ? ld16(srcs[t] + (int64_t)row * lds[t] + c * 8) : zero4;
+        }
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int idx = idx0 + it * blockDim.x;
+            if (idx < total) {
+                const int row = idx / CH, c = idx % CH;
+#pragma unroll
+                for (int t = 0; t < NTILES; ++t) st16(tiles[t] + att_off<HD>(row, c), v[it][t]);
+            }
+        }
     }
 }
 
@@ -104,8 +121,12 @@ k_mhsa_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __re
     const int C = heads * HD;
     const int64_t ld = 3 * C;
     const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
-    att_stage<HD>(Ks, base + C, ld, N, Npad);
-    att_stage<HD>(Vs, base + 2 * C, ld, N, Npad);
+    {
+        bf16_t* tiles[2] = {Ks, Vs};
+        const bf16_t* srcs[2] = {base + C, base + 2 * C};
+        const int64_t strides[2] = {ld, ld};
+        att_stage_n<HD, 2, 4>(tiles, srcs, strides, N, Npad);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
     const float c2 = scale * 1.4426950408889634f;
@@ -200,10 +221,12 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
     const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
     const bf16_t* obase = out + (int64_t)b * N * C + h * HD;
     const bf16_t* gbase = dout + (int64_t)b * N * C + h * HD;
-    att_stage<HD>(Qs, base, ld, N, Npad);
-    att_stage<HD>(Ks, base + C, ld, N, Npad);
-    att_stage<HD>(Vs, base + 2 * C, ld, N, Npad);
-    att_stage<HD>(Gs, gbase, C, N, Npad);
+    {
+        bf16_t* tiles[4] = {Qs, Ks, Vs, Gs};
+        const bf16_t* srcs[4] = {base, base + C, base + 2 * C, gbase};
+        const int64_t strides[4] = {ld, ld, ld, (int64_t)C};
+        att_stage_n<HD, 4, 2>(tiles, srcs, strides, N, Npad);
+    }
     for (int idx = threadIdx.x; idx < Npad * CH; idx += 512) {     // Npad*CH is a multiple of 128: whole waves
         const int row = idx / CH, c = idx % CH;
         float part = 0.f;
