@@ -227,21 +227,40 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
         const int64_t strides[4] = {ld, ld, ld, (int64_t)C};
         att_stage_n<HD, 4, 2>(tiles, srcs, strides, N, Npad);
     }
-    for (int idx = threadIdx.x; idx < Npad * CH; idx += 512) {     // Npad*CH is a multiple of 128: whole waves
-        const int row = idx / CH, c = idx % CH;
-        float part = 0.f;
-        if (row < N) {
-            float a[8], d[8];
-            unpack8(ld16(obase + (int64_t)row * C + c * 8), a);
-            unpack8(ld16(gbase + (int64_t)row * C + c * 8), d);
+    // delta = rowsum(dO * O) and the scaled lse: both iterations' loads are issued before anything is reduced
+    {
+        constexpr int DIT = 2;
+        const u32x4 zero4 = {0u, 0u, 0u, 0u};
+        for (int idx0 = threadIdx.x; idx0 < Npad * CH; idx0 += DIT * 512) {     // Npad*CH is a multiple of 128: whole waves
+            u32x4 va[DIT], vd[DIT];
+            float ls[DIT];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) part += a[k] * d[k];
-        }
+            for (int it = 0; it < DIT; ++it) {
+                const int idx = idx0 + it * 512;
+                const int row = idx / CH, c = idx % CH;
+                const bool ok = idx < Npad * CH && row < N;
+                va[it] = ok ? ld16(obase + (int64_t)row * C + c * 8) : zero4;
+                vd[it] = ok ? ld16(gbase + (int64_t)row * C + c * 8) : zero4;
+                ls[it] = (ok && c == 0) ? lse[((int64_t)b * heads + h) * N + row] : 0.f;
+            }
 #pragma unroll
-        for (int o = 1; o < CH; o <<= 1) part += __shfl_xor(part, o, 64);
-        if (c == 0) {
-            fd[row] = part;
-            fl[row] = (row < N) ? lse[((int64_t)b * heads + h) * N + row] * 1.4426950408889634f : 1.0e30f;
+            for (int it = 0; it < DIT; ++it) {
+                const int idx = idx0 + it * 512;
+                if (idx >= Npad * CH) continue;                                   // wave-uniform (whole waves)
+                const int row = idx / CH, c = idx % CH;
+                float a[8], d[8];
+                unpack8(va[it], a);
+                unpack8(vd[it], d);
+                float part = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) part += a[k] * d[k];
+#pragma unroll
+                for (int o = 1; o < CH; o <<= 1) part += __shfl_xor(part, o, 64);
+                if (c == 0) {
+                    fd[row] = part;
+                    fl[row] = (row < N) ? ls[it] * 1.4426950408889634f : 1.0e30f;
+                }
+            }
         }
     }
     __syncthreads();

@@ -32,32 +32,57 @@ __device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float acc) {
 __device__ __forceinline__ void stage_patch(bf16_t* patch, const bf16_t* src, int H, int W, int C, int y0, int rows, int pw, int npix, int nthreads) {
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const int total = rows * pw * 4;
-    for (int idx = threadIdx.x; idx < total; idx += nthreads) {
-        const int c = idx & 3, pix = idx >> 2;
-        const int pr = pix / pw, pc = pix - pr * pw;
-        const int y = y0 + pr, x = pc - 1;
-        const bool in = (y >= 0) & (y < H) & (x >= 0) & (x < W);
-        const u32x4 v = in ? ld16(src + ((int64_t)y * W + x) * C + c * 8) : zero4;
-        st16(patch + (c * npix + pix) * 8, v);
+    constexpr int SU = 4;               // loads in flight per thread (one load -> one LDS store per iteration exposed a latency each)
+    for (int idx0 = threadIdx.x; idx0 < total; idx0 += SU * nthreads) {
+        u32x4 v[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int idx = idx0 + u * nthreads;
+            const int c = idx & 3, pix = idx >> 2;
+            const int pr = pix / pw, pc = pix - pr * pw;
+            const int y = y0 + pr, x = pc - 1;
+            const bool in = (idx < total) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
+            v[u] = in ? ld16(src + ((int64_t)y * W + x) * C + c * 8) : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int idx = idx0 + u * nthreads;
+            if (idx < total) st16(patch + ((idx & 3) * npix + (idx >> 2)) * 8, v[u]);
+        }
     }
 }
 
 // softmax rows of the windows [wy0, wy0+nwr) x [0,w) of one head -> fp32 P[win][9][9]
 __device__ __forceinline__ void stage_probs(float* P, const bf16_t* logits, int ldl, int64_t win_base, int w, int nwin,
                                             int head, float scale, int nthreads) {
-    for (int r = threadIdx.x; r < nwin * OKK; r += nthreads) {
-        const int wl = r / OKK, p = r - wl * OKK;
-        const bf16_t* a = logits + (win_base + wl) * ldl + head * OPP + p * OKK;
+    // the 9 logits of up to PU rows per thread are loaded before the first softmax (rows are independent)
+    constexpr int PU = 3;
+    for (int r0 = threadIdx.x; r0 < nwin * OKK; r0 += PU * nthreads) {
+        unsigned short raw[PU][OKK];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int r = r0 + u * nthreads;
+            const int rc = min(r, nwin * OKK - 1);
+            const int wl = rc / OKK, p = rc - wl * OKK;
+            const bf16_t* a = logits + (win_base + wl) * ldl + head * OPP + p * OKK;
+#pragma unroll
+            for (int q = 0; q < OKK; ++q) raw[u][q] = a[q];
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+        const int r = r0 + u * nthreads;
+        if (r >= nwin * OKK) continue;
         float s[OKK];
         float mx = -3.0e38f;
 #pragma unroll
-        for (int q = 0; q < OKK; ++q) { s[q] = bf2f(a[q]) * scale; mx = fmaxf(mx, s[q]); }
+        for (int q = 0; q < OKK; ++q) { s[q] = bf2f(raw[u][q]) * scale; mx = fmaxf(mx, s[q]); }
         float sum = 0.f;
 #pragma unroll
         for (int q = 0; q < OKK; ++q) { s[q] = __expf(s[q] - mx); sum += s[q]; }
         const float inv = 1.0f / sum;
 #pragma unroll
         for (int q = 0; q < OKK; ++q) P[r * OKK + q] = s[q] * inv;
+        }
     }
 }
 
