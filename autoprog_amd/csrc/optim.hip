@@ -86,10 +86,14 @@ k_batched_transpose(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, co
     const int lt = t - d.first_tile;
     const int r0 = (lt / tiles_c) * 32, c0 = (lt % tiles_c) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8) {
-        const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < d.rows && c < d.cols) ? src[d.src_off + (long long)r * d.cols + c] : (bf16_t)0;
+    bf16_t v[4];                                  // all four loads of the thread before the first LDS store
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int r = r0 + ty + 8 * u, c = c0 + tx;
+        v[u] = (r < d.rows && c < d.cols) ? src[d.src_off + (long long)r * d.cols + c] : (bf16_t)0;
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) tile[ty + 8 * u][tx] = v[u];
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + tx;
