@@ -156,12 +156,22 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
     // wave (or two) per SIMD, and three co-resident workgroups already keep three K steps of loads in flight.  Default 1.
     u32x4 ra0[NA], rb0[NB], ra1[PF > 1 ? NA : 1], rb1[PF > 1 ? NB : 1];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // K % 64 == 0 (every Linear of the models except the 1000-class heads): unconditional loads.  The per-lane `ok ? load : 0`
+    // of the ragged-K path compiles to one exec-masked branch block with 8 register zeroings per load pair.
+    const bool kfull = (K & (SBK - 1)) == 0;
     auto gload = [&](u32x4* ra, u32x4* rb, int k0) {
-        const bool ok = (k0 + kc * 8) < K;
+        if (kfull) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = ok ? ld16(ga[i] + k0) : zero4;
+            for (int i = 0; i < NA; ++i) ra[i] = ld16(ga[i] + k0);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = ok ? ld16(gb[i] + k0) : zero4;
+            for (int i = 0; i < NB; ++i) rb[i] = ld16(gb[i] + k0);
+        } else {
+            const bool ok = (k0 + kc * 8) < K;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = ok ? ld16(ga[i] + k0) : zero4;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] = ok ? ld16(gb[i] + k0) : zero4;
+        }
     };
 
     f32x4 acc[NT][MT];
@@ -781,7 +791,21 @@ __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, c
     // (rocprof: 1.4 waves/SIMD resident, 42 % of wave cycles parked waiting for the single prefetch)
     u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // full token steps: unconditional loads; the guarded form compiles to an exec-masked branch block with register zeroing
+    // around every load
+    // (columns beyond N1 / N2 only feed output rows / columns that are never stored: their chunk index is clamped into the
+    // row instead of being guarded, so ragged tiles -- N = 192, 486, 576 -- take the fast path too)
+    const int ca = min(n0 + j * 8, lda - 8), cb = min(k0 + j * 8, ldb - 8);
     auto gload = [&](u32x4* ra, u32x4* rb, int step) {
+        if (step < step_end && (step + 1) * TM <= M) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = step * TM + srow + 16 * i;
+                ra[i] = ld16(A + (int64_t)m * lda + ca);
+                rb[i] = ld16(B + (int64_t)m * ldb + cb);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = step * TM + srow + 16 * i;
