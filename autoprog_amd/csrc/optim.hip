@@ -7,6 +7,7 @@
 
 struct AdamArgs {
     float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt;   // bc1 = 1-beta1^t, bc2_sqrt = sqrt(1-beta2^t)
+    float gscale;                                      // gradient pre-scale (1/world_size: the data-parallel mean)
     int n_ema;
     float decay[4];
     float* ema[4];
@@ -20,7 +21,8 @@ k_adamw_ema(float* __restrict__ p, const float* __restrict__ g, float* __restric
     const float step_size = a.lr / a.bc1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
-        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 gg = reinterpret_cast<const float4*>(g)[i];
+        gg.x *= a.gscale; gg.y *= a.gscale; gg.z *= a.gscale; gg.w *= a.gscale;
         float4 mm = reinterpret_cast<float4*>(m)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
         const uchar4 wm = reinterpret_cast<const uchar4*>(wd_mask)[i];
@@ -53,12 +55,12 @@ k_adamw_ema(float* __restrict__ p, const float* __restrict__ g, float* __restric
 }
 
 extern "C" int ap_adamw_ema_step(float* p, const float* g, float* m, float* v, const unsigned char* wd_mask, int64_t n,
-                                 float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                                  float* const* ema, const float* ema_decay, int n_ema, ap_bf16* p_bf16, ap_stream_t stream) {
     if (!p || !g || !m || !v || !wd_mask) return AP_ERR_NULL;
     if (n <= 0 || (n & 3) || n_ema < 0 || n_ema > 4 || step < 1) return AP_ERR_SHAPE;
     AdamArgs a;
-    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.gscale = grad_scale;
     a.bc1 = 1.0f - powf(beta1, (float)step);
     a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
     a.n_ema = n_ema;

@@ -17,7 +17,11 @@ import torch.distributed as dist
 
 
 class GradientBucketReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, world_size=None):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, world_size=None, defer_mean=False):
+        """defer_mean: finish() leaves the all-reduced SUM in the slab and the consumer applies 1/world itself
+        (optim.FlatAdamWEma folds it into the fused update kernel via take_pending_scale(): no extra pass over the slab)."""
+        self.defer_mean = defer_mean
+        self._pending_scale = 1.0
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
@@ -48,10 +52,18 @@ class GradientBucketReducer:
         self._seen = set()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.world > 1 else []
         self._owned = {id(p) for p in self.params}
+        self._no_sink = set()
 
     # ------------------------------------------------------------------ gradient sink (functional.set_grad_sink)
     def owns(self, p):
-        return id(p) in self._owned and p.grad is not None
+        return id(p) in self._owned and id(p) not in self._no_sink and p.grad is not None
+
+    def exclude_from_sink(self, params):
+        """parameters used MORE THAN ONCE per forward (VOLO applies `norm` to the class token and to the tokens) must not be
+        delivered through the sink: the first backward use would mark them ready and a small bucket's all-reduce could start
+        before the second use has accumulated.  Their gradients go through autograd, which sums every use and then fires
+        the post-accumulate hook exactly once."""
+        self._no_sink.update(id(p) for p in params)
 
     def needs_stream_join(self):
         """with more than one rank a ready parameter may trigger a bucket all-reduce right away"""
@@ -61,10 +73,13 @@ class GradientBucketReducer:
         if self.world > 1:
             self._on_grad(p)
 
-    def install_sink(self):
+    def install_sink(self, model=None):
         """let the fused block backward passes accumulate straight into the slab (no per-parameter
-        temporaries, no autograd add kernels)"""
+        temporaries, no autograd add kernels).  `model.multi_use_parameters()` (when present) names the
+        parameters that stay on the autograd path (see exclude_from_sink)."""
         from . import functional
+        if model is not None and hasattr(model, "multi_use_parameters"):
+            self.exclude_from_sink(model.multi_use_parameters())
         functional.set_grad_sink(self)
 
     def uninstall_sink(self):
@@ -109,7 +124,15 @@ class GradientBucketReducer:
                 self._launch(b)
         for h in self._handles:
             h.wait()
-        self.flat.mul_(1.0 / self.world)
+        if self.defer_mean:
+            self._pending_scale = 1.0 / self.world
+        else:
+            self.flat.mul_(1.0 / self.world)
+
+    def take_pending_scale(self):
+        """factor that still has to be applied to the slab (1/world after a deferred-mean finish(), else 1); reading resets it"""
+        s, self._pending_scale = self._pending_scale, 1.0
+        return s
 
     def remove(self):
         self.uninstall_sink()

@@ -22,7 +22,10 @@ BF16 = torch.bfloat16
 # ------------------------------------------------------------------------------ weight bank
 class _WeightBank:
     """bf16 (and transposed bf16) copies of fp32 Linear weights, refreshed when the parameter's
-    storage or version counter changes (i.e. after optimizer.step() / load_state_dict()).  Replaces
+    storage or version counter changes (i.e. after optimizer.step() / load_state_dict()); the
+    copies maintained by optim.FlatAdamWEma are trusted only while the parameter's version
+    counter equals the one stamped at their last refresh (an in-place write from outside --
+    load_state_dict, manual edits -- falls back to the keyed path until FlatAdamWEma.resync()).  Replaces
     apex's per-call casts.  The copies are stored ON the Parameter object, so they can never
     outlive it or be confused with another parameter that reuses its address."""
 
@@ -41,7 +44,7 @@ class _WeightBank:
         if not isinstance(p, torch.nn.Parameter):      # derived tensor (e.g. permuted conv weight): no caching
             return ops.cast_bf16(self._flat(p))
         flat = getattr(p, "_ap_flat16", None)          # kept current by optim.FlatAdamWEma (no cast kernels at all)
-        if flat is not None and flat[0] == p.data_ptr():
+        if flat is not None and flat[0] == p.data_ptr() and flat[3] == p._version:
             return flat[1]
         ent = getattr(p, "_ap_bf16", None)
         key = self._key(p)
@@ -54,7 +57,7 @@ class _WeightBank:
         if not isinstance(p, torch.nn.Parameter):
             return ops.cast_transpose_bf16(self._flat(p))
         flat = getattr(p, "_ap_flat16", None)
-        if flat is not None and flat[0] == p.data_ptr() and flat[2] is not None:
+        if flat is not None and flat[0] == p.data_ptr() and flat[3] == p._version and flat[2] is not None:
             return flat[2]
         ent = getattr(p, "_ap_bf16_t", None)
         key = self._key(p)

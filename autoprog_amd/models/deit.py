@@ -9,6 +9,7 @@ from functools import partial
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import functional as AF
 from ..prog.helpers import get_new_layer_idx
@@ -107,12 +108,28 @@ class VisionTransformer(nn.Module):
             blk.set_sample_config(is_identity_layer=i in skip)
         return skip
 
+    def interpolate_pos_encoding(self, n_patches, n_extra):
+        """elastic resolution for AutoProg-DeiT (BASELINE configs[3]: r in {128..224}; build-defined): the
+        class / distillation embeddings are kept, the patch-grid part is resized exactly like VOLO.interpolate_pos_encoding
+        (models/volo.py:580-596: bicubic, scale_factor (g+0.1)/g0)."""
+        g0 = int(round((self.pos_embed.shape[1] - n_extra) ** 0.5))
+        g = int(round(n_patches ** 0.5))
+        if g == g0:
+            return self.pos_embed
+        D = self.pos_embed.shape[-1]
+        grid = self.pos_embed[:, n_extra:].reshape(1, g0, g0, D).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid, scale_factor=((g + 0.1) / g0, (g + 0.1) / g0), mode="bicubic")
+        assert grid.shape[-1] == g and grid.shape[-2] == g
+        return torch.cat([self.pos_embed[:, :n_extra], grid.permute(0, 2, 3, 1).reshape(1, g * g, D)], dim=1)
+
     def _tokens(self, x, extra):
         B = x.shape[0]
         x = self.patch_embed(x)
+        n_patches = x.shape[1]
         toks = [self.cls_token.expand(B, -1, -1).to(BF16)] + [t.expand(B, -1, -1).to(BF16) for t in extra]
         x = torch.cat(toks + [x], dim=1)
-        return AF.AddPosFn.apply(x.unsqueeze(1), self.pos_embed.unsqueeze(1)).squeeze(1)
+        pos = self.interpolate_pos_encoding(n_patches, 1 + len(extra))
+        return AF.AddPosFn.apply(x.unsqueeze(1), pos.unsqueeze(1)).squeeze(1)
 
     def forward_features(self, x):
         x = self._tokens(x, [])

@@ -448,6 +448,11 @@ class VOLO(nn.Module):
     def no_weight_decay(self):
         return {"pos_embed", "cls_token"}
 
+    def multi_use_parameters(self):
+        """parameters applied more than once per forward (the final LayerNorm runs on the class token and on the tokens,
+        models/volo.py:676-680): dist.GradientBucketReducer keeps them on the autograd path"""
+        return [self.norm.weight, self.norm.bias] if self.post_network is not None else []
+
     def get_classifier(self):
         return self.head
 

@@ -17,7 +17,11 @@ class FlatAdamWEma:
     def __init__(self, model, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, ema_decays=()):
         assert len(ema_decays) <= 4
         self.model, self.reducer = model, reducer
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.betas, self.eps = betas, eps
+        # torch.optim-style groups (timm's create_optimizer layout: decayed, then un-decayed parameters).  step() reads
+        # `lr` / `weight_decay` from here every call, so timm LR schedulers that write param_groups[i]["lr"] work unchanged.
+        self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "betas": betas, "eps": eps, "params": []},
+                             {"lr": lr, "weight_decay": 0.0, "betas": betas, "eps": eps, "params": []}]
         self.ema_decays = list(ema_decays)
         self.step_count = 0
         flat_g = reducer.flat
@@ -38,8 +42,9 @@ class FlatAdamWEma:
             p.data = view                                   # parameters now live in the slab
             name = names.get(id(p), "")
             decay = not (p.dim() == 1 or name.endswith(".bias") or name in skip)
-            if decay and weight_decay > 0:
+            if decay:
                 self.wd_mask[off:off + p.numel()] = 1
+            self.param_groups[0 if decay else 1]["params"].append(p)
             self._views.append((name, off, p.shape))
         self.m = torch.zeros_like(self.p)
         self.v = torch.zeros_like(self.p)
@@ -66,12 +71,54 @@ class FlatAdamWEma:
         self.p16.copy_(self.p)                                   # initial fill (torch cast, once)
         for p, (name, off, shape) in zip(reducer.params, self._views):
             rows = shape[0] if len(shape) else 1
-            p._ap_flat16 = (p.data_ptr(), self.p16[off:off + p.numel()].view(rows, -1) if p.dim() >= 2 else None, None)
+            p._ap_flat16 = [p.data_ptr(), self.p16[off:off + p.numel()].view(rows, -1) if p.dim() >= 2 else None, None, p._version]
         for p, off, rows, cols, ld, toff in mats:
-            p._ap_flat16 = (p.data_ptr(), self.p16[off:off + rows * cols].view(rows, cols), self.p16_t[toff:toff + cols * ld].view(cols, ld))
+            p._ap_flat16 = [p.data_ptr(), self.p16[off:off + rows * cols].view(rows, cols), self.p16_t[toff:toff + cols * ld].view(cols, ld), p._version]
         self._refresh_transposes()
-        self._buffers = [b for b in model.buffers() if b.dtype.is_floating_point]
+        self._float_buffers = [(n_, b) for n_, b in model.named_buffers() if b.dtype.is_floating_point]
+        self._buffers = [b for _, b in self._float_buffers]
         self.ema_buffers = [[b.detach().clone() for b in self._buffers] for _ in self.ema_decays]
+        # model.load_state_dict() copies INTO the slab views (pointers unchanged): re-derive the bf16 copies afterwards
+        self._load_hook = model.register_load_state_dict_post_hook(lambda module, incompatible: self.resync())
+
+    # ------------------------------------------------------------------ properties kept for callers of the round-1 API
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, v):
+        for g in self.param_groups:
+            g["lr"] = v
+
+    @property
+    def weight_decay(self):
+        return self.param_groups[0]["weight_decay"]
+
+    def _stamp_versions(self):
+        for p in self.reducer.params:
+            p._ap_flat16[3] = p._version
+
+    def resync(self, reset_ema=False, reset_moments=False):
+        """re-derive the bf16 / transposed weight copies from the fp32 slab after the parameters were written from outside
+        (load_state_dict, grow_clone_ema / extract_subnet, manual edits); optionally restart the EMA copies at the new weights
+        (the reference rebuilds its ModelEma list after a stage transition, main_prog.py:1406) and zero the Adam moments."""
+        with torch.no_grad():
+            self.p16.copy_(self.p)
+            self._refresh_transposes()
+            if reset_ema:
+                for e in self.ema:
+                    e.copy_(self.p)
+                for bufs in self.ema_buffers:
+                    for dst, src in zip(bufs, self._buffers):
+                        dst.copy_(src)
+            if reset_moments:
+                self.m.zero_()
+                self.v.zero_()
+                self.step_count = 0
+        self._stamp_versions()
+        from . import functional
+        functional._WeightBank.generation += 1
 
     def _refresh_transposes(self):
         if self._tr_desc is not None:
@@ -85,8 +132,11 @@ class FlatAdamWEma:
             gp = torch.zeros(self.n_pad, dtype=torch.float32, device=g.device)
             gp[:g.numel()] = g
             g = gp
+        lr, wd = float(self.param_groups[0]["lr"]), float(self.param_groups[0]["weight_decay"])
+        if float(self.param_groups[1]["lr"]) != lr:
+            raise ValueError("FlatAdamWEma: both parameter groups must share one learning rate (timm schedulers do)")
         check(lib.ap_adamw_ema_step(self.p.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.wd_mask.data_ptr(),
-                                    self.n_pad, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
+                                    self.n_pad, lr, self.betas[0], self.betas[1], self.eps, wd, self.step_count, float(self.reducer.take_pending_scale()),
                                     self._ema_ptrs, self._ema_decay, len(self.ema), self.p16.data_ptr(),
                                     torch.cuda.current_stream().cuda_stream), "ap_adamw_ema_step")
         self._refresh_transposes()
@@ -97,9 +147,63 @@ class FlatAdamWEma:
                 for d, bufs in zip(self.ema_decays, self.ema_buffers):
                     torch._foreach_lerp_(bufs, self._buffers, 1.0 - d)
 
+    def zero_grad(self, set_to_none=False):
+        """gradients are views of the reducer's slab and stay attached (prog/scaler.py:60-68 step contract)"""
+        self.reducer.zero_grad()
+
     def ema_state_dict(self, i):
-        """name -> tensor views of EMA copy i (checkpoint format `state_dict_ema_{i}`, prog/checkpoint_saver.py:110-130)"""
-        out = {name: self.ema[i][off:off + int(torch.tensor(shape).prod())].view(shape) for name, off, shape in self._views}
-        for (bname, _), t in zip(self.model.named_buffers(), self.ema_buffers[i] if self.ema_buffers else []):
-            out[bname] = t
+        """name -> tensor of EMA copy i in the checkpoint format `state_dict_ema_{i}` (prog/checkpoint_saver.py:110-130): parameters
+        are views of the EMA slab, floating-point buffers (BatchNorm running stats) the lerp-averaged copies, integer buffers
+        (num_batches_tracked) the model's current value -- as ModelEmaV2 keeps them."""
+        out = {}
+        for name, off, shape in self._views:
+            n = 1
+            for d in shape:
+                n *= d
+            out[name] = self.ema[i][off:off + n].view(shape)
+        ema_b = dict(zip((n for n, _ in self._float_buffers), self.ema_buffers[i])) if self.ema_buffers else {}
+        for bname, b in self.model.named_buffers():
+            out[bname] = ema_b[bname] if bname in ema_b else b.detach().clone()
         return out
+
+    # ------------------------------------------------------------------ checkpointing (prog/checkpoint_saver.py:115 calls optimizer.state_dict())
+    def state_dict(self):
+        """torch.optim.AdamW layout: {"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]} with parameter indices
+        in group order, plus the EMA slabs under "ema" (the reference keeps those in separate ModelEma objects)."""
+        state, groups, idx = {}, [], 0
+        offs = {id(p): off for p, (_, off, _) in zip(self.reducer.params, self._views)}
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                off, n = offs[id(p)], p.numel()
+                state[idx] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.m[off:off + n].view_as(p).clone(),
+                              "exp_avg_sq": self.v[off:off + n].view_as(p).clone()}
+                ids.append(idx)
+                idx += 1
+            groups.append({k: v for k, v in g.items() if k != "params"} | {"params": ids})
+        return {"state": state, "param_groups": groups, "ema": [e.clone() for e in self.ema],
+                "ema_buffers": [[b.clone() for b in bufs] for bufs in self.ema_buffers]}
+
+    def load_state_dict(self, sd):
+        offs = {id(p): off for p, (_, off, _) in zip(self.reducer.params, self._views)}
+        idx = 0
+        with torch.no_grad():
+            for g, saved in zip(self.param_groups, sd["param_groups"]):
+                for k, v in saved.items():
+                    if k != "params":
+                        g[k] = v
+                if len(saved["params"]) != len(g["params"]):
+                    raise ValueError("FlatAdamWEma.load_state_dict: parameter group sizes differ")
+                for p in g["params"]:
+                    st = sd["state"].get(idx)
+                    if st is not None:
+                        off, n = offs[id(p)], p.numel()
+                        self.m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                        self.v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                        self.step_count = int(st["step"])
+                    idx += 1
+            for dst, src in zip(self.ema, sd.get("ema", [])):
+                dst.copy_(src)
+            for bufs, saved in zip(self.ema_buffers, sd.get("ema_buffers", [])):
+                for dst, src in zip(bufs, saved):
+                    dst.copy_(src)

@@ -80,6 +80,21 @@ def cpu_baseline(variant, res, seconds_budget, threads):
             "sample": "oracle/ref_cpu.py fp32 fwd+loss+bwd, %s %dpx, batch %d, %d steps in %.1fs (no optimizer)" % (variant, res, B, n_steps, dt)}
 
 
+def self_launch(n, argv):
+    """start `torch.distributed.run --nproc-per-node n bench.py <argv>` as a child and return its exit code"""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL needs it on this driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 class GemmProbe:
     """HIP-event timing of every ap_gemm_nt launch (events recorded on the launch stream)"""
 
@@ -146,6 +161,10 @@ def main():
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+loss+backward only")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (reference: distributed_train_prog.sh:4 starts its 8 ranks the same
+        # way).  Nothing in this process has touched the GPU yet; the ranks are CHILD processes (never an exec of this one).
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -181,7 +200,7 @@ def main():
             dist.broadcast(t.data, src=0)
     loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=1000)
     reducer = GradientBucketReducer(list(model.parameters()), world_size=world)
-    reducer.install_sink()
+    reducer.install_sink(model)
     from autoprog_amd.optim import FlatAdamWEma
     ema_decays = [0.998, 0.9986, 0.999, 0.9996]            # scripts/train_autoprog.sh:5
     opt = FlatAdamWEma(model, reducer, lr=1.6e-3, weight_decay=0.05, ema_decays=ema_decays)   # one fused kernel per step

@@ -162,6 +162,7 @@ int ap_bn_relu_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, cons
  * are HOST arrays of n_ema device pointers / decays; `step` is the 1-based update count. */
 int ap_adamw_ema_step(float* p, const float* g, float* m, float* v, const unsigned char* wd_mask, int64_t n,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                      float grad_scale /* g is multiplied by this first: 1/world_size turns the all-reduced SUM into the mean */,
                       float* const* ema, const float* ema_decay, int n_ema,
                       ap_bf16* p_bf16 /* nullable: bf16 copy of the updated parameters, same offsets */,
                       ap_stream_t stream);

@@ -468,7 +468,12 @@ def vit_forward(p: Params, img, depth: int, heads: int, patch: int = 16, distill
     toks = [p["cls_token"].expand(B, -1, -1)]
     if distilled:
         toks.append(p["dist_token"].expand(B, -1, -1))
-    x = torch.cat(toks + [x], dim=1) + p["pos_embed"]
+    pos, n_extra = p["pos_embed"], len(toks)
+    g0, g = int(round((pos.shape[1] - n_extra) ** 0.5)), int(round(x.shape[1] ** 0.5))
+    if g != g0:     # elastic resolution (build-defined for AutoProg-DeiT): patch-grid part resized as VOLO does, models/volo.py:580-596
+        grid = interpolate_pos_encoding(pos[:, n_extra:].reshape(1, g0, g0, -1), g, g)
+        pos = torch.cat([pos[:, :n_extra], grid.reshape(1, g * g, -1)], dim=1)
+    x = torch.cat(toks + [x], dim=1) + pos
     for i in range(depth):
         if i in skip:
             continue

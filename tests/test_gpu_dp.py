@@ -44,7 +44,7 @@ def _worker(rank, world, port, q):
         model = _make()
         model.set_sample_config(dict(layer_num=4, min_layer_num=3, max_layer_num=6))     # some layers skipped: no gradients there
         red = GradientBucketReducer(list(model.parameters()), bucket_bytes=64 << 10, world_size=world)
-        red.install_sink()
+        red.install_sink(model)
         x, t = _data(rank)
         np.random.seed(5)                                   # same mix-token box on both ranks
         red.zero_grad()

@@ -1,0 +1,145 @@
+"""FlatAdamWEma as the drop-in for create_optimizer + the ModelEma list (main_prog.py:484,507-514; prog/checkpoint_saver.py:110-130):
+EMA checkpoints incl. BatchNorm buffers, refresh of the bf16 weight copies after load_state_dict, LR-scheduler-visible
+param_groups, optimizer state_dict round trip, and the deferred data-parallel mean folded into the update kernel."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny():
+    from autoprog_amd.models import create_model
+    torch.manual_seed(0)
+    return create_model("model_variant", variant="volo_h2_l3", num_classes=16, img_size=64, stem_hidden_dim=16).cuda().train()
+
+
+def _step(model, red, opt, loss_fn, x, target):
+    red.zero_grad()
+    loss = loss_fn(model(x), target)
+    loss.backward()
+    red.finish()
+    opt.step()
+    return float(loss.detach())
+
+
+def _setup(decays=(0.9, 0.99), **kw):
+    from autoprog_amd.dist import GradientBucketReducer
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    from autoprog_amd.optim import FlatAdamWEma
+    model = _tiny()
+    red = GradientBucketReducer(list(model.parameters()), world_size=1, **kw)
+    red.install_sink(model)
+    opt = FlatAdamWEma(model, red, lr=1e-3, weight_decay=0.05, ema_decays=list(decays))
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(4, 3, 64, 64, generator=g).cuda()
+    target = torch.softmax(torch.randn(4, 16, 18, generator=g) * 2, dim=1).cuda()
+    return model, red, opt, TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=16), x, target
+
+
+def test_ema_state_dict_loads_strict_and_tracks_batchnorm_buffers():
+    model, red, opt, loss_fn, x, target = _setup()
+    try:
+        bn0 = {n: b.detach().clone() for n, b in model.named_buffers()}
+        ema_ref = {n: b.detach().clone() for n, b in model.named_buffers() if b.dtype.is_floating_point}
+        np.random.seed(0)
+        for _ in range(3):
+            _step(model, red, opt, loss_fn, x, target)
+            for n, b in model.named_buffers():
+                if b.dtype.is_floating_point:
+                    ema_ref[n].lerp_(b.detach(), 1.0 - 0.9)
+        sd = opt.ema_state_dict(0)
+        assert set(sd) == set(model.state_dict())
+        for n, b in model.named_buffers():
+            if b.dtype.is_floating_point:
+                assert torch.allclose(sd[n], ema_ref[n], atol=1e-6), n            # the right statistic under the right name
+                assert not torch.equal(sd[n], bn0[n]) or "num_batches" in n
+            else:
+                assert sd[n].dtype == b.dtype and int(sd[n]) == int(b), n           # num_batches_tracked: the model's value
+        twin = copy.deepcopy(model)
+        twin.load_state_dict(sd, strict=True)
+    finally:
+        red.remove()
+
+
+def test_load_state_dict_refreshes_weight_copies_and_resync():
+    """after load_state_dict the parameters live at the same addresses: the forward must NOT keep using the bf16 copies of
+    the old weights; FlatAdamWEma.resync() (load post-hook) re-derives them and can restart the EMAs."""
+    model, red, opt, loss_fn, x, target = _setup()
+    try:
+        np.random.seed(0)
+        _step(model, red, opt, loss_fn, x, target)
+        model.eval()
+        with torch.no_grad():
+            y0 = model(x).float()
+            sd = {k: (v * 0.5 if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in model.state_dict().items()}
+            ptr = model.head.weight.data_ptr()
+            model.load_state_dict(sd, strict=True)
+            assert model.head.weight.data_ptr() == ptr                             # in-place copy into the slab view
+            y1 = model(x).float()
+            fresh = _tiny().eval()
+            fresh.load_state_dict(sd, strict=True)
+            y2 = fresh(x).float()
+        assert float((y1 - y2).norm() / y2.norm()) < 1e-3                          # the loaded weights are the ones used
+        assert float((y1 - y0).norm() / y0.norm()) > 1e-2
+        opt.resync(reset_ema=True, reset_moments=True)
+        assert torch.equal(opt.ema[0], opt.p) and float(opt.m.abs().sum()) == 0.0 and opt.step_count == 0
+    finally:
+        red.remove()
+
+
+def test_param_groups_drive_the_learning_rate_and_state_dict_round_trip():
+    model, red, opt, loss_fn, x, target = _setup()
+    try:
+        assert len(opt.param_groups) == 2 and opt.param_groups[1]["weight_decay"] == 0.0
+        names = {id(p): n for n, p in model.named_parameters()}
+        assert all(names[id(p)] in ("pos_embed", "cls_token") or p.dim() == 1 or names[id(p)].endswith(".bias") for p in opt.param_groups[1]["params"])
+        np.random.seed(0)
+        _step(model, red, opt, loss_fn, x, target)
+        for g in opt.param_groups:                      # what a timm scheduler does every epoch
+            g["lr"] = 0.0
+        before = opt.p.clone()
+        _step(model, red, opt, loss_fn, x, target)
+        wd_only = (before - opt.p).abs().max()
+        assert float(wd_only) == 0.0                    # lr 0: neither the Adam step nor the decoupled decay (lr * wd) moves a weight
+        for g in opt.param_groups:
+            g["lr"] = 1e-3
+        saved = copy.deepcopy(opt.state_dict())
+        weights = {k: v.clone() for k, v in model.state_dict().items()}
+        rng_state = np.random.get_state()
+        losses_a = [_step(model, red, opt, loss_fn, x, target) for _ in range(2)]
+        # resume: same weights, same optimizer state -> same continuation (fp32 atomics in the weight gradients: to 1e-4)
+        model.load_state_dict(weights, strict=True)
+        opt.load_state_dict(saved)
+        assert opt.step_count == 2
+        np.random.set_state(rng_state)                  # same mix-token boxes as the first continuation
+        losses_b = [_step(model, red, opt, loss_fn, x, target) for _ in range(2)]
+        assert len(saved["state"]) == len(list(model.parameters())) and "exp_avg_sq" in saved["state"][0]
+        assert np.allclose(losses_a, losses_b, atol=2e-3), (losses_a, losses_b)
+    finally:
+        red.remove()
+
+
+def test_deferred_mean_is_folded_into_the_update():
+    """defer_mean: finish() leaves the all-reduced SUM in the slab and the fused kernel applies 1/world -- equal to scaling first"""
+    from autoprog_amd.dist import GradientBucketReducer
+    from autoprog_amd.optim import FlatAdamWEma
+    torch.manual_seed(0)
+    nets = [torch.nn.Linear(24, 16).cuda() for _ in range(2)]
+    nets[1].load_state_dict(nets[0].state_dict())
+    outs = []
+    for net, defer in zip(nets, (False, True)):
+        red = GradientBucketReducer(list(net.parameters()), world_size=1, defer_mean=defer)
+        opt = FlatAdamWEma(net, red, lr=1e-2, weight_decay=0.0)
+        red.zero_grad()
+        torch.manual_seed(3)
+        net(torch.randn(8, 24, device="cuda")).pow(2).mean().backward()
+        if defer:
+            red._pending_scale = 0.25                  # as finish() sets it for world = 4
+        else:
+            red.flat.mul_(0.25)
+        opt.step()
+        outs.append(net.weight.detach().clone())
+    assert torch.allclose(outs[0], outs[1], atol=1e-7)
