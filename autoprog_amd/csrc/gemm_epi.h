@@ -1,0 +1,83 @@
+// Epilogue shared by every bf16 MFMA GEMM of the hot path (gemm.hip, gemm_dma.h): bias, GELU (+ stored
+// pre-activation), gelu'(h) factor, DropPath row scale, residual add, bf16 store -- on 8 consecutive output columns.
+#pragma once
+#include "common.h"
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+struct EpiArgs {
+    const float* bias; int gelu; bf16_t* preact; const bf16_t* dgelu_of; const float* row_scale;
+    int rows_per_scale; const bf16_t* residual; int ldr; int dbg; unsigned long long* stamps;
+};
+
+// epilogue of 8 consecutive output columns [n, n+8) of row m held in v[] (fp32 accumulators):
+// +bias; GELU (storing the pre-activation); * gelu'(h); * DropPath row scale; + residual; bf16 store.
+// All global accesses are 16-byte when the chunk is complete and the leading dimensions allow it.
+__device__ __forceinline__ void epi_chunk(float* v, int m, int n, int N, int ldc, bool vec_ok, const EpiArgs& ep, bf16_t* __restrict__ C) {
+    const int nval = min(8, N - n);
+    const bool full = (nval == 8) && vec_ok;
+    if (ep.bias) {
+        if (nval == 8) {
+            const float4 b0 = *reinterpret_cast<const float4*>(ep.bias + n), b1 = *reinterpret_cast<const float4*>(ep.bias + n + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (q < nval) v[q] += ep.bias[n + q];
+        }
+    }
+    if (ep.gelu) {
+        if (ep.preact) {
+            bf16_t* p = ep.preact + (int64_t)m * ldc + n;
+            if (full) st16(p, pack8(v));
+            else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (q < nval) p[q] = f2bf(v[q]);
+            }
+            // the activation is applied to the ROUNDED pre-activation so that backward (which reads the
+            // stored bf16 h) differentiates exactly what forward computed
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = bf2f(f2bf(v[q]));
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]);
+    }
+    if (ep.dgelu_of) {
+        const bf16_t* hp = ep.dgelu_of + (int64_t)m * ldc + n;
+        float h[8];
+        if (full) unpack8(ld16(hp), h);
+        else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) h[q] = (q < nval) ? bf2f(hp[q]) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] *= gelu_erf_grad(h[q]);
+    }
+    if (ep.row_scale) {
+        const float rs = ep.row_scale[m / ep.rows_per_scale];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] *= rs;
+    }
+    if (ep.residual) {
+        const bf16_t* rp = ep.residual + (int64_t)m * ep.ldr + n;
+        float h[8];
+        if (full) unpack8(ld16(rp), h);
+        else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) h[q] = (q < nval) ? bf2f(rp[q]) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += h[q];
+    }
+    bf16_t* cp = C + (int64_t)m * ldc + n;
+    if (full) st16(cp, pack8(v));
+    else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (q < nval) cp[q] = f2bf(v[q]);
+    }
+}
+
+__device__ __forceinline__ int key_a(int r) { return r & 7; }
+// B-tile swizzle key for the N-permuted fragment rows (see "direct epilogue" below): the 16 rows one
+// ds_read_b128 lane group touches are 8q + 4b + p (q = 0..3, p = 0..3) -> keys p | (q&1)<<2 are distinct
+__device__ __forceinline__ int key_b(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+

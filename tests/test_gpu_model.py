@@ -431,11 +431,12 @@ def test_loss_curve_realistic_init_vs_reference():
             print("realistic-init first-step gradient rel-L2 errors:", {k: round(v, 4) for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:6]})
             print("worst gradient-norm deviations:", {k: round(v, 4) for k, v in sorted(norms.items(), key=lambda kv: -kv[1])[:6]})
             bad = {k: v for k, v in errs.items() if v > 6e-2}
-            assert not bad, bad
-            assert max(norms.values()) < 6e-2, max(norms.values())
+            norm_dev = max(norms.values())
         opt.step()
         losses.append(float(loss.detach()))
     dev = np.abs(np.array(losses) - d["losses"])
     print("realistic-init loss curve |hip - ref(fp64)|:", [round(float(v), 5) for v in dev],
           " reference fp32 vs fp64:", [round(float(v), 5) for v in np.abs(d["losses_fp32"] - d["losses"])])
+    assert not bad, bad
+    assert norm_dev < 6e-2, norm_dev
     assert dev.max() < 1e-3, (losses, d["losses"].tolist())
