@@ -359,7 +359,11 @@ def gen_step_curve_init(ns):
     target = make_target(B, classes, (r // 16) ** 2, gen)
     out = {"x": npy(x), "target": npy(target), "np_seed": np.array(123), "lr": np.array(1e-3), "wd": np.array(0.05),
            "init_seed": np.array(seed), "classes": np.array(classes)}
-    for dt, tag in ((torch.float64, ""), (torch.float32, "_fp32")):
+    for dt, tag in ((torch.float64, ""), (torch.float32, "_fp32"), (torch.float32, "_fp16_autocast")):
+        # "_fp16_autocast": the reference model under torch.autocast("cpu", float16) -- the closest thing to its apex-O1 training
+        # path that runs here (16-bit GEMM/conv operands, fp32 master weights and loss): the reference's own mixed-precision
+        # deviation from its exact curve, recorded as the yardstick for any 16-bit-activation implementation
+        amp = tag == "_fp16_autocast"
         net = tiny_volo(ns, "volo_h4_l6", r, classes).train()
         net.load_state_dict(init_state_dict(net.state_dict(), seed), strict=True)
         net = net.to(dt)
@@ -372,7 +376,12 @@ def gen_step_curve_init(ns):
         np.random.seed(123)
         g0 = None
         for step in range(10):
-            outp = net(x.to(dt))
+            if amp:
+                with torch.autocast("cpu", dtype=torch.float16):
+                    outp = net(x)
+                outp = (outp[0].float(), outp[1].float(), outp[2])
+            else:
+                outp = net(x.to(dt))
             loss = loss_fn(outp, target.to(dt))
             opt.zero_grad()
             loss.backward()
