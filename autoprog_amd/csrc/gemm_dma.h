@@ -15,32 +15,63 @@
 #pragma once
 #include "gemm_epi.h"
 
-template <int N_>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+#ifndef AP_DMA_ABL
+#define AP_DMA_ABL 0      // timing-only ablation builds (tools/gemm_lab): 2 = no fragment reads / MFMAs, 4 = no DMA
+#endif
 
-template <int TM, int TN, int WGM, int WGN, int ST>
+// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the instruction takes an immediate, so dispatch over the values the ring
+// can ask for (n <= 48); larger requests wait for 48 (waiting for MORE operations than necessary is always safe)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+#define AP_VM_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        AP_VM_CASE(0) AP_VM_CASE(1) AP_VM_CASE(2) AP_VM_CASE(3) AP_VM_CASE(4) AP_VM_CASE(5) AP_VM_CASE(6) AP_VM_CASE(7) 
+        AP_VM_CASE(8) AP_VM_CASE(9) AP_VM_CASE(10) AP_VM_CASE(11) AP_VM_CASE(12) AP_VM_CASE(13) AP_VM_CASE(14) AP_VM_CASE(15) 
+        AP_VM_CASE(16) AP_VM_CASE(17) AP_VM_CASE(18) AP_VM_CASE(19) AP_VM_CASE(20) AP_VM_CASE(21) AP_VM_CASE(22) AP_VM_CASE(23) 
+        AP_VM_CASE(24) AP_VM_CASE(25) AP_VM_CASE(26) AP_VM_CASE(27) AP_VM_CASE(28) AP_VM_CASE(29) AP_VM_CASE(30) AP_VM_CASE(31) 
+        AP_VM_CASE(32) AP_VM_CASE(33) AP_VM_CASE(34) AP_VM_CASE(35) AP_VM_CASE(36) AP_VM_CASE(37) AP_VM_CASE(38) AP_VM_CASE(39) 
+        AP_VM_CASE(40) AP_VM_CASE(41) AP_VM_CASE(42) AP_VM_CASE(43) AP_VM_CASE(44) AP_VM_CASE(45) AP_VM_CASE(46) AP_VM_CASE(47) 
+        
+        default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+    }
+#undef AP_VM_CASE
+}
+
+// bank-swizzle keys (XORed into the 16-byte chunk index of a row).  BK = 64: 128-byte rows, 8 chunks, key_a / key_b of
+// gemm_epi.h.  BK = 32: 64-byte rows, 4 chunks: the 16 lanes of one ds_read_b128 group read rows {0-3,12-15} chunk c and rows
+// {4-11} chunk c+1 (or the mirrored set); four rows share a 256-byte bank line, so rows 4j..4j+3 get key (-j)&3 = {0,3,2,1}:
+// every group then touches 16 distinct 16-byte slots.  For the N-permuted weight rows (fragment row 4q+p lives at tile row
+// 8q + 4(t&1) + p) the row group is q = (r>>3)&3.
+template <int BK> __device__ __forceinline__ int dkey_a(int r) { return BK == 64 ? (r & 7) : ((0 - (r >> 2)) & 3); }
+template <int BK> __device__ __forceinline__ int dkey_b(int r) { return BK == 64 ? ((r & 3) | (((r >> 3) & 1) << 2)) : ((0 - (r >> 3)) & 3); }
+
+template <int TM, int TN, int WGM, int WGN, int ST, int BK = 64>
 __global__ void __launch_bounds__(WGM * WGN * 64)
 k_gemm_nt_dma(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
               int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dma_raw[];
     constexpr int NW = WGM * WGN;
     constexpr int ROWS = TM + TN;
-    constexpr int PIECES = ROWS / 8;                 // one DMA wave-instruction fills 8 rows (1 KiB)
-    constexpr int NI = PIECES / NW;                  // DMA instructions per wave per K step
+    constexpr int RPP = 512 / BK;                    // rows per DMA wave-instruction (1 KiB): 8 at BK 64, 16 at BK 32
+    constexpr int CPR = BK / 8;                      // 16-byte chunks per row
+    constexpr int PIECES = ROWS / RPP;
+    constexpr int NI = (PIECES + NW - 1) / NW;       // DMA instructions per wave per K step (the last one may be absent)
     constexpr int MT = TM / WGM / 16, NT = TN / WGN / 16;
-    constexpr int STAGE = ROWS * 64;                 // bf16 elements per stage
-    static_assert(TM % 8 == 0 && PIECES % NW == 0, "stage rows split evenly over the waves");
+    constexpr int STAGE = ROWS * BK;                 // bf16 elements per stage
+    constexpr int KS = BK / 32;                      // MFMA k-steps per stage
+    static_assert(BK == 32 || BK == 64, "BK");
+    static_assert(TM % RPP == 0 && ROWS % RPP == 0, "a DMA piece lies entirely in the activation or in the weight rows");
     static_assert((TM / WGM) % 16 == 0 && (TN / WGN) % 32 == 0, "wave tile: 16-row fragments, N-permuted fragment pairs");
-    static_assert(ST >= 2 && ST <= 4, "ring depth");
+    static_assert(ST >= 2 && ST <= 8, "ring depth");
     bf16_t* ring = reinterpret_cast<bf16_t*>(dma_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
     const int fr = lane & 15, g = lane >> 4;
-    const int nk = K >> 6;
+    const int nk = K / BK;
     const int G = gridDim.x;
     const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
     const int total = my_tiles * nk;
+    const int my_ni = (PIECES % NW == 0 || wave < PIECES % NW) ? NI : NI - 1;      // DMA instructions this wave issues per K step
 
     // ---- DMA issue cursor over the flattened (tile, k) stream
     uint32_t soff[NI];                               // per-lane source offsets in elements (launcher checks < 2^32)
@@ -49,13 +80,13 @@ k_gemm_nt_dma(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ 
         const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int r = (wave + NW * i) * 8 + (lane >> 3);
+            const int r = (wave + NW * i) * RPP + lane / CPR;
             if (r < TM) {
-                const int c = (lane & 7) ^ key_a(r);
+                const int c = (lane % CPR) ^ dkey_a<BK>(r);
                 soff[i] = (uint32_t)min(m0 + r, M - 1) * (uint32_t)lda + c * 8;
             } else {
-                const int rb = r - TM;
-                const int c = (lane & 7) ^ key_b(rb);
+                const int rb = min(r - TM, TN - 1);
+                const int c = (lane % CPR) ^ dkey_b<BK>(rb);
                 soff[i] = (uint32_t)min(n0 + rb, N - 1) * (uint32_t)ldb + c * 8;
             }
         }
@@ -63,12 +94,16 @@ k_gemm_nt_dma(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ 
     int q_tile = 0, q_k = 0, q_stage = 0;
     auto issue_next = [&]() {
         if (q_k == 0) set_tile_src(q_tile);
+        if (!(AP_DMA_ABL & 4)) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int r0 = (wave + NW * i) * 8;      // wave-uniform first row of this piece
-            const bf16_t* base = (r0 < TM) ? A : B;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + soff[i] + q_k * 64),
-                                             (__attribute__((address_space(3))) void*)(ring + q_stage * STAGE + r0 * 64), 16, 0, 0);
+            for (int i = 0; i < NI; ++i) {
+                const int p = wave + NW * i;             // wave-uniform piece index
+                if (i == NI - 1 && PIECES % NW != 0 && p >= PIECES) break;
+                const int r0 = p * RPP;
+                const bf16_t* base = (r0 < TM) ? A : B;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + soff[i] + q_k * BK),
+                                                 (__attribute__((address_space(3))) void*)(ring + q_stage * STAGE + r0 * BK), 16, 0, 0);
+            }
         }
         if (++q_k == nk) { q_k = 0; ++q_tile; }
         q_stage = (q_stage == ST - 1) ? 0 : q_stage + 1;
@@ -89,35 +124,34 @@ k_gemm_nt_dma(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ 
         // K steps issued beyond s: issued - s - 1 in [0, ST-2].  Wait until only those are outstanding: step s has landed
         // (this wave's pieces; the barrier extends it to every wave's).  Over-waiting (epilogue stores of the previous tile are
         // younger than some of these DMAs and get drained too) is always safe.
-        const int ahead = issued - s - 1;
-        if (ST >= 4 && ahead >= 2) wait_vmcnt<2 * NI>();
-        else if (ST >= 3 && ahead >= 1) wait_vmcnt<NI>();
-        else wait_vmcnt<0>();
+        wait_vmcnt_dyn((issued - s - 1) * my_ni);
         __builtin_amdgcn_s_barrier();
         // every wave has finished reading the slot of step s-1: refill it with step s + ST - 1
         if (issued < total) { issue_next(); ++issued; }
         const bf16_t* sA = ring + stage * STAGE;
-        const bf16_t* sB = sA + TM * 64;
+        const bf16_t* sB = sA + TM * BK;
+        if (!(AP_DMA_ABL & 2)) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             bf16x8 xf[MT], wf[NT];
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 const int r = wm * (TM / WGM) + t * 16 + fr;
-                xf[t] = as_bf16x8(ld16(sA + r * 64 + (((ks * 4 + g) ^ key_a(r)) << 3)));
+                xf[t] = as_bf16x8(ld16(sA + r * BK + (((ks * 4 + g) ^ dkey_a<BK>(r)) << 3)));
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 // fragment t of pair P = t>>1 holds weight rows 32P + 8q + 4(t&1) + p for MFMA row 4q + p: a lane's 4 + 4
                 // accumulator registers of the pair are 8 CONSECUTIVE output columns
                 const int r = wn * (TN / WGN) + 32 * (t >> 1) + 8 * (fr >> 2) + 4 * (t & 1) + (fr & 3);
-                wf[t] = as_bf16x8(ld16(sB + r * 64 + (((ks * 4 + g) ^ key_b(r)) << 3)));
+                wf[t] = as_bf16x8(ld16(sB + r * BK + (((ks * 4 + g) ^ dkey_b<BK>(r)) << 3)));
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
         }
         stage = (stage == ST - 1) ? 0 : stage + 1;
         if (++kt < nk) continue;
@@ -126,7 +160,7 @@ k_gemm_nt_dma(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ 
         const int tile = xcd_remap(blockIdx.x + ti * G, ntiles);
         ++ti;
         const int m0 = (tile / tiles_n) * TM + wm * (TM / WGM), n0 = (tile % tiles_n) * TN + wn * (TN / WGN);
-        if (ep.dbg & 1) {
+        if ((AP_DMA_ABL & 1) || (ep.dbg & 1)) {
             float sacc = 0.f;
 #pragma unroll
             for (int a = 0; a < NT; ++a)
@@ -148,5 +182,178 @@ k_gemm_nt_dma(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ 
                 epi_chunk(v, m, n, N, ldc, vec_ok, ep, C);
             }
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second structure (lab measurements, profiles/r02_gemm_lab.txt): in k_gemm_nt_dma the three phases of a tile ADD UP
+// (256x192 tile on the qkv shape: DMA only 19.7 us, MFMAs + fragment reads ~16 us, stores only 20.6 us, everything 49.8 us):
+//   * all DMA instructions of a step were issued in one burst right behind the barrier; a VMEM instruction that finds the
+//     CU's address pipeline full blocks its wave, so every wave sat in the burst before its first MFMA and nothing was sent
+//     while the MFMAs ran.  Here the DMA instructions of a step are spread BETWEEN its MFMAs (ILV).
+//   * the counted wait at the top of a step also drained the previous tile's epilogue stores (they are younger than the DMA
+//     it waits for).  Here their number is added to the count for the ST-1 steps in which they are inside the window, so the
+//     stores of a full tile retire behind the next tile's MFMAs.
+template <int TM, int TN, int WGM, int WGN, int ST, int BK, int ILV>
+__global__ void __launch_bounds__(WGM * WGN * 64)
+k_gemm_nt_dma2(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
+               int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dma_raw[];
+    constexpr int NW = WGM * WGN;
+    constexpr int ROWS = TM + TN;
+    constexpr int RPP = 512 / BK;
+    constexpr int CPR = BK / 8;
+    constexpr int PIECES = ROWS / RPP;
+    constexpr int NI = (PIECES + NW - 1) / NW;
+    constexpr int MT = TM / WGM / 16, NT = TN / WGN / 16;
+    constexpr int STAGE = ROWS * BK;
+    constexpr int KS = BK / 32;
+    constexpr int NMFMA = KS * NT * MT;              // MFMAs of one K step
+    static_assert(BK == 32 || BK == 64, "BK");
+    static_assert(TM % RPP == 0 && ROWS % RPP == 0, "a DMA piece lies entirely in the activation or in the weight rows");
+    static_assert((TM / WGM) % 16 == 0 && (TN / WGN) % 32 == 0, "wave tile: 16-row fragments, N-permuted fragment pairs");
+    static_assert(ST >= 2 && ST <= 8, "ring depth");
+    bf16_t* ring = reinterpret_cast<bf16_t*>(dma_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int fr = lane & 15, g = lane >> 4;
+    const int nk = K / BK;
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    const int total = my_tiles * nk;
+    const int my_ni = (PIECES % NW == 0 || wave < PIECES % NW) ? NI : NI - 1;
+
+    uint32_t soff[NI];
+    auto set_tile_src = [&](int ti) {
+        const int tile = xcd_remap(blockIdx.x + ti * G, ntiles);
+        const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = (wave + NW * i) * RPP + lane / CPR;
+            if (r < TM) {
+                const int c = (lane % CPR) ^ dkey_a<BK>(r);
+                soff[i] = (uint32_t)min(m0 + r, M - 1) * (uint32_t)lda + c * 8;
+            } else {
+                const int rb = min(r - TM, TN - 1);
+                const int c = (lane % CPR) ^ dkey_b<BK>(rb);
+                soff[i] = (uint32_t)min(n0 + rb, N - 1) * (uint32_t)ldb + c * 8;
+            }
+        }
+    };
+    int q_tile = 0, q_k = 0, q_stage = 0;            // cursor: the K step the NEXT DMA group belongs to
+    auto issue_piece = [&](int i) {                  // one DMA instruction of the cursor's K step
+        const int p = wave + NW * i;
+        if (PIECES % NW != 0 && i == NI - 1 && p >= PIECES) return;
+        const int r0 = p * RPP;
+        const bf16_t* base = (r0 < TM) ? A : B;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + soff[i] + q_k * BK),
+                                         (__attribute__((address_space(3))) void*)(ring + q_stage * STAGE + r0 * BK), 16, 0, 0);
+    };
+    auto advance = [&]() {
+        if (++q_k == nk) { q_k = 0; ++q_tile; }
+        q_stage = (q_stage == ST - 1) ? 0 : q_stage + 1;
+    };
+
+    f32x4 acc[NT][MT];
+    int issued = 0;
+    for (; issued < ST - 1 && issued < total; ++issued) {
+        if (q_k == 0) set_tile_src(q_tile);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) issue_piece(i);
+        advance();
+    }
+    int stage = 0, kt = 0, ti = 0;
+    int epi_stores = 0, since_epi = 1 << 20;         // stores of the last full-tile epilogue, K steps since it ran
+    const bool vec_ok = ((ldc & 7) == 0) && (ep.residual == nullptr || (ep.ldr & 7) == 0);
+    for (int s = 0; s < total; ++s) {
+        if (kt == 0) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // step s has landed once only the YOUNGER operations of this wave are outstanding: the DMA groups of steps s+1 .. issued-1
+        // and, for ST-1 steps after a full-tile epilogue, its stores (issued after the DMA group of step s)
+        ++since_epi;                                  // = s - (last step of the previous tile)
+        wait_vmcnt_dyn((issued - s - 1) * my_ni + ((since_epi <= ST - 1) ? epi_stores : 0));
+        __builtin_amdgcn_s_barrier();
+        const bool do_issue = issued < total;         // the slot of step s-1 is free now: refill it with step s + ST - 1
+        if (do_issue && q_k == 0) set_tile_src(q_tile);
+        if (!ILV && do_issue && !(AP_DMA_ABL & 4)) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) issue_piece(i);
+        }
+        const bf16_t* sA = ring + stage * STAGE;
+        const bf16_t* sB = sA + TM * BK;
+        if (!(AP_DMA_ABL & 2)) {
+            int j = 0, di = 0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 xf[MT], wf[NT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const int r = wm * (TM / WGM) + t * 16 + fr;
+                    xf[t] = as_bf16x8(ld16(sA + r * BK + (((ks * 4 + g) ^ dkey_a<BK>(r)) << 3)));
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int r = wn * (TN / WGN) + 32 * (t >> 1) + 8 * (fr >> 2) + 4 * (t & 1) + (fr & 3);
+                    wf[t] = as_bf16x8(ld16(sB + r * BK + (((ks * 4 + g) ^ dkey_b<BK>(r)) << 3)));
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                        ++j;
+                        if (ILV && !(AP_DMA_ABL & 4) && di < NI && j == ((di + 1) * NMFMA) / (NI + 1)) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (do_issue) issue_piece(di);
+                            __builtin_amdgcn_sched_barrier(0);
+                            ++di;
+                        }
+                    }
+            }
+        } else if (ILV && do_issue && !(AP_DMA_ABL & 4)) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) issue_piece(i);
+        }
+        if (do_issue) { advance(); ++issued; }
+        stage = (stage == ST - 1) ? 0 : stage + 1;
+        if (++kt < nk) continue;
+        kt = 0;
+        // ------------------------------------------------------------ direct epilogue of tile `ti`
+        const int tile = xcd_remap(blockIdx.x + ti * G, ntiles);
+        ++ti;
+        const int m0 = (tile / tiles_n) * TM + wm * (TM / WGM), n0 = (tile % tiles_n) * TN + wn * (TN / WGN);
+        if ((AP_DMA_ABL & 1) || (ep.dbg & 1)) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < MT; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+            if (sacc == 12345.678f) C[0] = 1;
+            continue;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + mt * 16 + fr;
+#pragma unroll
+            for (int pr = 0; pr < NT / 2; ++pr) {
+                const int n = n0 + 32 * pr + 8 * g;
+                if (m >= M || n >= N) continue;
+                float v[8];
+                v[0] = acc[2 * pr][mt][0]; v[1] = acc[2 * pr][mt][1]; v[2] = acc[2 * pr][mt][2]; v[3] = acc[2 * pr][mt][3];
+                v[4] = acc[2 * pr + 1][mt][0]; v[5] = acc[2 * pr + 1][mt][1]; v[6] = acc[2 * pr + 1][mt][2]; v[7] = acc[2 * pr + 1][mt][3];
+                epi_chunk(v, m, n, N, ldc, vec_ok, ep, C);
+            }
+        }
+        // every lane of this wave stored all its chunks (interior tile): exactly MT * NT/2 store instructions (twice with a stored
+        // pre-activation) are in flight behind the DMA groups issued so far
+        const bool interior = vec_ok && (m0 + TM / WGM <= M) && (n0 + TN / WGN <= N);
+        epi_stores = interior ? MT * (NT / 2) * ((ep.gelu && ep.preact) ? 2 : 1) : 0;
+        since_epi = 0;
     }
 }

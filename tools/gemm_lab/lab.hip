@@ -42,23 +42,41 @@ struct Variant { std::string name; std::function<bool(const Shape&, const Set&, 
 
 static int g_ncu = 256;
 
-template <int TM, int TN, int WGM, int WGN, int ST>
+static int g_dbg = 0;
+template <int TM, int TN, int WGM, int WGN, int ST, int BK = 64>
 static bool launch_dma(const Shape& s, const Set& b, int ldc, EpiArgs ep, int wg_per_cu /*0 = one workgroup per tile*/, hipStream_t st) {
-    if (s.K % 64) return false;
-    const size_t lds = (size_t)ST * (TM + TN) * 128;
+    if (s.K % BK) return false;
+    ep.dbg = g_dbg;
+    const size_t lds = (size_t)ST * (TM + TN) * BK * 2;
     if (lds > 160 * 1024) return false;
     static bool attr = false;
-    if (!attr) { CK(hipFuncSetAttribute((const void*)k_gemm_nt_dma<TM, TN, WGM, WGN, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    if (!attr) { CK(hipFuncSetAttribute((const void*)k_gemm_nt_dma<TM, TN, WGM, WGN, ST, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
     const int tm = (s.M + TM - 1) / TM, tn = (s.N + TN - 1) / TN, nt = tm * tn;
     int grid = nt;
     if (wg_per_cu > 0) grid = std::min(nt, wg_per_cu * g_ncu);
-    hipLaunchKernelGGL((k_gemm_nt_dma<TM, TN, WGM, WGN, ST>), dim3(grid), dim3(WGM * WGN * 64), lds, st, b.A, s.K, b.B, s.K, b.C, ldc, s.M, s.N, s.K, tn, nt, ep);
+    hipLaunchKernelGGL((k_gemm_nt_dma<TM, TN, WGM, WGN, ST, BK>), dim3(grid), dim3(WGM * WGN * 64), lds, st, b.A, s.K, b.B, s.K, b.C, ldc, s.M, s.N, s.K, tn, nt, ep);
+    return hipGetLastError() == hipSuccess;
+}
+
+template <int TM, int TN, int WGM, int WGN, int ST, int BK, int ILV>
+static bool launch_dma2(const Shape& s, const Set& b, int ldc, EpiArgs ep, int wg_per_cu, hipStream_t st) {
+    if (s.K % BK) return false;
+    ep.dbg = g_dbg;
+    const size_t lds = (size_t)ST * (TM + TN) * BK * 2;
+    if (lds > 160 * 1024) return false;
+    static bool attr = false;
+    if (!attr) { CK(hipFuncSetAttribute((const void*)k_gemm_nt_dma2<TM, TN, WGM, WGN, ST, BK, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    const int tm = (s.M + TM - 1) / TM, tn = (s.N + TN - 1) / TN, nt = tm * tn;
+    int grid = nt;
+    if (wg_per_cu > 0) grid = std::min(nt, wg_per_cu * g_ncu);
+    hipLaunchKernelGGL((k_gemm_nt_dma2<TM, TN, WGM, WGN, ST, BK, ILV>), dim3(grid), dim3(WGM * WGN * 64), lds, st, b.A, s.K, b.B, s.K, b.C, ldc, s.M, s.N, s.K, tn, nt, ep);
     return hipGetLastError() == hipSuccess;
 }
 
 int main(int argc, char** argv) {
     const char* filter = argc > 1 ? argv[1] : "";
     const char* vfilter = argc > 2 ? argv[2] : "";
+    if (getenv("LAB_DBG")) g_dbg = atoi(getenv("LAB_DBG"));
     hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); g_ncu = pr.multiProcessorCount;
     printf("# device %s, %d CUs\n", pr.name, g_ncu);
     std::vector<Shape> shapes = {
@@ -74,20 +92,21 @@ int main(int argc, char** argv) {
         e.bias = ep.bias; e.gelu = ep.gelu; e.preact_out = ep.preact; e.dgelu_of = ep.dgelu_of; e.row_scale = ep.row_scale; e.rows_per_scale = ep.rows_per_scale;
         e.residual = ep.residual; e.ldr = ep.ldr;
         return ap_gemm_nt(b.A, s.K, b.B, s.K, b.C, ldc, s.M, s.N, s.K, &e, st) == 0; }});
-#define DMA(NAME, TM, TN, WGM, WGN, ST, WPC) vars.push_back({NAME, [](const Shape& s, const Set& b, int ldc, EpiArgs ep, float*, float*, hipStream_t st) { return launch_dma<TM, TN, WGM, WGN, ST>(s, b, ldc, ep, WPC, st); }});
-    DMA("d128x128w4s2", 128, 128, 2, 2, 2, 0)
-    DMA("d128x128w4s3p1", 128, 128, 2, 2, 3, 1)
-    DMA("d128x192w4s2", 128, 192, 2, 2, 2, 0)
-    DMA("d128x192w4s2p2", 128, 192, 2, 2, 2, 2)
-    DMA("d128x192w4s3p1", 128, 192, 2, 2, 3, 1)
-    DMA("d256x128w8s3p1", 256, 128, 4, 2, 3, 1)
-    DMA("d256x128w8s3", 256, 128, 4, 2, 3, 0)
-    DMA("d256x192w8s2p1", 256, 192, 4, 2, 2, 1)
-    DMA("d256x192w8s2", 256, 192, 4, 2, 2, 0)
-    DMA("d192x192w8s3p1", 192, 192, 4, 2, 3, 1)
-    DMA("d256x128w4s3p1", 256, 128, 2, 2, 3, 1)
-    DMA("d128x64w4s4p2", 128, 64, 2, 2, 4, 2)
-    DMA("d128x64w4s3", 128, 64, 2, 2, 3, 0)
+#define DMA(NAME, TM, TN, WGM, WGN, ST, BK, WPC) vars.push_back({NAME, [](const Shape& s, const Set& b, int ldc, EpiArgs ep, float*, float*, hipStream_t st) { return launch_dma<TM, TN, WGM, WGN, ST, BK>(s, b, ldc, ep, WPC, st); }});
+    DMA("d256x192w8k64s2p1", 256, 192, 4, 2, 2, 64, 1)
+    DMA("d256x256w8k32s4p1", 256, 256, 4, 2, 4, 32, 1)
+#define DMA2(NAME, TM, TN, WGM, WGN, ST, BK, ILV, WPC) vars.push_back({NAME, [](const Shape& s, const Set& b, int ldc, EpiArgs ep, float*, float*, hipStream_t st) { return launch_dma2<TM, TN, WGM, WGN, ST, BK, ILV>(s, b, ldc, ep, WPC, st); }});
+    DMA2("e256x192k64s2i0", 256, 192, 4, 2, 2, 64, 0, 1)
+    DMA2("e256x192k64s2i1", 256, 192, 4, 2, 2, 64, 1, 1)
+    DMA2("e256x192k32s5i0", 256, 192, 4, 2, 5, 32, 0, 1)
+    DMA2("e256x192k32s5i1", 256, 192, 4, 2, 5, 32, 1, 1)
+    DMA2("e256x192k32s3i1", 256, 192, 4, 2, 3, 32, 1, 1)
+    DMA2("e256x256k32s4i1", 256, 256, 4, 2, 4, 32, 1, 1)
+    DMA2("e256x256k32s3i1", 256, 256, 4, 2, 3, 32, 1, 1)
+    DMA2("e256x128k64s3i1", 256, 128, 4, 2, 3, 64, 1, 1)
+    DMA2("e256x128k32s6i1", 256, 128, 4, 2, 6, 32, 1, 1)
+    DMA2("e128x128k32s5i1p2", 128, 128, 2, 2, 5, 32, 1, 2)
+    DMA2("e128x192k32s7i1", 128, 192, 4, 2, 7, 32, 1, 1)
     const size_t ROT_BYTES = (size_t)640 << 20;
     hipStream_t st; CK(hipStreamCreate(&st));
     float* d_diff; CK(hipMalloc(&d_diff, 8));
@@ -158,7 +177,7 @@ int main(int argc, char** argv) {
             (void)reps;
             const float us = tot / 3 * 1e3f;
             printf("    %-18s %7.1f us (best %6.1f)  %6.0f TF  %5.2f TB/s   maxdiff %.3g (ref max %.3g)%s\n", v.name.c_str(), us, best * 1e3f, flops / us / 1e6, bytes / us / 1e6,
-                   hd[0], hd[1], (vi > 0 && hd[0] > 0.02f * hd[1] + 1e-3f) ? "  <-- MISMATCH" : "");
+                   hd[0], hd[1], (vi > 0 && !g_dbg && !AP_DMA_ABL && hd[0] > 0.02f * hd[1] + 1e-3f) ? "  <-- MISMATCH" : "");
             CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
         }
         for (Set& b : sets) { hipFree(b.A); hipFree(b.B); hipFree(b.C); if (b.R) hipFree(b.R); if (b.H) hipFree(b.H); }
