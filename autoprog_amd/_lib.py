@@ -44,7 +44,8 @@ _SIGNATURES = {
     "ap_avgpool2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ap_avgpool2_bwd_acc": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ap_mhsa_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
-    "ap_mhsa_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "ap_mhsa_bwd_workspace": (ctypes.c_size_t, [_I, _I, _I, _I]),
+    "ap_mhsa_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, ctypes.c_size_t, _P]),
     "ap_class_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "ap_class_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "ap_mix_token_swap": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -16,67 +16,9 @@
 // f((row>>2)&3), f = {0,2,3,1}: conflict-free for both the ds_read_b128 row reads and the
 // transposed reads.
 #include "common.h"
+#include "attn_frag.h"
+#include <cstdlib>
 
-#define AHD 32          // head dim of the class-attention kernels below
-
-// element offset of 16-B chunk `chunk` of row `row` in a [tokens][HD] LDS tile.
-// HD=32 (64-B rows): chunk ^= f((row>>2)&3), f={0,2,3,1}; HD=64 (128-B rows): chunk ^= row&7.
-// Both are conflict-free for the ds_read_b128 row reads and for the transposed reads used here.
-template <int HD>
-__device__ __forceinline__ int att_off(int row, int chunk) {
-    if (HD == 32) {
-        const int f = (0x78 >> (((row >> 2) & 3) << 1)) & 3;
-        return row * 32 + ((chunk ^ f) << 3);
-    }
-    return row * 64 + ((chunk ^ (row & 7)) << 3);
-}
-template <int HD>
-__device__ __forceinline__ bf16x8 att_row_frag(const bf16_t* tile, int row0, int lane, int kc = 0) {
-    // operand whose k axis is the head dim: tile row row0+(lane&15), k chunk kc*4 + lane>>4
-    return __builtin_bit_cast(bf16x8, ld16(tile + att_off<HD>(row0 + (lane & 15), kc * 4 + (lane >> 4))));
-}
-template <int HD>
-__device__ __forceinline__ bf16x8 att_tr_frag(const bf16_t* tile, int row0, int dt, int lane) {
-    // operand whose k axis is the TOKEN axis in the accumulator-permuted order:
-    // k = 8g+j  <->  token row0 + 16*(j>>2) + 4g + (j&3); column = dt*16 + (lane&15)
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const int r1 = row0 + 4 * g + q, r2 = r1 + 16;
-    const int ch = 2 * dt + (p >> 1), e = (p & 1) * 4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + att_off<HD>(r1, ch) + e));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + att_off<HD>(r2, ch) + e));
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-}
-// Lane-constant parts of the two fragment address patterns, computed ONCE per kernel: the swizzle term
-// only depends on lane bits (row offsets used in the loops are multiples of 16 resp. 32 tokens, which do
-// not touch the swizzled row bits), so every read in the loops is base + compile-time/loop-linear offset.
-// (rocprof: ~930 VALU instructions per 16-query tile before hoisting, most of them address arithmetic.)
-template <int HD>
-__device__ __forceinline__ int att_row_base(int lane, int kc) { return att_off<HD>(lane & 15, kc * 4 + (lane >> 4)); }
-template <int HD>
-__device__ __forceinline__ bf16x8 att_row_at(const bf16_t* tile, int base, int row0) {
-    return __builtin_bit_cast(bf16x8, ld16(tile + base + row0 * HD));
-}
-template <int HD>
-__device__ __forceinline__ int att_tr_base(int lane, int dt) {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    return att_off<HD>(4 * g + q, 2 * dt + (p >> 1)) + (p & 1) * 4;
-}
-template <int HD>
-__device__ __forceinline__ bf16x8 att_tr_at(const bf16_t* tile, int base, int row0) {
-    const bf16_t* a1 = tile + base + row0 * HD;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1 + 16 * HD));
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-}
-__device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
-    u32x4 v;
-    v[0] = pack_bf2(a[0], a[1]); v[1] = pack_bf2(a[2], a[3]); v[2] = pack_bf2(b[0], b[1]); v[3] = pack_bf2(b[2], b[3]);
-    return __builtin_bit_cast(bf16x8, v);
-}
 
 // Stage NTILES token-major operands ([N, HD] slices with row stride ld[i]) into their LDS tiles.  ALL global loads of a thread
 // (up to MAXIT iterations x NTILES tiles) are issued before the first LDS store: the former one-load-then-store loop, called
@@ -369,25 +311,29 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
 }
 
 // ------------------------------------------------------------------------- class attention
-// one query (token 0) per image and head: HBM-bound VALU kernel, 4 lanes x 16 B per key row.
+// one query (token 0) per image and head: HBM-bound VALU kernel, PARTS lanes x 16 B per key row (PARTS = 4: head_dim 32;
+// PARTS = 8: head_dim 48 / 64 -- lanes whose 8 columns lie beyond head_dim contribute zeros).
+template <int PARTS>
 __global__ void __launch_bounds__(256)
 k_class_attn_fwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, bf16_t* __restrict__ out,
-                 float* __restrict__ probs, int N, int heads, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];     // scores[N] | red[64*32]
+                 float* __restrict__ probs, int N, int heads, int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // scores[N] | red[KS*HDP]
+    constexpr int KS = 256 / PARTS, HDP = PARTS * 8;               // keys per pass, padded head dim
     float* sc = sm;
     float* red = sm + ((N + 63) & ~63);
     __shared__ float wred[8];
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int C = heads * AHD;
-    const int part = threadIdx.x & 3, kslot = threadIdx.x >> 2;          // 64 keys per pass
-    float qv[8];
-    unpack8(ld16(q + (int64_t)b * C + h * AHD + part * 8), qv);
-    const bf16_t* kb = kv + (int64_t)b * N * 2 * C + h * AHD + part * 8;
+    const int C = heads * hd;
+    const int part = threadIdx.x % PARTS, kslot = threadIdx.x / PARTS;
+    const bool pok = part * 8 < hd;
+    float qv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (pok) unpack8(ld16(q + (int64_t)b * C + h * hd + part * 8), qv);
+    const bf16_t* kb = kv + (int64_t)b * N * 2 * C + h * hd + part * 8;
     float mx = -1.0e30f;
-    for (int k0 = 0; k0 < N; k0 += 64) {
+    for (int k0 = 0; k0 < N; k0 += KS) {
         const int key = k0 + kslot;
         float d = 0.f;
-        if (key < N) {
+        if (key < N && pok) {
             float kk[8];
             unpack8(ld16(kb + (int64_t)key * 2 * C), kk);
 #pragma unroll
@@ -395,6 +341,7 @@ k_class_attn_fwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, bf
         }
         d += __shfl_xor(d, 1, 64);
         d += __shfl_xor(d, 2, 64);
+        if (PARTS == 8) d += __shfl_xor(d, 4, 64);
         d *= scale;
         if (key < N) { if (part == 0) sc[key] = d; mx = fmaxf(mx, d); }
     }
@@ -409,50 +356,57 @@ k_class_attn_fwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, bf
     __syncthreads();
     const float inv = 1.0f / (wred[4] + wred[5] + wred[6] + wred[7]);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k0 = 0; k0 < N; k0 += 64) {
+    for (int k0 = 0; k0 < N; k0 += KS) {
         const int key = k0 + kslot;
         if (key < N) {
             const float p = sc[key] * inv;
             if (part == 0) probs[((int64_t)b * heads + h) * N + key] = p;
-            float vv[8];
-            unpack8(ld16(kb + (int64_t)key * 2 * C + C), vv);
+            if (pok) {
+                float vv[8];
+                unpack8(ld16(kb + (int64_t)key * 2 * C + C), vv);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += p * vv[i];
+                for (int i = 0; i < 8; ++i) acc[i] += p * vv[i];
+            }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) red[kslot * 32 + part * 8 + i] = acc[i];
+    for (int i = 0; i < 8; ++i) red[kslot * HDP + part * 8 + i] = acc[i];
     __syncthreads();
-    if (threadIdx.x < 32) {
+    if ((int)threadIdx.x < hd) {
         float s = 0.f;
-        for (int k = 0; k < 64; ++k) s += red[k * 32 + threadIdx.x];
-        out[(int64_t)b * C + h * AHD + threadIdx.x] = f2bf(s);
+        for (int k = 0; k < KS; ++k) s += red[k * HDP + threadIdx.x];
+        out[(int64_t)b * C + h * hd + threadIdx.x] = f2bf(s);
     }
 }
 
+template <int PARTS>
 __global__ void __launch_bounds__(256)
 k_class_attn_bwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, const float* __restrict__ probs,
                  const bf16_t* __restrict__ dout, bf16_t* __restrict__ dq, bf16_t* __restrict__ dkv,
-                 int N, int heads, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];     // dp[N] | red[64*32]
+                 int N, int heads, int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];     // dp[N] | red[KS*HDP]
+    constexpr int KS = 256 / PARTS, HDP = PARTS * 8;
     float* dps = sm;
     float* red = sm + ((N + 63) & ~63);
     __shared__ float wred[4];
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int C = heads * AHD;
-    const int part = threadIdx.x & 3, kslot = threadIdx.x >> 2;
-    float qv[8], gv[8];
-    unpack8(ld16(q + (int64_t)b * C + h * AHD + part * 8), qv);
-    unpack8(ld16(dout + (int64_t)b * C + h * AHD + part * 8), gv);
-    const bf16_t* kb = kv + (int64_t)b * N * 2 * C + h * AHD + part * 8;
-    bf16_t* db = dkv + (int64_t)b * N * 2 * C + h * AHD + part * 8;
+    const int C = heads * hd;
+    const int part = threadIdx.x % PARTS, kslot = threadIdx.x / PARTS;
+    const bool pok = part * 8 < hd;
+    float qv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (pok) {
+        unpack8(ld16(q + (int64_t)b * C + h * hd + part * 8), qv);
+        unpack8(ld16(dout + (int64_t)b * C + h * hd + part * 8), gv);
+    }
+    const bf16_t* kb = kv + (int64_t)b * N * 2 * C + h * hd + part * 8;
+    bf16_t* db = dkv + (int64_t)b * N * 2 * C + h * hd + part * 8;
     const float* pr = probs + ((int64_t)b * heads + h) * N;
     // dp_k = <dout, V_k>;  dV_k = p_k * dout;  dot = sum_k p_k dp_k
     float dot = 0.f;
-    for (int k0 = 0; k0 < N; k0 += 64) {
+    for (int k0 = 0; k0 < N; k0 += KS) {
         const int key = k0 + kslot;
         float d = 0.f;
-        if (key < N) {
+        if (key < N && pok) {
             float vv[8], o8[8];
             unpack8(ld16(kb + (int64_t)key * 2 * C + C), vv);
             const float p = pr[key];
@@ -462,6 +416,7 @@ k_class_attn_bwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, co
         }
         d += __shfl_xor(d, 1, 64);
         d += __shfl_xor(d, 2, 64);
+        if (PARTS == 8) d += __shfl_xor(d, 4, 64);
         if (key < N && part == 0) { dps[key] = d; dot += pr[key] * d; }
     }
     dot = group_sum<64>(dot);
@@ -469,9 +424,9 @@ k_class_attn_bwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, co
     __syncthreads();
     dot = wred[0] + wred[1] + wred[2] + wred[3];
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k0 = 0; k0 < N; k0 += 64) {
+    for (int k0 = 0; k0 < N; k0 += KS) {
         const int key = k0 + kslot;
-        if (key < N) {
+        if (key < N && pok) {
             const float ds = pr[key] * (dps[key] - dot) * scale;       // d(score)/d(q.k)
             float kk[8], o8[8];
             unpack8(ld16(kb + (int64_t)key * 2 * C), kk);
@@ -481,12 +436,12 @@ k_class_attn_bwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, co
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) red[kslot * 32 + part * 8 + i] = acc[i];
+    for (int i = 0; i < 8; ++i) red[kslot * HDP + part * 8 + i] = acc[i];
     __syncthreads();
-    if (threadIdx.x < 32) {
+    if ((int)threadIdx.x < hd) {
         float s = 0.f;
-        for (int k = 0; k < 64; ++k) s += red[k * 32 + threadIdx.x];
-        dq[(int64_t)b * C + h * AHD + threadIdx.x] = f2bf(s);
+        for (int k = 0; k < KS; ++k) s += red[k * HDP + threadIdx.x];
+        dq[(int64_t)b * C + h * hd + threadIdx.x] = f2bf(s);
     }
 }
 
@@ -496,12 +451,22 @@ k_class_attn_bwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, co
                   MHSA_FWD_CASE(10, HDV) MHSA_FWD_CASE(12, HDV) MHSA_FWD_CASE(14, HDV)             \
                   default: hipLaunchKernelGGL((k_mhsa_fwd<16, HDV>), grid, dim3(256), lds, s, qkv, out, lse, N, heads, scale); break; }
 
+// N <= 256 with head_dim 32 / 64: one workgroup holds the whole head in LDS (kernels above); anything else (448-px inputs,
+// head_dim 48 of VOLO-D4/D5) goes to the key/query-blocked kernels of mhsa_flash.hip.  AP_MHSA_FLASH=1 forces the blocked path
+// (parity tests run both on the same inputs).
+static bool mhsa_use_flash(int N, int hd) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("AP_MHSA_FLASH"); force = (e && e[0] == '1') ? 1 : 0; }
+    return force || N > 256 || hd == 48;
+}
+
 extern "C" {
 
 int ap_mhsa_fwd(const ap_bf16* qkv, ap_bf16* out, float* lse, int B, int N, int heads, int hd, float scale, ap_stream_t stream) {
     if (!qkv || !out || !lse) return AP_ERR_NULL;
     if (B <= 0 || N <= 0 || heads <= 0) return AP_ERR_SHAPE;
-    if ((hd != 32 && hd != 64) || N > 256) return AP_ERR_UNSUPPORTED;
+    if (hd != 32 && hd != 48 && hd != 64) return AP_ERR_UNSUPPORTED;
+    if (mhsa_use_flash(N, hd)) return ap_mhsa_flash_fwd(qkv, out, lse, B, N, heads, hd, scale, (hipStream_t)stream);
     const int nt = 2 * ((N + 31) / 32);
     const dim3 grid(B * heads);
     const size_t lds = (size_t)2 * nt * 16 * hd * sizeof(bf16_t);
@@ -517,11 +482,21 @@ int ap_mhsa_fwd(const ap_bf16* qkv, ap_bf16* out, float* lse, int B, int N, int 
     return ap_check_launch();
 }
 
+size_t ap_mhsa_bwd_workspace(int B, int N, int heads, int hd) {
+    if (B <= 0 || N <= 0 || heads <= 0) return 0;
+    return mhsa_use_flash(N, hd) ? ap_mhsa_flash_bwd_ws(B, N, heads) : 0;
+}
+
 int ap_mhsa_bwd(const ap_bf16* qkv, const ap_bf16* out, const ap_bf16* dout, const float* lse, ap_bf16* dqkv,
-                int B, int N, int heads, int hd, float scale, ap_stream_t stream) {
+                int B, int N, int heads, int hd, float scale, void* workspace, size_t ws_bytes, ap_stream_t stream) {
     if (!qkv || !out || !dout || !lse || !dqkv) return AP_ERR_NULL;
     if (B <= 0 || N <= 0 || heads <= 0) return AP_ERR_SHAPE;
-    if ((hd != 32 && hd != 64) || N > 256) return AP_ERR_UNSUPPORTED;
+    if (hd != 32 && hd != 48 && hd != 64) return AP_ERR_UNSUPPORTED;
+    if (mhsa_use_flash(N, hd)) {
+        if (!workspace) return AP_ERR_NULL;
+        if (ws_bytes < ap_mhsa_flash_bwd_ws(B, N, heads)) return AP_ERR_SHAPE;
+        return ap_mhsa_flash_bwd(qkv, out, dout, lse, dqkv, B, N, heads, hd, scale, (float*)workspace, (hipStream_t)stream);
+    }
     const int nt = 2 * ((N + 31) / 32);
     const dim3 grid(B * heads);
     const size_t lds = (size_t)4 * nt * 16 * hd * sizeof(bf16_t) + (size_t)2 * nt * 16 * sizeof(float);
@@ -542,11 +517,12 @@ int ap_class_attn_fwd(const ap_bf16* q, const ap_bf16* kv, ap_bf16* out, float* 
                       float scale, ap_stream_t stream) {
     if (!q || !kv || !out || !probs) return AP_ERR_NULL;
     if (B <= 0 || N <= 0 || heads <= 0) return AP_ERR_SHAPE;
-    if (hd != AHD) return AP_ERR_UNSUPPORTED;
-    const size_t lds = ((size_t)((N + 63) & ~63) + 64 * 32) * sizeof(float);
+    if (hd != 32 && hd != 48 && hd != 64) return AP_ERR_UNSUPPORTED;
+    const size_t lds = ((size_t)((N + 63) & ~63) + 64 * 32) * sizeof(float);          // KS * HDP = 2048 floats for both PARTS
     if (lds > 64 * 1024) return AP_ERR_UNSUPPORTED;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_class_attn_fwd, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, out, probs, N, heads, scale);
+    if (hd == 32) hipLaunchKernelGGL(k_class_attn_fwd<4>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, out, probs, N, heads, hd, scale);
+    else hipLaunchKernelGGL(k_class_attn_fwd<8>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, out, probs, N, heads, hd, scale);
     return ap_check_launch();
 }
 
@@ -554,11 +530,12 @@ int ap_class_attn_bwd(const ap_bf16* q, const ap_bf16* kv, const float* probs, c
                       int B, int N, int heads, int hd, float scale, ap_stream_t stream) {
     if (!q || !kv || !probs || !dout || !dq || !dkv) return AP_ERR_NULL;
     if (B <= 0 || N <= 0 || heads <= 0) return AP_ERR_SHAPE;
-    if (hd != AHD) return AP_ERR_UNSUPPORTED;
+    if (hd != 32 && hd != 48 && hd != 64) return AP_ERR_UNSUPPORTED;
     const size_t lds = ((size_t)((N + 63) & ~63) + 64 * 32) * sizeof(float);
     if (lds > 64 * 1024) return AP_ERR_UNSUPPORTED;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_class_attn_bwd, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, probs, dout, dq, dkv, N, heads, scale);
+    if (hd == 32) hipLaunchKernelGGL(k_class_attn_bwd<4>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, probs, dout, dq, dkv, N, heads, hd, scale);
+    else hipLaunchKernelGGL(k_class_attn_bwd<8>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, probs, dout, dq, dkv, N, heads, hd, scale);
     return ap_check_launch();
 }
 

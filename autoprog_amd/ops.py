@@ -193,8 +193,10 @@ def mhsa_bwd(qkv, out, dout, lse, B, N, heads, scale):
     _req(qkv, BF16, "qkv"); _req(out, BF16, "out"); _req(dout, BF16, "dout")
     C = qkv.shape[-1] // 3
     dqkv = torch.empty_like(qkv)
+    ws_bytes = lib.ap_mhsa_bwd_workspace(B, N, heads, C // heads)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=qkv.device) if ws_bytes else None
     check(lib.ap_mhsa_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), B, N, heads, C // heads,
-                          float(scale), _stream()), "ap_mhsa_bwd")
+                          float(scale), ws.data_ptr() if ws is not None else None, ws_bytes, _stream()), "ap_mhsa_bwd")
     return dqkv
 
 

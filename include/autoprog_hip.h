@@ -106,11 +106,17 @@ int ap_avgpool2_fwd(const ap_bf16* x, ap_bf16* y, int B, int H, int W, int C, ap
 int ap_avgpool2_bwd_acc(const ap_bf16* dpooled, ap_bf16* dx, int B, int H, int W, int C, ap_stream_t stream);
 
 /* ---- Multi-head self-attention core (models/volo.py:188-197) ---------------------------
- * qkv [B,N,3C] packed (channel = which*C + head*hd + d), out [B,N,C], lse [B,heads,N]      */
+ * qkv [B,N,3C] packed (channel = which*C + head*hd + d), out [B,N,C], lse [B,heads,N].
+ * head_dim 32 / 48 / 64 (VOLO-D1..D3 and DeiT: 32 / 64; VOLO-D4/D5: 48, models/volo.py:776-821), any N:
+ * N <= 256 with head_dim 32 / 64 runs LDS-resident kernels, everything else key/query-blocked ones.
+ * The backward of the blocked path needs ap_mhsa_bwd_workspace() bytes of device scratch (0 for the
+ * resident path: `workspace` may then be NULL).                                              */
 int ap_mhsa_fwd(const ap_bf16* qkv, ap_bf16* out, float* lse, int B, int N, int heads, int hd,
                 float scale, ap_stream_t stream);
+size_t ap_mhsa_bwd_workspace(int B, int N, int heads, int hd);
 int ap_mhsa_bwd(const ap_bf16* qkv, const ap_bf16* out, const ap_bf16* dout, const float* lse,
-                ap_bf16* dqkv, int B, int N, int heads, int hd, float scale, ap_stream_t stream);
+                ap_bf16* dqkv, int B, int N, int heads, int hd, float scale,
+                void* workspace, size_t ws_bytes, ap_stream_t stream);
 
 /* ---- Class attention core (models/volo.py:264-274): one query per image ----------------
  * q [B,C] (un-scaled), kv [B,N,2C] (channel = which*C + head*hd + d), out [B,C], probs [B,heads,N] */

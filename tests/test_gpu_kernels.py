@@ -212,7 +212,10 @@ def test_avgpool(ops, B, H, W, C):
 
 
 @pytest.mark.parametrize("B,N,heads,hd", [(2, 196, 12, 32), (3, 64, 2, 32), (2, 100, 4, 32), (1, 144, 12, 32), (2, 197, 3, 32), (2, 25, 2, 32),
-                                          (1, 256, 2, 32), (5, 36, 1, 32), (2, 197, 3, 64), (2, 64, 2, 64), (1, 256, 1, 64), (3, 50, 6, 64)])
+                                          (1, 256, 2, 32), (5, 36, 1, 32), (2, 197, 3, 64), (2, 64, 2, 64), (1, 256, 1, 64), (3, 50, 6, 64),
+                                          # key/query-blocked kernels (mhsa_flash.hip): head_dim 48 of VOLO-D4/D5, N > 256 (448 px -> 784 tokens)
+                                          (2, 784, 16, 48), (1, 196, 16, 48), (2, 50, 3, 48), (1, 784, 2, 32), (1, 400, 3, 64), (2, 257, 1, 32),
+                                          (1, 130, 2, 48), (3, 64, 1, 48), (1, 1025, 1, 48)])
 def test_mhsa(ops, B, N, heads, hd):
     C = heads * hd
     qkv = rnd(B * N, 3 * C, seed=1)
@@ -233,15 +236,15 @@ def test_mhsa(ops, B, N, heads, hd):
         assert rel(d[:, i], g[:, i]) < 1.5e-2, nm
 
 
-@pytest.mark.parametrize("B,N,heads", [(2, 197, 12), (3, 65, 2), (4, 17, 1)])
-def test_class_attention(ops, B, N, heads):
-    C = heads * 32
+@pytest.mark.parametrize("B,N,heads,hd", [(2, 197, 12, 32), (3, 65, 2, 32), (4, 17, 1, 32), (2, 785, 16, 48), (3, 197, 3, 64), (2, 50, 2, 48)])
+def test_class_attention(ops, B, N, heads, hd):
+    C = heads * hd
     q, kv, do = rnd(B, C, seed=1), rnd(B * N, 2 * C, seed=2), rnd(B, C, seed=3)
-    scale = 32 ** -0.5
+    scale = hd ** -0.5
     qr = q.double().requires_grad_(True)
-    kvr = kv.double().reshape(B, N, 2, heads, 32).requires_grad_(True)
+    kvr = kv.double().reshape(B, N, 2, heads, hd).requires_grad_(True)
     kk, vv = kvr[:, :, 0].transpose(1, 2), kvr[:, :, 1].transpose(1, 2)
-    att = torch.softmax((qr.reshape(B, heads, 1, 32) * scale) @ kk.transpose(-1, -2), dim=-1)
+    att = torch.softmax((qr.reshape(B, heads, 1, hd) * scale) @ kk.transpose(-1, -2), dim=-1)
     orf = (att @ vv).transpose(1, 2).reshape(B, C)
     orf.backward(do.double())
     o, probs = ops.class_attn_fwd(dev(q), dev(kv), B, N, heads, scale)
@@ -298,7 +301,7 @@ def test_errors_are_loud(ops):
     with pytest.raises(AutoProgHipError):
         ops.layernorm_fwd(torch.zeros(4, 64, dtype=torch.bfloat16), torch.ones(64), torch.zeros(64), 1e-5)   # CPU tensor
     with pytest.raises(AutoProgHipError):
-        ops.mhsa_fwd(torch.zeros(2 * 300, 96, dtype=torch.bfloat16, device="cuda"), 2, 300, 1, 32 ** -0.5)   # N > 256
+        ops.mhsa_fwd(torch.zeros(2 * 30, 3 * 40, dtype=torch.bfloat16, device="cuda"), 2, 30, 1, 40 ** -0.5)   # head_dim 40: unsupported
 
 
 def test_fused_adamw_ema_matches_torch(ops):
@@ -377,15 +380,16 @@ def test_bn_relu_fused(ops, B, H, W, C):
     assert rel(ye, torch.relu(bn(x.double().permute(0, 3, 1, 2))).permute(0, 2, 3, 1)) < TOL_BF16
 
 
-@pytest.mark.parametrize("env", [{"AP_GEMM_NT_P": "1"}, {"AP_GEMM_NT_P": "4"}, {"AP_GEMM_NT_RING": "1"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"},
+@pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_GEMM_NT_P": "1"}, {"AP_GEMM_NT_P": "4"}, {"AP_GEMM_NT_RING": "1"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"},
                                  {"AP_GEMM_TN_RING": "1"}, {"AP_ASYNC_WGRAD": "1"}])
 def test_experimental_kernel_paths_stay_parity_green(env):
     """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:
     re-run the GEMM / block tests in a child process with the switch set (the switches are read once per process)"""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sel = "gemm and not experimental" if "WGRAD" not in next(iter(env)) else "vs_reference_golden or grad_sink"
-    files = ["tests/test_gpu_kernels.py"] if "WGRAD" not in next(iter(env)) else ["tests/test_gpu_blocks.py", "tests/test_gpu_model.py"]
+    key = next(iter(env))
+    sel = "test_mhsa" if "MHSA" in key else ("gemm and not experimental" if "WGRAD" not in key else "vs_reference_golden or grad_sink")
+    files = ["tests/test_gpu_kernels.py"] if "WGRAD" not in key else ["tests/test_gpu_blocks.py", "tests/test_gpu_model.py"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", sel] + files, cwd=root, env=dict(os.environ, **env),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
@@ -423,8 +427,9 @@ def test_c_abi_error_codes_and_empty_inputs(ops):
     assert lib.ap_gemm_tn_acc_grouped(ctypes.cast(arr, ctypes.c_void_p), 1, st) == 0
     # attention
     q = torch.zeros(2 * 16, 3 * 48, dtype=torch.bfloat16, device="cuda")
-    assert lib.ap_mhsa_fwd(P(q), P(q), P(f), 2, 16, 1, 48, ctypes.c_float(0.1), st) == -2               # head_dim 48
-    assert lib.ap_mhsa_fwd(P(q), P(q), P(f), 1, 300, 1, 32, ctypes.c_float(0.1), st) == -2              # more than 256 tokens
+    assert lib.ap_mhsa_fwd(P(q), P(q), P(f), 2, 16, 1, 40, ctypes.c_float(0.1), st) == -2               # head_dim 40
+    assert lib.ap_mhsa_bwd_workspace(2, 196, 12, 32) == 0 and lib.ap_mhsa_bwd_workspace(2, 784, 16, 48) == 2 * 16 * 784 * 4
+    assert lib.ap_mhsa_bwd(P(q), P(q), P(q), P(f), P(q), 1, 300, 1, 32, ctypes.c_float(0.1), None, 0, st) == -4   # blocked path without workspace
     assert lib.ap_mhsa_fwd(P(q), None, P(f), 2, 16, 1, 32, ctypes.c_float(0.1), st) == -4
     assert lib.ap_outlook_fwd(P(x), P(x), 88, P(x), 1, 8, 8, 1, 16, ctypes.c_float(0.25), st) == -2     # outlook head_dim != 32
     torch.cuda.synchronize()                                                                          # nothing above may have faulted

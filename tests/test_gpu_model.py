@@ -159,6 +159,66 @@ def test_d1_shapes_droppath_and_oracle_agreement():
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
 
 
+def test_volo_d5_shapes_448_vs_oracle():
+    """BASELINE configs[4] shapes in bf16: VOLO-D5 widths (384 / 768 channels, 12 / 16 heads -> head_dim 32 outlook, head_dim 48
+    attention, mlp ratio 4, stem width 128; models/volo.py:799-821) at 448 px (56x56 outlook grid, 784 tokens -> the key/query-
+    blocked attention kernels), one block per kind, batch 1: forward, loss and every parameter gradient against the oracle."""
+    from autoprog_amd.models.volo import VOLO
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    torch.manual_seed(0)
+    arch = dict(layers=[1, 2, 0, 0], embed_dims=[384, 768, 768, 768], num_heads=[12, 16, 16, 16])
+    model = VOLO(arch["layers"], img_size=448, num_classes=96, embed_dims=arch["embed_dims"], num_heads=arch["num_heads"],
+                 mlp_ratios=[4, 4, 4, 4], downsamples=[True, False, False, False], outlook_attention=[True, False, False, False],
+                 post_layers=["ca", "ca"], stem_hidden_dim=128).cuda().train()
+    B, r = 1, 448
+    x = torch.randn(B, 3, r, r, device="cuda")
+    np.random.seed(4)
+    x_cls, x_aux, bb = model(x)
+    assert x_aux.shape == (B, 784, 96)
+    g = torch.Generator().manual_seed(1)
+    target = torch.softmax(torch.randn(B, 96, 2 + 784, generator=g) * 3, dim=1).cuda()
+    loss = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=96)((x_cls, x_aux, bb), target)
+    loss.backward()
+    p = {k: v.detach().double().cpu() for k, v in model.state_dict().items()}
+    for v in p.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    rng = np.random.RandomState(4)
+    lam, box = R.draw_mix_box((B, r // 8, r // 8, 384), 2, 1.0, rng)
+    assert tuple(bb) == tuple(box)
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    ref = R.volo_forward(p, x.double().cpu(), train=True, mix=(lam, box), **arch)
+    ref_loss = R.token_label_ce(ref, target.double().cpu(), 0.5, 1.0)
+    ref_loss.backward()
+    assert rel(x_cls, ref[0]) < 3e-2 and rel(x_aux, ref[1]) < 3e-2, (rel(x_cls, ref[0]), rel(x_aux, ref[1]))
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 3e-3 * float(ref_loss.detach())
+    errs = {n: rel(q.grad, p[n].grad) for n, q in model.named_parameters() if float(p[n].grad.norm()) > 1e-9}
+    print("D5-shape grad errors: max %.4f (%s)" % (max(errs.values()), max(errs, key=errs.get)))
+    bad = {k: v for k, v in errs.items() if v > (0.15 if k.startswith("patch_embed.") else 6e-2)}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+
+
+def test_volo_d5_full_depth_448_smoke():
+    """volo_d5(img_size=448) (models/volo.py:799-821; BASELINE configs[4] in bf16): one full forward / loss / backward at batch 2
+    through the HIP kernels -- shapes, finiteness, every parameter receives a gradient, elastic depth mask works on it."""
+    from autoprog_amd.models import create_model
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    torch.manual_seed(0)
+    model = create_model("volo_d5", img_size=448, drop_path_rate=0.1).cuda().train()
+    assert sum(p.numel() for p in model.parameters()) == 295907168          # SURVEY.md / BASELINE.md: exact D5 parameter count
+    x = torch.randn(2, 3, 448, 448, device="cuda")
+    target = torch.softmax(torch.randn(2, 1000, 2 + 784, device="cuda") * 3, dim=1)
+    np.random.seed(0)
+    out = model(x)
+    assert out[0].shape == (2, 1000) and out[1].shape == (2, 784, 1000)
+    loss = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0)(out, target)
+    loss.backward()
+    assert torch.isfinite(loss) and 6.0 < float(loss) < 12.0, float(loss)
+    for n, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    assert float(model.network[3][5].attn.qkv.weight.grad.abs().sum()) > 0
+
+
 def test_product_never_imports_oracle():
     import os
     import re

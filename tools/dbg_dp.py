@@ -13,7 +13,7 @@ def worker(rank, world, port):
     model = _make()
     model.set_sample_config(dict(layer_num=4, min_layer_num=3, max_layer_num=6))
     red = GradientBucketReducer(list(model.parameters()), bucket_bytes=64 << 10, world_size=world)
-    red.install_sink()
+    red.install_sink(model)
     names = {id(p): n for n, p in model.named_parameters()}
     log = []
     orig = red._on_grad

@@ -13,7 +13,7 @@ torch.backends.cudnn.benchmark = True
 torch.manual_seed(0); np.random.seed(0)
 model = create_model("model_variant", variant="volo_h12_l18", drop_path_rate=0.1).cuda().train()
 loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=1000)
-red = GradientBucketReducer(list(model.parameters()), world_size=1); red.install_sink()
+red = GradientBucketReducer(list(model.parameters()), world_size=1); red.install_sink(model)
 opt = FlatAdamWEma(model, red, lr=1.6e-3, weight_decay=0.05, ema_decays=[0.998, 0.9986, 0.999, 0.9996])
 B = 128
 g = torch.Generator().manual_seed(0)
