@@ -21,7 +21,7 @@ class GemmEpilogue(Structure):
 class TnProblem(Structure):
     """ap_tn_problem (include/autoprog_hip.h)"""
     _fields_ = [("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int), ("C", c_void_p), ("ldc", c_int),
-                ("M", c_int), ("N1", c_int), ("N2", c_int), ("colsum_A", c_void_p)]
+                ("M", c_int), ("N1", c_int), ("N2", c_int), ("alpha", c_float), ("colsum_A", c_void_p), ("colsum_weight", c_void_p), ("colsum_scale", c_float)]
 
 
 TN_MAX_GROUP = 8
@@ -37,13 +37,14 @@ _SIGNATURES = {
     "ap_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, _P]),
     "ap_gemm_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, POINTER(GemmEpilogue), _P]),
     "ap_gemm_tn_acc": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
-    "ap_gemm_tn_acc_grouped": (_I, [_P, _I, _P]),
+    "ap_gemm_tn_grouped_workspace": (ctypes.c_size_t, [_P, _I]),
+    "ap_gemm_tn_acc_grouped": (_I, [_P, _I, _P, ctypes.c_size_t, _P]),
     "ap_colsum_acc": (_I, [_P, _I, _P, _I, _I, _P]),
     "ap_outlook_fwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "ap_outlook_bwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "ap_avgpool2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "ap_avgpool2_bwd_acc": (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    "ap_mhsa_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "ap_mhsa_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P]),
     "ap_mhsa_bwd_workspace": (ctypes.c_size_t, [_I, _I, _I, _I]),
     "ap_mhsa_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, ctypes.c_size_t, _P]),
     "ap_class_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),

@@ -688,13 +688,21 @@ __device__ __forceinline__ bf16x8 tr_frag_at(const bf16_t* tile, int base, int k
 struct TnArgs {
     const bf16_t* A; const bf16_t* B; float* C; float* colsum;
     int lda, ldb, ldc, M, N1, N2, steps_per_split, t1, t2, nblocks, start;
+    const bf16_t* cs_weight;    // per-token weights of the fused column sum (bf16 [M], nullptr = ones)
+    float cs_scale;             // factor applied to the column sums
+    float alpha;                // factor applied to the product
+    float* slab;                // deterministic mode: partial tiles [splits][N1][N2] (+ [splits][N1] column sums behind them), else nullptr
+    int splits;
 };
+// deterministic mode: partial results are STORED per token split and summed in split order by k_tn_reduce
+struct TnDet { float* slab; float* cs_slab; };
 #define TN_MAX_GROUP 8
 struct TnGroup { TnArgs p[TN_MAX_GROUP]; int count; };
 
 __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
                                         int M, int N1, int N2, int steps_per_split, float* __restrict__ colsum, int t1, int t2, int nblocks, int block,
-                                        bf16_t* sA, bf16_t* sB) {
+                                        bf16_t* sA, bf16_t* sB, const bf16_t* __restrict__ cs_weight = nullptr, float cs_scale = 1.0f,
+                                        float* __restrict__ slab = nullptr, int splits = 1, float alpha = 1.0f) {
     // XCD-aware decode: workgroups that share an XCD (and its L2) get consecutive ids, i.e. all output
     // tiles of the SAME token split, so each token range is fetched from HBM by one L2 only
     // (before: 347 MB of beyond-L2 traffic for 77 MB of operands on the qkv shape)
@@ -719,6 +727,21 @@ __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, c
     // (columns beyond N1 / N2 only feed output rows / columns that are never stored: their chunk index is clamped into the
     // row instead of being guarded, so ragged tiles -- N = 192, 486, 576 -- take the fast path too)
     const int ca = min(n0 + j * 8, lda - 8), cb = min(k0 + j * 8, ldb - 8);
+    // per-token weights of the fused column sum travel with the operands (same prefetch distance): loading them inside the MFMA loop
+    // made the loop wait for ALL older loads -- the operand prefetch included -- and cost 0.8 ms per training step
+    // (branch-free: a guarded load compiles to an exec-masked block, and the wait-count pass then drains the operand prefetch at its join)
+    const bool cs_w = (colsum != nullptr) && (cs_weight != nullptr) && (by == 0) && (wk == 0);
+    const bf16_t* wsrc = (cs_weight != nullptr) ? cs_weight : A;                  // any valid address when there are no weights
+    const int wmax = (cs_weight != nullptr) ? ((M + 7) & ~7) - 8 : 0;            // the weight vector is padded to a multiple of 8 tokens
+    // only the few waves that own a column-sum (wk == 0 of the by == 0 tiles) of a weighted problem load them: a PROVABLY wave-uniform
+    // branch (readfirstlane), so the other waves neither issue the two extra loads per step nor wait for them
+    const bool cs_w_u = __builtin_amdgcn_readfirstlane((int)cs_w) != 0;
+    auto wload = [&](u32x4* rw, int step) {
+        if (cs_w_u) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) rw[ks] = ld16(wsrc + min(step * TM + ks * 32 + 8 * (lane >> 4), wmax));
+        }
+    };
     auto gload = [&](u32x4* ra, u32x4* rb, int step) {
         if (step < step_end && (step + 1) * TM <= M) {
 #pragma unroll
@@ -760,7 +783,8 @@ __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, c
         const int r = srow + 16 * t;
         woff[t] = r * 128 + ((j ^ tn_swz(r)) << 3);
     }
-    auto stage_and_compute = [&](u32x4* ra, u32x4* rb, int refill_step) {
+    auto stage_and_compute = [&](u32x4* ra, u32x4* rb, u32x4* rw, int refill_step) {
+        const u32x4 wcur[2] = {rw[0], rw[1]};          // this step's weights (the refill below overwrites the set)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             st16(sA + woff[i], ra[i]);
@@ -768,6 +792,7 @@ __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, c
         }
         __syncthreads();
         gload(ra, rb, refill_step);
+        wload(rw, refill_step);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[4], bfr[4];
@@ -782,27 +807,49 @@ __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, c
                 for (int kt = 0; kt < 4; ++kt)
                     acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
             if (do_colsum) {
+                const bf16x8 wfrag = cs_w ? __builtin_bit_cast(bf16x8, wcur[ks]) : ones;       // element j <-> token 8g + j of this k-step
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) csum[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], ones, csum[nt], 0, 0, 0);
+                for (int nt = 0; nt < 4; ++nt) csum[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], wfrag, csum[nt], 0, 0, 0);
             }
         }
         __syncthreads();
     };
+    u32x4 rw0[2] = {zero4, zero4}, rw1[2] = {zero4, zero4};
     gload(ra0, rb0, step_begin);
+    wload(rw0, step_begin);
     gload(ra1, rb1, step_begin + 1);
+    wload(rw1, step_begin + 1);
     for (int step = step_begin; step < step_end; step += 2) {
-        stage_and_compute(ra0, rb0, step + 2);
-        if (step + 1 < step_end) stage_and_compute(ra1, rb1, step + 3);
+        stage_and_compute(ra0, rb0, rw0, step + 2);
+        if (step + 1 < step_end) stage_and_compute(ra1, rb1, rw1, step + 3);
     }
     const int fr = lane & 15, g = lane >> 4;
+    // deterministic mode: this split's partial tile / column sums are STORED (k_tn_reduce adds the splits in order)
+    float* cs_out = slab ? slab + (int64_t)splits * N1 * N2 + (int64_t)bz * N1 : colsum;
     if (do_colsum && fr == 0) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + wn * 64 + nt * 16 + 4 * g + r;
-                if (n < N1) atomicAdd(colsum + n, csum[nt][r]);
+                if (n < N1) { if (slab) cs_out[n] = csum[nt][r] * cs_scale; else atomicAdd(cs_out + n, csum[nt][r] * cs_scale); }
             }
+    }
+    if (slab) {
+        float* part = slab + (int64_t)bz * N1 * N2;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const int kk = k0 + wk * 64 + kt * 16 + fr;
+                if (kk >= N2) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn * 64 + nt * 16 + 4 * g + r;
+                    if (n < N1) part[(int64_t)n * N2 + kk] = acc[nt][kt][r] * alpha;
+                }
+            }
+        return;
     }
 #if (AP_ABL & 64)
     {   // ablation: no atomics (keep the accumulators live)
@@ -824,7 +871,7 @@ __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, c
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + wn * 64 + nt * 16 + 4 * g + r;
-                if (n < N1) atomicAdd(C + (int64_t)n * ldc + kk, acc[nt][kt][r]);
+                if (n < N1) atomicAdd(C + (int64_t)n * ldc + kk, acc[nt][kt][r] * alpha);
             }
         }
 }
@@ -850,7 +897,29 @@ k_gemm_tn_grouped(TnGroup grp) {
         if (i < grp.count && (int)blockIdx.x >= grp.p[i].start) pi = i;
     const TnArgs& a = grp.p[pi];
     tn_tile(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N1, a.N2, a.steps_per_split, a.colsum, a.t1, a.t2, a.nblocks,
-            (int)blockIdx.x - a.start, sA, sB);
+            (int)blockIdx.x - a.start, sA, sB, a.cs_weight, a.cs_scale, a.slab, a.splits, a.alpha);
+}
+
+// deterministic mode, second pass: C[n][k] += sum over splits (in split order) of the stored partial tiles; same for the column sums
+__global__ void __launch_bounds__(256)
+k_tn_reduce(TnGroup grp) {
+    for (int pi = 0; pi < grp.count; ++pi) {
+        const TnArgs& a = grp.p[pi];
+        const int64_t nmat = (int64_t)a.N1 * a.N2, ntot = nmat + (a.colsum ? a.N1 : 0);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ntot; i += (int64_t)gridDim.x * 256) {
+            if (i < nmat) {
+                float acc = 0.f;
+                for (int z = 0; z < a.splits; ++z) acc += a.slab[(int64_t)z * nmat + i];
+                const int64_t n = i / a.N2, k = i - n * a.N2;
+                a.C[n * a.ldc + k] += acc;
+            } else {
+                const int64_t n = i - nmat;
+                float acc = 0.f;
+                for (int z = 0; z < a.splits; ++z) acc += a.slab[(int64_t)a.splits * nmat + (int64_t)z * a.N1 + n];
+                a.colsum[n] += acc;
+            }
+        }
+    }
 }
 
 // --------------------------------------------------------------------- wgrad, LDS-DMA ring
@@ -1175,7 +1244,8 @@ int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* 
     return AP_OK;
 }
 
-int ap_gemm_tn_acc_grouped(const ap_tn_problem* problems, int count, ap_stream_t stream) {
+// plan of a grouped launch: token splits per problem such that the launch fills the resident workgroup capacity once
+static int tn_plan(const ap_tn_problem* problems, int count, TnGroup& grp, int& total_blocks, size_t& slab_floats) {
     if (!problems) return AP_ERR_NULL;
     if (count <= 0 || count > AP_TN_MAX_GROUP) return AP_ERR_SHAPE;
     // Two 256-thread workgroups are resident per CU: the launch should fill that single wave of workgroups as fully as
@@ -1211,9 +1281,9 @@ int ap_gemm_tn_acc_grouped(const ap_tn_problem* problems, int count, ap_stream_t
         if (blocks_at(mid) <= capacity) hi = mid; else lo = mid + 1;
     }
     const int sps_target = lo;
-    TnGroup grp;
     grp.count = count;
     int start = 0;
+    slab_floats = 0;
     for (int i = 0; i < count; ++i) {
         const ap_tn_problem& q = problems[i];
         TnArgs& a = grp.p[i];
@@ -1225,11 +1295,39 @@ int ap_gemm_tn_acc_grouped(const ap_tn_problem* problems, int count, ap_stream_t
         a.A = reinterpret_cast<const bf16_t*>(q.A); a.B = reinterpret_cast<const bf16_t*>(q.B); a.C = q.C; a.colsum = q.colsum_A;
         a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.M = q.M; a.N1 = q.N1; a.N2 = q.N2;
         a.steps_per_split = sps; a.t1 = t1; a.t2 = t2; a.nblocks = t1 * t2 * splits; a.start = start;
+        a.cs_weight = reinterpret_cast<const bf16_t*>(q.colsum_weight);
+        a.cs_scale = q.colsum_weight ? q.colsum_scale : 1.0f;
+        a.alpha = q.alpha != 0.0f ? q.alpha : 1.0f;
+        a.slab = nullptr; a.splits = splits;
+        slab_floats += (size_t)splits * ((size_t)q.N1 * q.N2 + (q.colsum_A ? (size_t)q.N1 : 0));
         start += a.nblocks;
     }
     for (int i = count; i < TN_MAX_GROUP; ++i) { grp.p[i] = grp.p[0]; grp.p[i].start = 0x7fffffff; grp.p[i].nblocks = 0; }
+    total_blocks = start;
+    return AP_OK;
+}
+
+size_t ap_gemm_tn_grouped_workspace(const ap_tn_problem* problems, int count) {
+    TnGroup grp; int blocks = 0; size_t fl = 0;
+    if (tn_plan(problems, count, grp, blocks, fl) != AP_OK) return 0;
+    return fl * sizeof(float);
+}
+
+int ap_gemm_tn_acc_grouped(const ap_tn_problem* problems, int count, void* workspace, size_t ws_bytes, ap_stream_t stream) {
+    TnGroup grp; int blocks = 0; size_t fl = 0;
+    const int rc = tn_plan(problems, count, grp, blocks, fl);
+    if (rc != AP_OK) return rc;
+    if (workspace) {                                  // deterministic: stored partial tiles + ordered reduce instead of fp32 atomics
+        if (ws_bytes < fl * sizeof(float)) return AP_ERR_SHAPE;
+        float* w = reinterpret_cast<float*>(workspace);
+        for (int i = 0; i < count; ++i) {
+            grp.p[i].slab = w;
+            w += (size_t)grp.p[i].splits * ((size_t)grp.p[i].N1 * grp.p[i].N2 + (grp.p[i].colsum ? (size_t)grp.p[i].N1 : 0));
+        }
+    }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_gemm_tn_grouped, dim3(start), dim3(256), 0, (hipStream_t)stream, grp);
+    hipLaunchKernelGGL(k_gemm_tn_grouped, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
+    if (workspace) hipLaunchKernelGGL(k_tn_reduce, dim3(1024), dim3(256), 0, (hipStream_t)stream, grp);
     return ap_check_launch();
 }
 

@@ -51,7 +51,8 @@ __device__ __forceinline__ void att_stage_n(bf16_t* const* tiles, const bf16_t* 
 
 template <int NT, int HD>
 __global__ void __launch_bounds__(256)
-k_mhsa_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int heads, float scale) {
+k_mhsa_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int heads, float scale,
+           const float* __restrict__ out_row_scale) {
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     constexpr int Npad = NT * 16;
     constexpr int KC = HD / 32, DT = HD / 16;
@@ -128,7 +129,7 @@ k_mhsa_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __re
             for (int dt = 0; dt < DT; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, att_tr_at<HD>(Vs, vb[dt], 32 * s2), o[dt], 0, 0, 0);
         }
-        const float inv = 1.0f / sum;
+        const float inv = (out_row_scale ? out_row_scale[b] : 1.0f) / sum;      // 0/1 DropPath keep mask of the projection that follows
         if (g == 0 && qt * 16 + fr < N) lse[((int64_t)b * heads + h) * N + qt * 16 + fr] = (mx * c2 + log2f(sum)) * 0.6931471805599453f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -445,11 +446,11 @@ k_class_attn_bwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, co
     }
 }
 
-#define MHSA_FWD_CASE(NTV, HDV) case NTV: hipLaunchKernelGGL((k_mhsa_fwd<NTV, HDV>), grid, dim3(256), lds, s, qkv, out, lse, N, heads, scale); break;
+#define MHSA_FWD_CASE(NTV, HDV) case NTV: hipLaunchKernelGGL((k_mhsa_fwd<NTV, HDV>), grid, dim3(256), lds, s, qkv, out, lse, N, heads, scale, out_row_scale); break;
 #define MHSA_FWD_SWITCH(HDV)                                                                     \
     switch (nt) { MHSA_FWD_CASE(2, HDV) MHSA_FWD_CASE(4, HDV) MHSA_FWD_CASE(6, HDV) MHSA_FWD_CASE(8, HDV)  \
                   MHSA_FWD_CASE(10, HDV) MHSA_FWD_CASE(12, HDV) MHSA_FWD_CASE(14, HDV)             \
-                  default: hipLaunchKernelGGL((k_mhsa_fwd<16, HDV>), grid, dim3(256), lds, s, qkv, out, lse, N, heads, scale); break; }
+                  default: hipLaunchKernelGGL((k_mhsa_fwd<16, HDV>), grid, dim3(256), lds, s, qkv, out, lse, N, heads, scale, out_row_scale); break; }
 
 // N <= 256 with head_dim 32 / 64: one workgroup holds the whole head in LDS (kernels above); anything else (448-px inputs,
 // head_dim 48 of VOLO-D4/D5) goes to the key/query-blocked kernels of mhsa_flash.hip.  AP_MHSA_FLASH=1 forces the blocked path
@@ -462,11 +463,12 @@ static bool mhsa_use_flash(int N, int hd) {
 
 extern "C" {
 
-int ap_mhsa_fwd(const ap_bf16* qkv, ap_bf16* out, float* lse, int B, int N, int heads, int hd, float scale, ap_stream_t stream) {
+int ap_mhsa_fwd(const ap_bf16* qkv, ap_bf16* out, float* lse, int B, int N, int heads, int hd, float scale, const float* out_row_scale,
+                ap_stream_t stream) {
     if (!qkv || !out || !lse) return AP_ERR_NULL;
     if (B <= 0 || N <= 0 || heads <= 0) return AP_ERR_SHAPE;
     if (hd != 32 && hd != 48 && hd != 64) return AP_ERR_UNSUPPORTED;
-    if (mhsa_use_flash(N, hd)) return ap_mhsa_flash_fwd(qkv, out, lse, B, N, heads, hd, scale, (hipStream_t)stream);
+    if (mhsa_use_flash(N, hd)) return ap_mhsa_flash_fwd(qkv, out, lse, B, N, heads, hd, scale, out_row_scale, (hipStream_t)stream);
     const int nt = 2 * ((N + 31) / 32);
     const dim3 grid(B * heads);
     const size_t lds = (size_t)2 * nt * 16 * hd * sizeof(bf16_t);

@@ -64,7 +64,8 @@ __device__ __forceinline__ void own_frag(bf16x8* f, const bf16_t* base, int64_t 
 
 template <int HDP, int DT>
 __global__ void __launch_bounds__(512)
-k_mhsa_flash_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int heads, int hd, float scale, int nqb) {
+k_mhsa_flash_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int heads, int hd, float scale, int nqb,
+                 const float* __restrict__ out_row_scale) {
     extern __shared__ __attribute__((aligned(16))) bf16_t fsm[];
     constexpr int KC = HDP / 32;
     const int wg = blockIdx.x;
@@ -142,7 +143,7 @@ k_mhsa_flash_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float
     if (!active) return;
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
+    const float inv = (out_row_scale ? out_row_scale[b] : 1.0f) / l;
     if (g == 0 && q0 + fr < N) lse[((int64_t)b * heads + h) * N + q0 + fr] = (m * c2 + log2f(l)) * 0.6931471805599453f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -362,13 +363,14 @@ k_mhsa_flash_bwd_q(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ do
     else if (hd == 48) hipLaunchKernelGGL((KERNEL<64, 3>), grid, dim3(512), lds, s, __VA_ARGS__);                      \
     else hipLaunchKernelGGL((KERNEL<64, 4>), grid, dim3(512), lds, s, __VA_ARGS__);
 
-int ap_mhsa_flash_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N, int heads, int hd, float scale, hipStream_t s) {
+int ap_mhsa_flash_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N, int heads, int hd, float scale, const float* out_row_scale,
+                      hipStream_t s) {
     const int nqb = (N + FW - 1) / FW;
     const int hdp = hd == 32 ? 32 : 64;
     const dim3 grid((unsigned)((int64_t)B * heads * nqb));
     const size_t lds = (size_t)4 * FB * hdp * sizeof(bf16_t);
     (void)hipGetLastError();
-    FLASH_DISPATCH(k_mhsa_flash_fwd, qkv, out, lse, N, heads, hd, scale, nqb)
+    FLASH_DISPATCH(k_mhsa_flash_fwd, qkv, out, lse, N, heads, hd, scale, nqb, out_row_scale)
     return ap_check_launch();
 }
 

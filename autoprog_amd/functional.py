@@ -180,17 +180,22 @@ def _launch_wgrads(problems):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             ops.gemm_tn_acc_grouped(problems)
-        for a, b, _, _, _, _ in problems:
-            a.record_stream(side)
-            b.record_stream(side)
+        for prob in problems:
+            prob[0].record_stream(side)
+            prob[1].record_stream(side)
     else:
         ops.gemm_tn_acc_grouped(problems)
 
 
-def _linear_bwd(g, x_in, w, dw, db, n=None, dgelu_of=None, need_dx=True):
-    """shared backward of y = x W^T + b given g = dL/dy (bf16 [M, ld]); accumulates dw/db."""
+def _linear_bwd(g, x_in, w, dw, db, n=None, dgelu_of=None, need_dx=True, row_scale=None, rows_per_scale=1, cs_weight=None, inv_keep=1.0):
+    """shared backward of y = x W^T + b given g = dL/dy (bf16 [M, ld]); accumulates dw/db.
+    DropPath (the branch output is scaled per sample by s = mask/keep and x_in has the rows of dropped samples zeroed): pass
+    row_scale = s (the input gradient gets it in the GEMM epilogue), cs_weight = per-token 0/1 mask and inv_keep = 1/keep:
+    dW = inv_keep * g^T x_in and db = inv_keep * sum_m mask[m] g[m] -- g itself is never scaled."""
     n = w.shape[0] if n is None else n
     prob = (g, x_in, _g2(dw), n, _g2(dw).shape[1], db)
+    if cs_weight is not None:
+        prob = prob + (cs_weight, inv_keep, inv_keep)
     if _wgrad_batch is not None:
         _wgrad_batch.append(prob)
     else:
@@ -198,56 +203,75 @@ def _linear_bwd(g, x_in, w, dw, db, n=None, dgelu_of=None, need_dx=True):
     if not need_dx:
         return None
     wt = bank.get_t(w)                       # [K, ld(N)]
-    return ops.gemm_nt(g, wt, n=wt.shape[0], k=wt.shape[1], dgelu_of=dgelu_of)
+    return ops.gemm_nt(g, wt, n=wt.shape[0], k=wt.shape[1], dgelu_of=dgelu_of, row_scale=row_scale, rows_per_scale=rows_per_scale)
+
+
+def token_mask(keep01, n_tokens):
+    """per-token bf16 keep mask (padded to whole 16-byte chunks) of a per-sample 0/1 mask (slow path; the models prefetch the
+    masks of a whole forward pass in one go, models/volo.py DropPathRng.prefetch)"""
+    m = keep01.to(BF16).repeat_interleave(n_tokens)
+    pad = (-m.numel()) % 8
+    return torch.cat([m, m.new_zeros(pad)]) if pad else m.contiguous()
 
 
 # ----------------------------------------------------------------------- transformer block
 class TransformerBlockFn(torch.autograd.Function):
     """x -> x + rs1*(proj(mhsa(qkv(LN1 x)))) -> + rs2*(fc2(gelu(fc1(LN2 .))))
-    (Transformer.forward, models/volo.py:230-234; timm Block for DeiT).  rs1/rs2 are the
-    per-sample DropPath factors (mask/keep) or None."""
+    (Transformer.forward, models/volo.py:230-234; timm Block for DeiT).  rs1/rs2 are the per-sample DropPath factors
+    (mask/keep) or None; k1/k2 the 0/1 masks as fp32 [B], tm1/tm2 as per-token bf16, inv_keep = 1/keep.
+
+    DropPath costs no extra pass over the gradients.  The INPUT of each scaled Linear has the rows of dropped samples zeroed
+    where it is produced (attention kernel / fc1 epilogue: free, and the forward result is unchanged because those rows are
+    multiplied by 0 anyway), so the weight gradient sum_m s[m] dy[m]^T a[m] = (1/keep) dy^T a_masked needs no scaled copy of dy;
+    the input gradient takes s in its GEMM epilogue and the bias gradient is a mask-weighted column sum."""
 
     @staticmethod
     def forward(ctx, x, rs1, rs2, n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b,
-                B, N, heads, eps):
+                B, N, heads, eps, k1=None, k2=None, tm1=None, tm2=None, inv_keep=1.0):
         C = x.shape[-1]
         x2 = x.reshape(B * N, C).contiguous()
         scale = (C // heads) ** -0.5
+        if rs1 is not None and k1 is None:
+            k1 = (rs1 != 0).float()
+        if rs2 is not None and k2 is None:
+            k2 = (rs2 != 0).float()
         xn1, m1, r1 = ops.layernorm_fwd(x2, n1w, n1b, eps)
         qkv = ops.gemm_nt(xn1, bank.get(qkv_w), bias=qkv_b)
-        o, lse = ops.mhsa_fwd(qkv, B, N, heads, scale)
+        o, lse = ops.mhsa_fwd(qkv, B, N, heads, scale, out_row_scale=k1)                       # rows of dropped samples: zeros
         x1 = ops.gemm_nt(o, bank.get(proj_w), bias=proj_b, row_scale=rs1, rows_per_scale=N, residual=x2)
         xn2, m2, r2 = ops.layernorm_fwd(x1, n2w, n2b, eps)
         h = torch.empty((B * N, fc1_w.shape[0]), dtype=BF16, device=x.device)
-        a = ops.gemm_nt(xn2, bank.get(fc1_w), bias=fc1_b, gelu=True, preact_out=h)
+        a = ops.gemm_nt(xn2, bank.get(fc1_w), bias=fc1_b, gelu=True, preact_out=h, row_scale=k2, rows_per_scale=N)
         y = ops.gemm_nt(a, bank.get(fc2_w), bias=fc2_b, row_scale=rs2, rows_per_scale=N, residual=x1)
-        ctx.save_for_backward(x2, m1, r1, xn1, qkv, o, lse, x1, m2, r2, xn2, h, a, rs1, rs2,
+        if rs1 is not None and tm1 is None:
+            tm1 = token_mask(k1, N)
+        if rs2 is not None and tm2 is None:
+            tm2 = token_mask(k2, N)
+        ctx.save_for_backward(x2, m1, r1, xn1, qkv, o, lse, x1, m2, r2, xn2, h, a, rs1, rs2, tm1, tm2,
                               n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
-        ctx.cfg = (B, N, heads, scale)
+        ctx.cfg = (B, N, heads, scale, float(inv_keep))
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        (x2, m1, r1, xn1, qkv, o, lse, x1, m2, r2, xn2, h, a, rs1, rs2,
+        (x2, m1, r1, xn1, qkv, o, lse, x1, m2, r2, xn2, h, a, rs1, rs2, tm1, tm2,
          n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b) = ctx.saved_tensors
-        B, N, heads, scale = ctx.cfg
+        B, N, heads, scale, inv_keep = ctx.cfg
         params = (n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
         bufs, sunk = _param_grad_buffers(params)
         (dn1w, dn1b, dqkv_w, dqkv_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = bufs
         dy2 = dy.reshape(x2.shape).contiguous()
-        with wgrad_batch():                  # the four weight gradients launch together (side stream) on exit
+        with wgrad_batch():                  # the four weight gradients launch together on exit
             # MLP branch
-            g2 = ops.row_scale(dy2, rs2, N) if rs2 is not None else dy2
-            dh = _linear_bwd(g2, a, fc2_w, dfc2_w, dfc2_b, dgelu_of=h)
+            dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, dgelu_of=h, row_scale=rs2, rows_per_scale=N, cs_weight=tm2, inv_keep=inv_keep)
             dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b)
             dx1 = ops.layernorm_bwd(dxn2, x1, n2w, m2, r2, dy2, dn2w, dn2b)
             # attention branch
-            g1 = ops.row_scale(dx1, rs1, N) if rs1 is not None else dx1
-            do = _linear_bwd(g1, o, proj_w, dproj_w, dproj_b)
-            dqkv = ops.mhsa_bwd(qkv, o, do, lse, B, N, heads, scale)
+            do = _linear_bwd(dx1, o, proj_w, dproj_w, dproj_b, row_scale=rs1, rows_per_scale=N, cs_weight=tm1, inv_keep=inv_keep)
+            dqkv = ops.mhsa_bwd(qkv, o, do, lse, B, N, heads, scale)      # dropped samples: do = 0, so the masked rows of o do not matter
             dxn1 = _linear_bwd(dqkv, xn1, qkv_w, dqkv_w, dqkv_b)
             dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b)
-        return (dx.view(dy.shape), None, None, *_finish_param_grads(params, bufs, sunk), None, None, None, None)
+        return (dx.view(dy.shape), None, None, *_finish_param_grads(params, bufs, sunk), None, None, None, None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------- outlooker block

@@ -47,17 +47,17 @@ def _bf16(x):
 
 
 class DropPathRng:
-    """source of the per-sample DropPath factors mask/keep (timm DropPath: mask = floor(keep+U)).
-    Masks can be injected for parity runs via `queue`."""
+    """source of the per-sample DropPath factors mask/keep (timm DropPath: mask = floor(keep+U)) and of their per-token keep
+    masks (consumed by the bias gradients of the fused blocks).  Masks can be injected for parity runs via `queue`."""
 
     def __init__(self):
         self.queue = []
         self._pool = []
         self._keep_cache = {}          # (keeps, device) -> device tensor: no host->device copy per step (HIP-graph capturable)
 
-    def prefetch(self, keeps, batch, device):
-        """draw the factors of a whole forward pass (one entry of `keeps` per DropPath site, in call order)
-        with three small kernels instead of three per site"""
+    def prefetch(self, keeps, batch, device, tokens=0):
+        """draw the factors of a whole forward pass (one entry of `keeps` per DropPath site, in call order) and, with
+        `tokens` > 0, their per-token bf16 masks, with a handful of small kernels instead of several per site"""
         if self.queue or not keeps:
             self._pool = []
             return
@@ -67,19 +67,26 @@ class DropPathRng:
             if len(self._keep_cache) > 64:
                 self._keep_cache.clear()
             k = self._keep_cache[key] = torch.tensor(keeps, dtype=torch.float32, device=device).unsqueeze(1)
-        f = (torch.rand(len(keeps), batch, device=device) + k).floor_() / k
-        self._pool = [(keeps[i], f[i]) for i in range(len(keeps))]
+        m = (torch.rand(len(keeps), batch, device=device) + k).floor_()                 # 0/1 keep masks
+        f = m / k
+        tm = None
+        if tokens:
+            row = (batch * tokens + 7) // 8 * 8                        # 16-byte aligned rows
+            tm = torch.zeros(len(keeps), row, dtype=BF16, device=device)
+            tm[:, :batch * tokens] = m.to(BF16).repeat_interleave(tokens, dim=1)
+        self._pool = [(keeps[i], f[i], m[i], tm[i] if tm is not None else None, tokens) for i in range(len(keeps))]
 
-    def draw(self, batch, keep, device):
+    def draw(self, batch, keep, device, tokens=0):
+        """-> (factors mask/keep fp32 [batch], 0/1 mask fp32 [batch] or None, per-token bf16 mask or None)"""
         if self.queue:
             m = self.queue.pop(0)
-            return (m.to(device=device, dtype=torch.float32) / keep).contiguous()
+            return (m.to(device=device, dtype=torch.float32) / keep).contiguous(), None, None
         if self._pool:
-            k, f = self._pool.pop(0)
+            k, f, m, tm, tk = self._pool.pop(0)
             if k == keep and f.shape[0] == batch:
-                return f
+                return f, m, (tm if tk == tokens else None)
             self._pool = []
-        return ((keep + torch.rand(batch, device=device)).floor_() / keep).contiguous()
+        return ((keep + torch.rand(batch, device=device)).floor_() / keep).contiguous(), None, None
 
 
 class Mlp(nn.Module):
@@ -203,15 +210,17 @@ class Transformer(nn.Module):
         x = _bf16(x)
         B, C = x.shape[0], x.shape[-1]
         N = x.numel() // (B * C)
-        rs1 = rs2 = None
+        rs1 = rs2 = k1 = k2 = tm1 = tm2 = None
+        keep = 1.0 - self.drop_prob
         if self.training and self.drop_prob > 0.0:
             rng = self.rng or _default_rng
-            rs1 = rng.draw(B, 1.0 - self.drop_prob, x.device)
-            rs2 = rng.draw(B, 1.0 - self.drop_prob, x.device)
+            rs1, k1, tm1 = rng.draw(B, keep, x.device, N)
+            rs2, k2, tm2 = rng.draw(B, keep, x.device, N)
         a, m = self.attn, self.mlp
         return AF.TransformerBlockFn.apply(x, rs1, rs2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,
                                            a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight,
-                                           m.fc1.bias, m.fc2.weight, m.fc2.bias, B, N, a.num_heads, self.norm1.eps)
+                                           m.fc1.bias, m.fc2.weight, m.fc2.bias, B, N, a.num_heads, self.norm1.eps,
+                                           k1, k2, tm1, tm2, 1.0 / keep)
 
 
 _default_rng = DropPathRng()
@@ -494,7 +503,8 @@ class VOLO(nn.Module):
                     for blk in stage:
                         if isinstance(blk, Transformer) and blk.drop_prob > 0.0 and not blk.is_identity_layer:
                             keeps += [1.0 - blk.drop_prob, 1.0 - blk.drop_prob]
-            self.drop_path_rng.prefetch(keeps, x.shape[0], x.device)
+            # the transformer stages run behind the 2x2 Downsample: (H/2)*(W/2) tokens per image
+            self.drop_path_rng.prefetch(keeps, x.shape[0], x.device, tokens=(x.shape[1] // 2) * (x.shape[2] // 2))
         for idx, block in enumerate(self.network):
             if idx == 2:
                 x = AF.AddPosFn.apply(x, self.interpolate_pos_encoding(x))

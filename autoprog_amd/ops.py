@@ -6,6 +6,7 @@ There is no fallback path: a CPU tensor or a missing library raises.
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -121,20 +122,41 @@ def gemm_tn_acc(a, b, c, n1=None, n2=None, colsum=None):
     return c
 
 
+# AP_DETERMINISTIC=1 (or ops.deterministic = True): weight gradients through stored partial tiles + an ordered reduce instead of
+# fp32 atomics -- bitwise reproducible steps (loss-curve pins, debugging) for a few percent of the backward time.
+deterministic = os.environ.get("AP_DETERMINISTIC", "0") == "1"
+
+
 def gemm_tn_acc_grouped(problems):
-    """problems: list of (a, b, c, n1, n2, colsum) as for gemm_tn_acc; ONE launch for the whole list (chunks of 8)."""
+    """problems: list of (a, b, c, n1, n2, colsum[, colsum_weight, colsum_scale[, alpha]]) as for gemm_tn_acc; ONE launch for the whole
+    list (chunks of 8).  colsum_weight: bf16 per-token weights of the column sum (DropPath keep mask), colsum_scale its factor;
+    alpha: factor of the product (c += alpha * a^T b)."""
     from ._lib import TnProblem, TN_MAX_GROUP
     for i0 in range(0, len(problems), TN_MAX_GROUP):
         chunk = problems[i0:i0 + TN_MAX_GROUP]
         arr = (TnProblem * len(chunk))()
-        for q, (a, b, c, n1, n2, colsum) in zip(arr, chunk):
+        for q, prob in zip(arr, chunk):
+            a, b, c, n1, n2, colsum = prob[:6]
+            csw, css = (prob[6], prob[7]) if len(prob) > 6 else (None, 1.0)
+            q.alpha = float(prob[8]) if len(prob) > 8 else 1.0
             _req(a, BF16, "a"); _req(b, BF16, "b"); _req(c, torch.float32, "c")
             if a.shape[0] != b.shape[0]:
                 raise ValueError("gemm_tn_acc_grouped: token counts differ")
             q.A, q.lda, q.B, q.ldb, q.C, q.ldc = a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1], c.data_ptr(), c.shape[1]
             q.M, q.N1, q.N2 = a.shape[0], (c.shape[0] if n1 is None else n1), (c.shape[1] if n2 is None else n2)
             q.colsum_A = colsum.data_ptr() if colsum is not None else None
-        check(lib.ap_gemm_tn_acc_grouped(ctypes.cast(arr, ctypes.c_void_p), len(chunk), _stream()), "ap_gemm_tn_acc_grouped")
+            if csw is not None:
+                _req(csw, BF16, "colsum_weight")
+                if csw.numel() < round_up(a.shape[0], 8) or csw.data_ptr() % 16:
+                    raise AutoProgHipError("colsum_weight needs ceil(M/8)*8 elements and 16-byte alignment")
+            q.colsum_weight = csw.data_ptr() if csw is not None else None
+            q.colsum_scale = float(css)
+        ptr = ctypes.cast(arr, ctypes.c_void_p)
+        ws, ws_bytes = None, 0
+        if deterministic:
+            ws_bytes = lib.ap_gemm_tn_grouped_workspace(ptr, len(chunk))
+            ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=chunk[0][0].device)
+        check(lib.ap_gemm_tn_acc_grouped(ptr, len(chunk), ws.data_ptr() if ws is not None else None, ws_bytes, _stream()), "ap_gemm_tn_acc_grouped")
 
 
 def colsum_acc(a, out, n=None):
@@ -180,12 +202,14 @@ def avgpool2_bwd_acc(dpooled, dx):
 
 
 # ------------------------------------------------------------------------------------- mhsa
-def mhsa_fwd(qkv, B, N, heads, scale):
+def mhsa_fwd(qkv, B, N, heads, scale, out_row_scale=None):
+    """out_row_scale: fp32 [B] factors (0/1 DropPath keep mask) folded into the stored output (see include/autoprog_hip.h)"""
     _req(qkv, BF16, "qkv")
     C = qkv.shape[-1] // 3
     out = torch.empty((B * N, C), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
-    check(lib.ap_mhsa_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, heads, C // heads, float(scale), _stream()), "ap_mhsa_fwd")
+    check(lib.ap_mhsa_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, heads, C // heads, float(scale),
+                          out_row_scale.data_ptr() if out_row_scale is not None else None, _stream()), "ap_mhsa_fwd")
     return out, lse
 
 

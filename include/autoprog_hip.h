@@ -86,9 +86,17 @@ typedef struct ap_tn_problem {
     const ap_bf16* B; int ldb;      /* [M,N2] */
     float* C; int ldc;              /* [N1,N2] += A^T . B */
     int M, N1, N2;
-    float* colsum_A;                /* [N1] += column sums of A, or NULL */
+    float alpha;                    /* C += alpha * A^T . B (0 is read as 1: zero-initialised structs keep the plain product) */
+    float* colsum_A;                /* [N1] += colsum_scale * sum_m w[m] * A[m,n], or NULL */
+    const ap_bf16* colsum_weight;   /* per-token weights w (bf16, ceil(M/8)*8 elements readable, 16-byte aligned), NULL = ones: the DropPath keep mask of the
+                                     * bias gradient d/db of x + (mask/keep) * (y W^T + b), models/volo.py:230-234 */
+    float colsum_scale;             /* used with colsum_weight only (1/keep) */
 } ap_tn_problem;
-int ap_gemm_tn_acc_grouped(const ap_tn_problem* problems, int count, ap_stream_t stream);
+/* `workspace` NULL: partial tiles of the token splits are added with fp32 atomics (results vary in the last bits from run to run).
+ * `workspace` of >= ap_gemm_tn_grouped_workspace() bytes: DETERMINISTIC -- every split stores its partial tile and a second kernel adds
+ * them in split order (bitwise reproducible; the mode behind AP_DETERMINISTIC=1 of the Python layer). */
+size_t ap_gemm_tn_grouped_workspace(const ap_tn_problem* problems, int count);
+int ap_gemm_tn_acc_grouped(const ap_tn_problem* problems, int count, void* workspace, size_t ws_bytes, ap_stream_t stream);
 /* bias gradient: out[n] += sum_m A[m,n] */
 int ap_colsum_acc(const ap_bf16* A, int lda, float* out, int M, int N, ap_stream_t stream);
 
@@ -111,8 +119,11 @@ int ap_avgpool2_bwd_acc(const ap_bf16* dpooled, ap_bf16* dx, int B, int H, int W
  * N <= 256 with head_dim 32 / 64 runs LDS-resident kernels, everything else key/query-blocked ones.
  * The backward of the blocked path needs ap_mhsa_bwd_workspace() bytes of device scratch (0 for the
  * resident path: `workspace` may then be NULL).                                              */
+/* out_row_scale (nullable, fp32 [B]): out[b] is stored multiplied by it.  Used with the 0/1 DropPath keep mask of the projection
+ * that follows: rows of dropped samples are zeros, so the projection's weight gradient dx^T out needs no masked copy of dx
+ * (models/volo.py:230-234).  The backward needs nothing extra: a dropped sample arrives with dout = 0. */
 int ap_mhsa_fwd(const ap_bf16* qkv, ap_bf16* out, float* lse, int B, int N, int heads, int hd,
-                float scale, ap_stream_t stream);
+                float scale, const float* out_row_scale, ap_stream_t stream);
 size_t ap_mhsa_bwd_workspace(int B, int N, int heads, int hd);
 int ap_mhsa_bwd(const ap_bf16* qkv, const ap_bf16* out, const ap_bf16* dout, const float* lse,
                 ap_bf16* dqkv, int B, int N, int heads, int hd, float scale,

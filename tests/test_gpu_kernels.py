@@ -166,6 +166,49 @@ def test_gemm_tn_acc_grouped(ops):
         ops.gemm_tn_acc_grouped([(probs[0][0], probs[1][1][:100], probs[0][2], None, None, None)])      # token counts differ
 
 
+def test_gemm_tn_grouped_deterministic_and_weighted_colsum(ops):
+    """AP_DETERMINISTIC path (stored partial tiles + ordered reduce): bit-identical across runs and equal to the reference;
+    the atomic path agrees to fp32 rounding.  Also the mask-weighted column sum (DropPath bias gradient): colsum += s * sum_m w[m] A[m,n], and the product factor alpha."""
+    M, N1, N2 = 25088 // 4 + 3, 384, 1152                # ragged token count: the last 16-byte chunk of the weights is padded
+    a, b = dev(rnd(M, N1, seed=1)), dev(rnd(M, N2, seed=2))
+    w = (torch.rand(M, generator=torch.Generator().manual_seed(3)) < 0.8).to(torch.bfloat16)
+    wpad = torch.cat([w, torch.zeros((-M) % 8, dtype=torch.bfloat16)])
+    ref_c = 0.8 * (a.double().cpu().t() @ b.double().cpu())
+    ref_cs = 1.25 * (w.double()[:, None] * a.double().cpu()).sum(0)
+    outs = []
+    old = ops.deterministic
+    try:
+        for det in (True, True, False):
+            ops.deterministic = det
+            c = torch.zeros(N1, N2, device="cuda")
+            cs = torch.zeros(N1, device="cuda")
+            ops.gemm_tn_acc_grouped([(a, b, c, N1, N2, cs, dev(wpad), 1.25, 0.8), (b, a, torch.zeros(N2, N1, device="cuda"), N2, N1, None)])
+            assert rel(c, ref_c) < TOL_F32 and rel(cs, ref_cs) < TOL_F32
+            outs.append((c.clone(), cs.clone()))
+    finally:
+        ops.deterministic = old
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])          # deterministic: bitwise
+    assert rel(outs[2][0], outs[0][0]) < 1e-5
+
+
+def test_mhsa_out_row_scale(ops):
+    """0/1 DropPath keep mask folded into the attention output: rows of dropped samples are exact zeros, kept ones unchanged;
+    the backward of a kept sample is unaffected and a dropped one (dout = 0) yields zeros.  Both kernel families."""
+    for (B, N, heads, hd) in [(4, 196, 3, 32), (3, 300, 2, 48)]:
+        C = heads * hd
+        qkv, do = rnd(B * N, 3 * C, seed=1), rnd(B * N, C, seed=2)
+        keep = torch.tensor([1.0, 0.0, 1.0, 1.0][:B])
+        scale = hd ** -0.5
+        o_ref, lse_ref = ops.mhsa_fwd(dev(qkv), B, N, heads, scale)
+        o, lse = ops.mhsa_fwd(dev(qkv), B, N, heads, scale, out_row_scale=keep.cuda())
+        assert torch.equal(o.reshape(B, N, C)[[0, 2]], o_ref.reshape(B, N, C)[[0, 2]]) and torch.equal(lse, lse_ref)
+        assert float(o.reshape(B, N, C)[1].abs().max()) == 0.0
+        do_m = (do.float().reshape(B, N, C) * keep[:, None, None]).to(torch.bfloat16).reshape(B * N, C)      # what the proj dgrad epilogue delivers
+        d1 = ops.mhsa_bwd(dev(qkv), o, dev(do_m), lse, B, N, heads, scale)
+        d0 = ops.mhsa_bwd(dev(qkv), o_ref, dev(do_m), lse, B, N, heads, scale)
+        assert torch.equal(d1, d0) and float(d1.reshape(B, N, 3 * C)[1].abs().max()) == 0.0
+
+
 def test_colsum(ops):
     for M, N in [(1000, 192), (77, 486), (5000, 1000), (10, 16)]:
         a = rnd(M, ops.round_up(N, 8), seed=M)
@@ -418,18 +461,20 @@ def test_c_abi_error_codes_and_empty_inputs(ops):
     assert lib.ap_gemm_nt(P(x), 64, P(x), 64, P(x), 64, 0, 64, 64, None, st) == -1                   # empty M is a caller error here
     c = torch.zeros(64, 64, device="cuda")
     assert lib.ap_gemm_tn_acc(P(x), 64, P(x), 64, P(c), 32, 64, 64, 64, None, st) == -1              # ldc < N2
-    assert lib.ap_gemm_tn_acc_grouped(None, 1, st) == -4
+    assert lib.ap_gemm_tn_acc_grouped(None, 1, None, 0, st) == -4
     arr = (TnProblem * 1)()
     arr[0].A, arr[0].lda, arr[0].B, arr[0].ldb, arr[0].C, arr[0].ldc = P(x), 64, P(x), 64, P(c), 64
-    arr[0].M, arr[0].N1, arr[0].N2, arr[0].colsum_A = 64, 64, 64, None
-    assert lib.ap_gemm_tn_acc_grouped(ctypes.cast(arr, ctypes.c_void_p), 0, st) == -1               # empty group
-    assert lib.ap_gemm_tn_acc_grouped(ctypes.cast(arr, ctypes.c_void_p), 9, st) == -1               # > AP_TN_MAX_GROUP
-    assert lib.ap_gemm_tn_acc_grouped(ctypes.cast(arr, ctypes.c_void_p), 1, st) == 0
+    arr[0].M, arr[0].N1, arr[0].N2, arr[0].alpha, arr[0].colsum_A, arr[0].colsum_weight, arr[0].colsum_scale = 64, 64, 64, 1.0, None, None, 1.0
+    assert lib.ap_gemm_tn_acc_grouped(ctypes.cast(arr, ctypes.c_void_p), 0, None, 0, st) == -1      # empty group
+    assert lib.ap_gemm_tn_acc_grouped(ctypes.cast(arr, ctypes.c_void_p), 9, None, 0, st) == -1      # > AP_TN_MAX_GROUP
+    assert lib.ap_gemm_tn_acc_grouped(ctypes.cast(arr, ctypes.c_void_p), 1, None, 0, st) == 0
+    assert lib.ap_gemm_tn_grouped_workspace(ctypes.cast(arr, ctypes.c_void_p), 1) == 64 * 64 * 4          # one split, no column sum
+    assert lib.ap_gemm_tn_acc_grouped(ctypes.cast(arr, ctypes.c_void_p), 1, P(c), 16, st) == -1           # deterministic mode: workspace too small
     # attention
     q = torch.zeros(2 * 16, 3 * 48, dtype=torch.bfloat16, device="cuda")
-    assert lib.ap_mhsa_fwd(P(q), P(q), P(f), 2, 16, 1, 40, ctypes.c_float(0.1), st) == -2               # head_dim 40
+    assert lib.ap_mhsa_fwd(P(q), P(q), P(f), 2, 16, 1, 40, ctypes.c_float(0.1), None, st) == -2         # head_dim 40
     assert lib.ap_mhsa_bwd_workspace(2, 196, 12, 32) == 0 and lib.ap_mhsa_bwd_workspace(2, 784, 16, 48) == 2 * 16 * 784 * 4
     assert lib.ap_mhsa_bwd(P(q), P(q), P(q), P(f), P(q), 1, 300, 1, 32, ctypes.c_float(0.1), None, 0, st) == -4   # blocked path without workspace
-    assert lib.ap_mhsa_fwd(P(q), None, P(f), 2, 16, 1, 32, ctypes.c_float(0.1), st) == -4
+    assert lib.ap_mhsa_fwd(P(q), None, P(f), 2, 16, 1, 32, ctypes.c_float(0.1), None, st) == -4
     assert lib.ap_outlook_fwd(P(x), P(x), 88, P(x), 1, 8, 8, 1, 16, ctypes.c_float(0.25), st) == -2     # outlook head_dim != 32
     torch.cuda.synchronize()                                                                          # nothing above may have faulted
