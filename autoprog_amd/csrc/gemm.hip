@@ -22,6 +22,7 @@
 // is split across blockIdx.z and partial tiles are added with fp32 atomics (few MB per call).
 #include "common.h"
 #include "gemm_epi.h"
+#include "gemm_dma.h"
 #include <cstdlib>
 #include <cstdio>
 
@@ -1058,6 +1059,28 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         static bool sk_attr = false;
         if (!sk_attr) { (void)hipFuncSetAttribute((const void*)k_gemm_nt_skinny, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); sk_attr = true; (void)hipGetLastError(); }
         hipLaunchKernelGGL(k_gemm_nt_skinny, dim3((N + 31) / 32, (M + 63) / 64), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, ep);
+        return ap_check_launch();
+    }
+    // LDS-DMA ring kernels of gemm_dma.h (round-2 lab, profiles/r02_gemm_lab.txt): AP_GEMM_NT_DMA=1 routes plain / bias-only launches
+    // with N % 192 == 0 and K % 64 == 0 to the persistent 256x192 tile (up to 8 % faster than the kernel below on cold operands
+    // for N = 192 / 384, slower with epilogue operands: its direct epilogue reads them in 64-byte row segments).  Default off.
+    static int use_dma = -1;
+    if (use_dma < 0) { const char* e = getenv("AP_GEMM_NT_DMA"); use_dma = e ? atoi(e) : 0; }
+    if (use_dma && (K & 63) == 0 && N % 192 == 0 && M >= 2048 && !ep.gelu && !ep.dgelu_of && !ep.residual && !ep.row_scale &&
+        (int64_t)M * lda < (1ll << 32) && (int64_t)N * ldb < (1ll << 32)) {
+        static int n_cu = 0;
+        if (n_cu == 0) { int dev = 0; hipGetDevice(&dev); hipDeviceProp_t pr; n_cu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+        const int tm = (M + 255) / 256, tn = N / 192, nt = tm * tn;
+        const int grid = nt < n_cu ? nt : n_cu;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)k_gemm_nt_dma2<256, 192, 4, 2, 2, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 448 * 128);
+            (void)hipFuncSetAttribute((const void*)k_gemm_nt_dma3<256, 192, 4, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 448 * 64);
+            attr_done = true;
+            (void)hipGetLastError();
+        }
+        if (use_dma == 3) hipLaunchKernelGGL((k_gemm_nt_dma3<256, 192, 4, 2, 4>), dim3(grid), dim3(512), 4 * 448 * 64, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
+        else hipLaunchKernelGGL((k_gemm_nt_dma2<256, 192, 4, 2, 2, 64, 1>), dim3(grid), dim3(512), 2 * 448 * 128, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
         return ap_check_launch();
     }
     static int force_small = -1;

@@ -357,3 +357,192 @@ k_gemm_nt_dma2(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
         since_epi = 0;
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Third structure: the MFMA loop itself.  Lab ablation of k_gemm_nt_dma2<256,192> on the qkv shape: the loop WITHOUT any global
+// traffic (AP_DMA_ABL=5) takes 25 us where 588 tiles x 37.7 MFLOP need 13.2 us of MFMA issue on the busiest CU -- every K step
+// opens with all 8 waves reading their fragments at once (nobody computes until the LDS queue has drained) and ends in a barrier.
+// Here (BK = 32 so that more ring stages fit):
+//   * the fragments of step s+1 are read WHILE the MFMAs of step s issue (two fragment sets, reads slotted between the MFMAs with
+//     sched_group_barrier), so a step opens with MFMAs whose operands are already in registers;
+//   * that needs stage s+1 landed one step early: the wait at the top of step s covers stage s+1, the ring (ST stages) keeps
+//     ST-2 further stages in flight;
+//   * K % 64 == 0 makes the number of 32-deep steps of a tile even, so the two fragment sets alternate in an unrolled pair of
+//     steps with compile-time register indices.
+template <int TM, int TN, int WGM, int WGN, int ST>
+__global__ void __launch_bounds__(WGM * WGN * 64)
+k_gemm_nt_dma3(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
+               int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dma_raw[];
+    constexpr int BK = 32;
+    constexpr int NW = WGM * WGN;
+    constexpr int ROWS = TM + TN;
+    constexpr int RPP = 16, CPR = 4;                 // rows per DMA instruction, 16-byte chunks per row
+    constexpr int PIECES = ROWS / RPP;
+    constexpr int NI = (PIECES + NW - 1) / NW;
+    constexpr int MT = TM / WGM / 16, NT = TN / WGN / 16;
+    constexpr int STAGE = ROWS * BK;
+    constexpr int NMFMA = NT * MT, NRD = MT + NT;
+    static_assert(TM % RPP == 0 && ROWS % RPP == 0, "a DMA piece lies entirely in the activation or in the weight rows");
+    static_assert((TM / WGM) % 16 == 0 && (TN / WGN) % 32 == 0, "wave tile");
+    static_assert(ST >= 3 && ST <= 8, "ring depth: computing + landed + >= 1 in flight");
+    bf16_t* ring = reinterpret_cast<bf16_t*>(dma_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int fr = lane & 15, g = lane >> 4;
+    const int nk = K / BK;                           // even (K % 64 == 0)
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    const int total = my_tiles * nk;
+    const int my_ni = (PIECES % NW == 0 || wave < PIECES % NW) ? NI : NI - 1;
+
+    uint32_t soff[NI];
+    auto set_tile_src = [&](int ti) {
+        const int tile = xcd_remap(blockIdx.x + ti * G, ntiles);
+        const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = (wave + NW * i) * RPP + lane / CPR;
+            if (r < TM) soff[i] = (uint32_t)min(m0 + r, M - 1) * (uint32_t)lda + ((lane % CPR) ^ dkey_a<BK>(r)) * 8;
+            else { const int rb = min(r - TM, TN - 1); soff[i] = (uint32_t)min(n0 + rb, N - 1) * (uint32_t)ldb + ((lane % CPR) ^ dkey_b<BK>(rb)) * 8; }
+        }
+    };
+    int q_tile = 0, q_k = 0, q_stage = 0;
+    auto issue_piece = [&](int i) {
+        const int p = wave + NW * i;
+        if (PIECES % NW != 0 && i == NI - 1 && p >= PIECES) return;
+        const int r0 = p * RPP;
+        const bf16_t* base = (r0 < TM) ? A : B;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + soff[i] + q_k * BK),
+                                         (__attribute__((address_space(3))) void*)(ring + q_stage * STAGE + r0 * BK), 16, 0, 0);
+    };
+    auto advance = [&]() {
+        if (++q_k == nk) { q_k = 0; ++q_tile; }
+        q_stage = (q_stage == ST - 1) ? 0 : q_stage + 1;
+    };
+    // lane-constant fragment addresses inside a stage
+    int xoff[MT], woff[NT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { const int r = wm * (TM / WGM) + t * 16 + fr; xoff[t] = r * BK + ((g ^ dkey_a<BK>(r)) << 3); }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int r = wn * (TN / WGN) + 32 * (t >> 1) + 8 * (fr >> 2) + 4 * (t & 1) + (fr & 3);
+        woff[t] = TM * BK + r * BK + ((g ^ dkey_b<BK>(r)) << 3);
+    }
+    // fragments are kept as plain 4 x u32 registers and bit-cast at the MFMA: a <8 x bf16> value that crosses control flow is
+    // legalised element by element (16 shifts + 16 v_perm per fragment set and step in the first version of this loop)
+    auto read_frags = [&](u32x4* xf, u32x4* wf, int stage) {
+        const bf16_t* st = ring + stage * STAGE;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) xf[t] = ld16(st + xoff[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wf[t] = ld16(st + woff[t]);
+    };
+
+    f32x4 acc[NT][MT];
+    u32x4 xf0[MT], wf0[NT], xf1[MT], wf1[NT];
+    int issued = 0;
+    for (; issued < ST - 1 && issued < total; ++issued) {
+        if (q_k == 0) set_tile_src(q_tile);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) issue_piece(i);
+        advance();
+    }
+    // stage 0 landed -> first fragment set
+    wait_vmcnt_dyn((issued - 1) * my_ni);
+    __builtin_amdgcn_s_barrier();
+    if (total > 0) read_frags(xf0, wf0, 0);
+    int kt = 0, ti = 0;
+    int epi_stores = 0, since_epi = 1 << 20;
+    const bool vec_ok = ((ldc & 7) == 0) && (ep.residual == nullptr || (ep.ldr & 7) == 0);
+
+    // one 32-deep step: MFMAs on (xc, wc) = stage s, fragment reads of stage s+1 into (xn, wn_) and the DMA of stage s+ST-1 between them
+    auto step = [&](int s, const u32x4* xc, const u32x4* wc, u32x4* xn, u32x4* wn_) {
+        if (kt == 0) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        ++since_epi;
+        // stage s+1 must have landed (it is read during this step); younger operations of this wave: the DMA groups of stages
+        // s+2 .. issued-1 and, for ST-2 steps after an epilogue, its stores
+        const bool more = s + 1 < total;
+        if (more) wait_vmcnt_dyn(max(issued - s - 2, 0) * my_ni + ((since_epi <= ST - 2) ? epi_stores : 0));
+        __builtin_amdgcn_s_barrier();                 // stage s+1 readable by every wave; every wave is done reading stage s-1
+        const bool do_issue = issued < total;
+        if (do_issue && q_k == 0) set_tile_src(q_tile);
+        const int nstage = (s + 1) % ST;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this step's fragments (read during the previous step)
+        __builtin_amdgcn_sched_barrier(0);
+        int j = 0, di = 0, ri = 0;
+        const bf16_t* st = ring + nstage * STAGE;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(wc[nt]), as_bf16x8(xc[mt]), acc[nt][mt], 0, 0, 0);
+                ++j;
+                // next step's fragment reads, one per two MFMAs from the start of the step
+                // (unconditional: past the last step they fetch a stage nobody uses)
+                if (!(AP_DMA_ABL & 2) && (j & 1) && ri < NRD) {
+                    if (ri < MT) xn[ri] = ld16(st + xoff[ri]);
+                    else wn_[ri - MT] = ld16(st + woff[ri - MT]);
+                    ++ri;
+                }
+                if (!(AP_DMA_ABL & 4) && di < NI && j == ((di + 1) * NMFMA) / (NI + 1)) {
+                    if (do_issue) issue_piece(di);
+                    ++di;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        if (!(AP_DMA_ABL & 2)) {                      // wave tiles with more fragments than MFMA pairs: the rest of the reads
+#pragma unroll
+            for (; ri < NRD; ++ri) {
+                if (ri < MT) xn[ri] = ld16(st + xoff[ri]);
+                else wn_[ri - MT] = ld16(st + woff[ri - MT]);
+            }
+        }
+        if (do_issue) { advance(); ++issued; }
+    };
+
+    for (int s = 0; s < total; s += 2) {
+        step(s, xf0, wf0, xf1, wf1);
+        kt += 1;
+        step(s + 1, xf1, wf1, xf0, wf0);
+        kt += 1;
+        if (kt < nk) continue;
+        kt = 0;
+        // ------------------------------------------------------------ direct epilogue of tile `ti`
+        const int tile = xcd_remap(blockIdx.x + ti * G, ntiles);
+        ++ti;
+        const int m0 = (tile / tiles_n) * TM + wm * (TM / WGM), n0 = (tile % tiles_n) * TN + wn * (TN / WGN);
+        if ((AP_DMA_ABL & 1) || (ep.dbg & 1)) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < MT; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+            if (sacc == 12345.678f) C[0] = 1;
+            continue;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + mt * 16 + fr;
+#pragma unroll
+            for (int pr = 0; pr < NT / 2; ++pr) {
+                const int n = n0 + 32 * pr + 8 * g;
+                if (m >= M || n >= N) continue;
+                float v[8];
+                v[0] = acc[2 * pr][mt][0]; v[1] = acc[2 * pr][mt][1]; v[2] = acc[2 * pr][mt][2]; v[3] = acc[2 * pr][mt][3];
+                v[4] = acc[2 * pr + 1][mt][0]; v[5] = acc[2 * pr + 1][mt][1]; v[6] = acc[2 * pr + 1][mt][2]; v[7] = acc[2 * pr + 1][mt][3];
+                epi_chunk(v, m, n, N, ldc, vec_ok, ep, C);
+            }
+        }
+        const bool interior = vec_ok && (m0 + TM / WGM <= M) && (n0 + TN / WGN <= N);
+        epi_stores = interior ? MT * (NT / 2) * ((ep.gelu && ep.preact) ? 2 : 1) : 0;
+        since_epi = 0;
+    }
+}

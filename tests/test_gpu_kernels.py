@@ -84,7 +84,8 @@ def test_layernorm(ops, rows, C, eps):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 192, 192), (300, 486, 192), (128, 1152, 384), (77, 1000, 384),
-                                   (512, 384, 1152), (130, 32, 32), (64, 96, 96), (200, 16, 64), (392, 384, 768)])
+                                   (512, 384, 1152), (130, 32, 32), (64, 96, 96), (200, 16, 64), (392, 384, 768),
+                                   (2304, 192, 192), (4100, 384, 384), (2500, 1152, 384), (3000, 576, 192), (70000, 192, 576)])
 def test_gemm_nt_plain_and_bias(ops, M, N, K):
     a, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
     bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
@@ -423,7 +424,7 @@ def test_bn_relu_fused(ops, B, H, W, C):
     assert rel(ye, torch.relu(bn(x.double().permute(0, 3, 1, 2))).permute(0, 2, 3, 1)) < TOL_BF16
 
 
-@pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_GEMM_NT_P": "1"}, {"AP_GEMM_NT_P": "4"}, {"AP_GEMM_NT_RING": "1"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"},
+@pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_GEMM_NT_DMA": "1"}, {"AP_GEMM_NT_DMA": "3"}, {"AP_GEMM_NT_P": "1"}, {"AP_GEMM_NT_P": "4"}, {"AP_GEMM_NT_RING": "1"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"},
                                  {"AP_GEMM_TN_RING": "1"}, {"AP_ASYNC_WGRAD": "1"}])
 def test_experimental_kernel_paths_stay_parity_green(env):
     """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:

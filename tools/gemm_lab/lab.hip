@@ -73,6 +73,21 @@ static bool launch_dma2(const Shape& s, const Set& b, int ldc, EpiArgs ep, int w
     return hipGetLastError() == hipSuccess;
 }
 
+template <int TM, int TN, int WGM, int WGN, int ST>
+static bool launch_dma3(const Shape& s, const Set& b, int ldc, EpiArgs ep, int wg_per_cu, hipStream_t st) {
+    if (s.K % 64) return false;
+    ep.dbg = g_dbg;
+    const size_t lds = (size_t)ST * (TM + TN) * 64;
+    if (lds > 160 * 1024) return false;
+    static bool attr = false;
+    if (!attr) { CK(hipFuncSetAttribute((const void*)k_gemm_nt_dma3<TM, TN, WGM, WGN, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    const int tm = (s.M + TM - 1) / TM, tn = (s.N + TN - 1) / TN, nt = tm * tn;
+    int grid = nt;
+    if (wg_per_cu > 0) grid = std::min(nt, wg_per_cu * g_ncu);
+    hipLaunchKernelGGL((k_gemm_nt_dma3<TM, TN, WGM, WGN, ST>), dim3(grid), dim3(WGM * WGN * 64), lds, st, b.A, s.K, b.B, s.K, b.C, ldc, s.M, s.N, s.K, tn, nt, ep);
+    return hipGetLastError() == hipSuccess;
+}
+
 int main(int argc, char** argv) {
     const char* filter = argc > 1 ? argv[1] : "";
     const char* vfilter = argc > 2 ? argv[2] : "";
@@ -96,17 +111,17 @@ int main(int argc, char** argv) {
     DMA("d256x192w8k64s2p1", 256, 192, 4, 2, 2, 64, 1)
     DMA("d256x256w8k32s4p1", 256, 256, 4, 2, 4, 32, 1)
 #define DMA2(NAME, TM, TN, WGM, WGN, ST, BK, ILV, WPC) vars.push_back({NAME, [](const Shape& s, const Set& b, int ldc, EpiArgs ep, float*, float*, hipStream_t st) { return launch_dma2<TM, TN, WGM, WGN, ST, BK, ILV>(s, b, ldc, ep, WPC, st); }});
-    DMA2("e256x192k64s2i0", 256, 192, 4, 2, 2, 64, 0, 1)
     DMA2("e256x192k64s2i1", 256, 192, 4, 2, 2, 64, 1, 1)
-    DMA2("e256x192k32s5i0", 256, 192, 4, 2, 5, 32, 0, 1)
     DMA2("e256x192k32s5i1", 256, 192, 4, 2, 5, 32, 1, 1)
-    DMA2("e256x192k32s3i1", 256, 192, 4, 2, 3, 32, 1, 1)
-    DMA2("e256x256k32s4i1", 256, 256, 4, 2, 4, 32, 1, 1)
-    DMA2("e256x256k32s3i1", 256, 256, 4, 2, 3, 32, 1, 1)
-    DMA2("e256x128k64s3i1", 256, 128, 4, 2, 3, 64, 1, 1)
-    DMA2("e256x128k32s6i1", 256, 128, 4, 2, 6, 32, 1, 1)
-    DMA2("e128x128k32s5i1p2", 128, 128, 2, 2, 5, 32, 1, 2)
-    DMA2("e128x192k32s7i1", 128, 192, 4, 2, 7, 32, 1, 1)
+#define DMA3(NAME, TM, TN, WGM, WGN, ST, WPC) vars.push_back({NAME, [](const Shape& s, const Set& b, int ldc, EpiArgs ep, float*, float*, hipStream_t st) { return launch_dma3<TM, TN, WGM, WGN, ST>(s, b, ldc, ep, WPC, st); }});
+    DMA3("f256x192s5", 256, 192, 4, 2, 5, 1)
+    DMA3("f256x192s4", 256, 192, 4, 2, 4, 1)
+    DMA3("f256x192s3", 256, 192, 4, 2, 3, 1)
+    DMA3("f320x192s4", 320, 192, 4, 2, 4, 1)
+    DMA3("f256x128s6", 256, 128, 4, 2, 6, 1)
+    DMA3("f128x192s4p2", 128, 192, 2, 2, 4, 2)
+    DMA3("f128x192w8s7", 128, 192, 4, 2, 7, 1)
+    DMA3("f256x256s4", 256, 256, 4, 2, 4, 1)
     const size_t ROT_BYTES = (size_t)640 << 20;
     hipStream_t st; CK(hipStreamCreate(&st));
     float* d_diff; CK(hipMalloc(&d_diff, 8));
