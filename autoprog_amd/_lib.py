@@ -32,6 +32,7 @@ _SIGNATURES = {
     "ap_cast_f32_bf16": (_I, [_P, _P, _L, _P]),
     "ap_cast_bf16_f32": (_I, [_P, _P, _L, _P]),
     "ap_cast_transpose_f32_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ap_resize_bilinear_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ap_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "ap_layernorm_bwd_workspace": (ctypes.c_size_t, [_L, _I]),
     "ap_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, _P]),

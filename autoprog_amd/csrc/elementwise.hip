@@ -203,9 +203,35 @@ __global__ void k_colsum_acc(const bf16_t* __restrict__ A, int lda, float* __res
 }
 
 // ===================================================================================== C ABI
+// ------------------------------------------------------------- input resize (main_prog.py:973,1908)
+// F.interpolate(input, size=(r, r), mode='bilinear', align_corners=False) of the fp32 NCHW batch, fused with the stem's layout
+// change and bf16 cast: one pass writes the NHWC bf16 image the stem convolution reads.  PyTorch's source-index rule:
+// src = max(0, (dst + 0.5) * in/out - 0.5), i0 = floor(src), i1 = i0 + (i0 < in - 1), weight of i1 = src - i0.
+__global__ void __launch_bounds__(256)
+k_resize_bilinear_nhwc(const float* __restrict__ x, bf16_t* __restrict__ y, int B, int C, int Hi, int Wi, int Ho, int Wo, float sh, float sw) {
+    const int64_t total = (int64_t)B * Ho * Wo;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % Wo);
+        const int64_t t = i / Wo;
+        const int oy = (int)(t % Ho), b = (int)(t / Ho);
+        const float fy = fmaxf(((float)oy + 0.5f) * sh - 0.5f, 0.f), fx = fmaxf(((float)ox + 0.5f) * sw - 0.5f, 0.f);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hi - 1), x1 = x0 + (x0 < Wi - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* p = x + (int64_t)b * C * Hi * Wi;
+        bf16_t* o = y + i * C;
+        for (int c = 0; c < C; ++c) {
+            const float* pc = p + (int64_t)c * Hi * Wi;
+            const float top = (1.f - lx) * pc[(int64_t)y0 * Wi + x0] + lx * pc[(int64_t)y0 * Wi + x1];
+            const float bot = (1.f - lx) * pc[(int64_t)y1 * Wi + x0] + lx * pc[(int64_t)y1 * Wi + x1];
+            o[c] = f2bf((1.f - ly) * top + ly * bot);
+        }
+    }
+}
+
 extern "C" {
 
-int ap_abi_version(void) { return 1; }
+int ap_abi_version(void) { return 2; }
 
 const char* ap_error_string(int code) {
     switch (code) {
@@ -240,6 +266,15 @@ int ap_cast_transpose_f32_bf16(const float* src, ap_bf16* dst, int rows, int col
     hipLaunchKernelGGL(k_cast_transpose, grid, dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols, ld_dst);
     return ap_check_launch();
 }
+int ap_resize_bilinear_nhwc(const float* x, ap_bf16* y, int B, int C, int Hi, int Wi, int Ho, int Wo, ap_stream_t stream) {
+    if (!x || !y) return AP_ERR_NULL;
+    if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return AP_ERR_SHAPE;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_resize_bilinear_nhwc, dim3(grid_for((int64_t)B * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, y, B, C, Hi, Wi, Ho, Wo,
+                       (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    return ap_check_launch();
+}
+
 int ap_row_scale(const ap_bf16* x, const float* scale, ap_bf16* y, int64_t M, int C, int rows_per_scale, ap_stream_t stream) {
     if (!x || !scale || !y) return AP_ERR_NULL;
     if ((C & 7) || rows_per_scale <= 0) return AP_ERR_SHAPE;

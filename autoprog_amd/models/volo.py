@@ -313,6 +313,7 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(hidden_dim, embed_dim, kernel_size=patch_size // stem_stride, stride=patch_size // stem_stride)
         self.num_patches = (img_size // patch_size) * (img_size // patch_size)
         self.compute_dtype = BF16          # torch.float32 runs the MIOpen stem un-autocast (parity debugging)
+        self.resize_to = None              # elastic input size: a fp32 batch of another size is resized on the way in (main_prog.py:973)
 
     def forward(self, x):
         """[B,3,r,r] -> NCHW feature map (channels_last memory, bf16).  Convolutions go through MIOpen
@@ -321,8 +322,16 @@ class PatchEmbed(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("autoprog_amd models run on the GPU only (no CPU fallback)")
         fused = self.compute_dtype == BF16
-        # one pass: NCHW fp32 -> NHWC(channels_last) in the compute dtype (autocast would otherwise cast a second time)
-        x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
+        size = self.resize_to if self.resize_to else x.shape[-1]
+        if fused and x.dtype == torch.float32 and x.shape[-1] == x.shape[-2] and not x.requires_grad:
+            # one kernel: bilinear resize to the step's resolution (identity when the sizes agree) + NCHW fp32 -> NHWC bf16
+            from .. import ops
+            x = ops.resize_bilinear_nhwc(x.contiguous(), size).permute(0, 3, 1, 2)      # NCHW view of channels_last memory
+        else:
+            if size != x.shape[-1]:
+                x = F.interpolate(x.float(), size=(size, size), mode="bilinear", align_corners=False)
+            # one pass: NCHW fp32 -> NHWC(channels_last) in the compute dtype (autocast would otherwise cast a second time)
+            x = x.to(dtype=self.compute_dtype, memory_format=torch.channels_last)
         with torch.autocast("cuda", dtype=BF16, enabled=fused):
             if self.stem_conv:
                 if fused:
@@ -472,6 +481,9 @@ class VOLO(nn.Module):
     # ---- elastic depth: one explicit mask object shared with extraction code
     def set_sample_config(self, config: dict):
         mask = ActiveLayerMask(config["layer_num"], config["min_layer_num"], config["max_layer_num"])
+        # the reference's search configs also carry the step's resolution (main_prog.py:1824-1828); its callers resize the batch
+        # themselves -- a batch that still has another size is resized by the stem's first kernel
+        self.patch_embed.resize_to = config.get("input_size")
         real_stage = 0
         for stage in self.network:
             if isinstance(stage, (nn.Sequential, nn.ModuleList)):
@@ -480,6 +492,19 @@ class VOLO(nn.Module):
                 real_stage += 1
         self.active_layers = mask
         return mask
+
+    def set_drop_path_rate(self, rate):
+        """per-block DropPath rates of the CURRENT elastic config as the reference's constructor assigns them to the extracted
+        network (models/volo.py:428-437: rate * (index among the active blocks) / (active blocks - 1); outlookers get none):
+        lets one supernet run the progressive schedule's per-stage strengths (prog/progressive.py:4-31)"""
+        stages = [s for s in self.network if isinstance(s, nn.Sequential)]
+        active = [[b for b in s if not b.is_identity_layer] for s in stages]
+        counts = [len(a) for a in active]
+        total = sum(counts)
+        for si, blocks in enumerate(active):
+            for bi, blk in enumerate(blocks):
+                if isinstance(blk, Transformer):
+                    blk.drop_prob = float(rate) * (bi + sum(counts[:si])) / max(total - 1, 1) if rate else 0.0
 
     def interpolate_pos_encoding(self, x):
         """reference VOLO.interpolate_pos_encoding (models/volo.py:580-596), fp32 on the host grid"""

@@ -58,6 +58,16 @@ def cast_transpose_bf16(w):
     return dst
 
 
+def resize_bilinear_nhwc(x, size):
+    """fp32 NCHW batch -> bf16 NHWC batch bilinearly resized to (size, size) (F.interpolate(..., mode='bilinear', align_corners=False),
+    main_prog.py:973); size equal to the input size is the plain layout change + cast"""
+    _req(x, torch.float32, "x")
+    B, C, Hi, Wi = x.shape
+    y = torch.empty((B, size, size, C), dtype=BF16, device=x.device)
+    check(lib.ap_resize_bilinear_nhwc(x.data_ptr(), y.data_ptr(), B, C, Hi, Wi, size, size, _stream()), "ap_resize_bilinear_nhwc")
+    return y
+
+
 # -------------------------------------------------------------------------------- layernorm
 def layernorm_fwd(x, gamma, beta, eps):
     _req(x, BF16, "x"); _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")

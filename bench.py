@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
-"""Benchmark of the AutoProg VOLO-D1 224 px training step on MI355X (BASELINE.json metric
+"""Benchmark of the AutoProg VOLO-D1 training step on MI355X (BASELINE.json metric
 "images/sec/GPU (fwd+bwd) VOLO-D1 224px AutoProg step").
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 without a launcher: bench.py starts `torch.distributed.run --nproc-per-node N` itself (child process; the
+      reference starts its ranks the same way, distributed_train_prog.sh:4).  Under a launcher (WORLD_SIZE set) it is a rank.
 
-A "step" is one pass of the hot path over one synthetic batch already resident in HBM:
-forward (mix-token, DropPath 0.1) + token-label loss + backward (+ bucketed RCCL gradient
-all-reduce overlapped with backward when N>1) + AdamW update + the 4 EMA updates of
-scripts/train_autoprog.sh.  Workload = BASELINE.json configs[1]: volo_h12_l18 (== VOLO-D1),
-224x224, per-GPU batch 128, bf16 activations / fp32 master weights, token-label target [B,1000,198].
+A "step" is one pass of the hot path over one synthetic batch already resident in HBM: forward (mix-token, DropPath) +
+token-label loss + backward (+ bucketed RCCL gradient all-reduce overlapped with backward when N > 1) + fused AdamW +
+the 4 EMA updates of scripts/train_autoprog.sh.
+
+Workloads (--workload):
+  d1      (default, the driver's line) BASELINE.json configs[1]: volo_h12_l18 (== VOLO-D1), 224 px, per-GPU batch 128, bf16
+          activations / fp32 master weights, token-label target [B,1000,198], DropPath 0.1
+  stages  BASELINE.json configs[2]: the reference schedule's four stages (l, r) = (9,128) (12,160) (15,192) (18,224) with DropPath
+          0 / .033 / .067 / .1 on ONE supernet (elastic depth mask + on-device bilinear resize, main_prog.py:973), a quarter
+          of the steps each; --search-mix draws (l, r) uniformly per step instead (supernet search, main_prog.py:1824-1828)
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     dominant kernel (k_gemm_nt, bound "mfma"): algorithmic FLOPs of its launches in one
-               step / their summed duration, measured with HIP events on the launch stream
-  cpu_baseline the CPU oracle (oracle/ref_cpu.py, kind "port") timed on this host on a bounded
-               sample of the same workload (smaller batch), rank 0 at N=1 only.
+  roofline     dominant kernel (k_gemm_nt): algorithmic FLOPs and bytes of its launches in one step / their summed duration,
+               measured with HIP events on the launch stream; `bound` follows from the launches' arithmetic intensity against
+               the ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B), the other roof's fraction is reported beside it
+  cpu_baseline the CPU oracle (oracle/ref_cpu.py, kind "port") timed on this host on bounded samples: the VOLO-D1 step at batch 8
+               and BASELINE.json configs[0] (DeiT-Tiny, depth-4 sub-net, batch 32, soft-target CE); rank 0 at N=1 only.
 """
 import argparse
 import json
 import os
+import random
 import sys
 import time
 
@@ -29,6 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PEAK_HBM_TBS = 8.0              # HBM3E peak
+STAGES = [(9, 128, 0.0), (12, 160, 0.0333), (15, 192, 0.0667), (18, 224, 0.1)]      # prog/progressive.py:4-31 with scripts/train_autoprog.sh
 
 
 def make_target(B, C, N, device, gen):
@@ -43,12 +54,25 @@ def make_target(B, C, N, device, gen):
     return t.to(device)
 
 
+def _time_steps(step, seconds_budget, max_steps=10):
+    step()                                   # warm-up
+    t0 = time.time()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.time() - t0 > seconds_budget or n >= max_steps:
+            break
+    return n, time.time() - t0
+
+
 def cpu_baseline(variant, res, seconds_budget, threads):
-    """time the CPU oracle (pure torch fp32 restatement of the reference) on a bounded sample"""
+    """time the CPU oracle (pure torch fp32 restatement of the reference) on bounded samples"""
     from oracle import ref_cpu as R
-    torch.set_num_threads(threads)
-    arch = R.variant_arch(variant)
     from autoprog_amd.models import create_model
+    torch.set_num_threads(threads)
+    # ---- the bench workload's twin: VOLO-D1 token-label step at batch 8
+    arch = R.variant_arch(variant)
     torch.manual_seed(42)
     model = create_model("model_variant", variant=variant, drop_path_rate=0.1)
     p = {k: v.detach().clone().float().requires_grad_(v.dtype.is_floating_point and "running_" not in k)
@@ -56,43 +80,32 @@ def cpu_baseline(variant, res, seconds_budget, threads):
     B = 8
     g = torch.Generator().manual_seed(42)
     x = torch.randn(B, 3, res, res, generator=g)
-    n = (res // 16) ** 2
-    target = make_target(B, 1000, n, "cpu", g)
+    target = make_target(B, 1000, (res // 16) ** 2, "cpu", g)
     rng = np.random.RandomState(42)
 
     def step():
         lam, box = R.draw_mix_box((B, res // 8, res // 8, arch["embed_dims"][0]), 2, 1.0, rng)
         out = R.volo_forward(p, x, train=True, mix=(lam, box), drop_path_rate=0.1, **arch)
         loss = R.token_label_ce(out, target, 0.5, 1.0)
-        grads = torch.autograd.grad(loss, [v for v in p.values() if v.requires_grad], allow_unused=True)
-        return float(loss.detach()), grads
+        torch.autograd.grad(loss, [v for v in p.values() if v.requires_grad], allow_unused=True)
 
-    step()                                   # warm-up
-    t0 = time.time()
-    n_steps = 0
-    while True:
-        step()
-        n_steps += 1
-        if time.time() - t0 > seconds_budget or n_steps >= 10:
-            break
-    dt = time.time() - t0
-    return {"value": round(B * n_steps / dt, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "oracle/ref_cpu.py fp32 fwd+loss+bwd, %s %dpx, batch %d, %d steps in %.1fs (no optimizer)" % (variant, res, B, n_steps, dt)}
+    n_steps, dt = _time_steps(step, seconds_budget * 0.6)
+    # ---- BASELINE.json configs[0]: DeiT-Tiny 224, depth-4 sub-net, batch 32, soft-target CE, one process
+    torch.manual_seed(42)
+    deit = create_model("model_variant", variant="deit_h3_l4")
+    pd = {k: v.detach().clone().float().requires_grad_(True) for k, v in deit.state_dict().items()}
+    xb = torch.randn(32, 3, 224, 224, generator=g)
+    tb = torch.softmax(torch.randn(32, 1000, generator=g) * 3, dim=-1)
 
+    def step_deit():
+        loss = R.soft_target_ce(R.vit_forward(pd, xb, depth=4, heads=3), tb)
+        torch.autograd.grad(loss, list(pd.values()), allow_unused=True)
 
-def self_launch(n, argv):
-    """start `torch.distributed.run --nproc-per-node n bench.py <argv>` as a child and return its exit code"""
-    import socket
-    import subprocess
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL needs it on this driver)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    return subprocess.call(cmd, env=env)
+    n2, dt2 = _time_steps(step_deit, seconds_budget * 0.4)
+    return {"value": round(B * n_steps / dt, 3), "unit": "images/sec", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "oracle/ref_cpu.py fp32 fwd+loss+bwd, %s %dpx, batch %d, %d steps in %.1fs (no optimizer)" % (variant, res, B, n_steps, dt),
+            "configs0_deit_tiny_l4_b32": {"value": round(32 * n2 / dt2, 2), "unit": "images/sec",
+                                          "sample": "oracle vit_forward(deit_h3_l4) fp32 fwd+CE+bwd, 224px, batch 32, %d steps in %.1fs" % (n2, dt2)}}
 
 
 class GemmProbe:
@@ -147,6 +160,42 @@ class GemmProbe:
         return len(self.records), ms, flops
 
 
+def self_launch(n, argv):
+    """start `torch.distributed.run --nproc-per-node n bench.py <argv>` as a child and return its exit code"""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL needs it on this driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(world, rank):
+    """--launch-check: the rendezvous + gradient-exchange plumbing of an N-rank run without the HIP path (CPU, gloo): every rank
+    reduces a slab through GradientBucketReducer and rank 0 prints what it saw.  The product path itself has no CPU mode."""
+    import torch.distributed as dist
+    from autoprog_amd.dist import GradientBucketReducer
+    dist.init_process_group("gloo")
+    params = [torch.nn.Parameter(torch.zeros(1000)), torch.nn.Parameter(torch.zeros(37, 5))]
+    red = GradientBucketReducer(params, bucket_bytes=1024, world_size=world, defer_mean=True)
+    red.zero_grad()
+    for p in params:
+        p.grad.add_(float(rank + 1))
+        red._on_grad(p)
+    red.finish()
+    mean = float(params[0].grad[0]) * red.take_pending_scale()
+    ok = abs(mean - (world + 1) / 2.0) < 1e-6
+    if rank == 0:
+        print(json.dumps({"launch_check": "ok" if ok else "FAILED", "rccl_ranks": dist.get_world_size(), "backend": "gloo", "grad_mean": mean}), flush=True)
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,21 +204,26 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (scripts/train_autoprog.sh: -b 128)")
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--variant", default="volo_h12_l18")
+    ap.add_argument("--workload", default="d1", choices=["d1", "stages"])
+    ap.add_argument("--search-mix", action="store_true", help="stages workload: uniform random (l, r) per step (supernet search)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+loss+backward only")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous + gradient exchange only (CPU/gloo), no GPU work")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: become the launcher (reference: distributed_train_prog.sh:4 starts its 8 ranks the same
-        # way).  Nothing in this process has touched the GPU yet; the ranks are CHILD processes (never an exec of this one).
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU yet; the ranks are
+        # CHILD processes (never an exec of this one).
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+    if args.launch_check:
+        sys.exit(launch_check(world, rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # AP_DIST_BACKEND=gloo (testing only): lets several ranks share one GPU to exercise the multi-rank code path where
@@ -199,7 +253,8 @@ def main():
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0)
     loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=1000)
-    reducer = GradientBucketReducer(list(model.parameters()), world_size=world)
+    # the 1/world of the gradient mean is folded into the fused optimizer kernel (no extra pass over the 106 MB slab)
+    reducer = GradientBucketReducer(list(model.parameters()), world_size=world, defer_mean=not args.no_optimizer)
     reducer.install_sink(model)
     from autoprog_amd.optim import FlatAdamWEma
     ema_decays = [0.998, 0.9986, 0.999, 0.9996]            # scripts/train_autoprog.sh:5
@@ -208,19 +263,52 @@ def main():
     B, res = args.batch, args.res
     gen = torch.Generator().manual_seed(42 + rank)
     images = torch.randn(B, 3, res, res, generator=gen).to(dev)
-    n_tok = (res // 16) ** 2
-    target = make_target(B, 1000, n_tok, dev, gen)
+    if args.workload == "stages":
+        targets = {r: make_target(B, 1000, (r // 16) ** 2, dev, gen) for _, r, _ in STAGES}
+        l_list, r_list = [s[0] for s in STAGES], [s[1] for s in STAGES]
+        random.seed(0)                 # identical (l, r) sequence on every rank (reference: random.seed(epoch), main_prog.py:1861)
+        counter = [0]
 
-    def step():
-        reducer.zero_grad()
-        out = model(images)
-        loss = loss_fn(out, target)
-        loss.backward()
-        reducer.finish()
-        if not args.no_optimizer:
-            opt.step()
-        return loss
+        def step():
+            i = counter[0]
+            counter[0] += 1
+            if args.search_mix:
+                l, r, dp = random.choice(l_list), random.choice(r_list), 0.1        # search epochs use the final strengths (main_prog.py:814-815)
+            else:
+                l, r, dp = STAGES[i % len(STAGES)]
+            model.set_sample_config(dict(layer_num=l, min_layer_num=l_list[0], max_layer_num=l_list[-1], input_size=r))
+            model.set_drop_path_rate(dp)
+            reducer.zero_grad()
+            loss = loss_fn(model(images), targets[r])       # the 224-px batch is resized to r by the stem's first kernel
+            loss.backward()
+            reducer.finish()
+            if not args.no_optimizer:
+                opt.step()
+            return loss
+        images_per_step = B
+    else:
+        n_tok = (res // 16) ** 2
+        target = make_target(B, 1000, n_tok, dev, gen)
 
+        def step():
+            reducer.zero_grad()
+            out = model(images)
+            loss = loss_fn(out, target)
+            loss.backward()
+            reducer.finish()
+            if not args.no_optimizer:
+                opt.step()
+            return loss
+
+    if args.workload == "stages":
+        # MIOpen measures its conv solvers the first time it sees a shape (cudnn.benchmark): touch every resolution once, untimed
+        for l_, r_, dp_ in STAGES:
+            model.set_sample_config(dict(layer_num=l_, min_layer_num=STAGES[0][0], max_layer_num=STAGES[-1][0], input_size=r_))
+            model.set_drop_path_rate(dp_)
+            reducer.zero_grad()
+            loss_fn(model(images), targets[r_]).backward()
+            reducer.finish()
+            reducer.take_pending_scale()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -244,11 +332,13 @@ def main():
     # SURVEY.md section 8(d) M1 asks for the optimizer + EMA share separately: time a few fwd+loss+bwd-only steps as well
     # (reported under config, never part of `value`)
     fwd_bwd_ms = None
-    if not args.no_optimizer:
+    allreduce_ms = None
+    if not args.no_optimizer and args.workload == "d1":
         def step_nb():
             reducer.zero_grad()
             loss_fn(model(images), target).backward()
             reducer.finish()
+            reducer.take_pending_scale()
         n_extra = max(1, min(5, args.steps))
         step_nb()
         torch.cuda.synchronize()
@@ -257,19 +347,32 @@ def main():
             step_nb()
         torch.cuda.synchronize()
         fwd_bwd_ms = (time.perf_counter() - t1) / n_extra * 1e3
+    if world > 1:
+        # the gradient exchange on its own (not overlapped with anything): what backward has to hide
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            for s_, e_, _ in reducer.buckets:
+                dist.all_reduce(reducer.flat[s_:e_])
+        torch.cuda.synchronize()
+        allreduce_ms = (time.perf_counter() - t1) / 5 * 1e3
 
     roofline = None
     if not args.no_roofline:
         probe = GemmProbe()
         probe.install()
-        nprobe = 3
+        nprobe = 3 if args.workload == "d1" else 4
         for _ in range(nprobe):
             step()
         launches, ms, flops = probe.summary()
         if rank == 0 and os.environ.get("AP_GEMM_TABLE") == "1":
             print(probe.table(), file=sys.stderr, flush=True)
         probe.remove()
-        achieved = flops / (ms * 1e-3) / 1e12
+        tflops = flops / (ms * 1e-3) / 1e12
+        tbs = probe.bytes / (ms * 1e-3) / 1e12
+        ai = flops / probe.bytes                      # FLOP per algorithmic byte, averaged over the launches of a step
+        ridge = PEAK_BF16_TFLOPS / PEAK_HBM_TBS       # 312.5 FLOP/B
         # HBM bytes per launch come from a separate rocprofv3 --pmc pass (tools/collect_profiles.sh writes the file below
         # from FETCH_SIZE / WRITE_SIZE with the gfx950 correction of MI355X_MICROARCH.md); null when that file is absent
         traffic = None
@@ -278,8 +381,14 @@ def main():
                 traffic = json.load(fh).get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             pass
-        roofline = {"bound": "mfma", "kernel": "k_gemm_nt", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+        hbm_bound = ai < ridge
+        roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": "k_gemm_nt",
+                    "achieved": round(tbs * 1e3 if hbm_bound else tflops, 2), "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else PEAK_BF16_TFLOPS,
+                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                    "frac": round(tbs / PEAK_HBM_TBS if hbm_bound else tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "arithmetic_intensity_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
+                    "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / PEAK_BF16_TFLOPS, 4),
+                    "hbm_tbs_algorithmic": round(tbs, 3), "hbm_frac": round(tbs / PEAK_HBM_TBS, 4),
                     "algorithmic_bytes_per_launch": round(probe.bytes / max(launches, 1)),
                     "launches_per_step": launches // nprobe, "avg_launch_us": round(ms * 1e3 / launches, 2),
                     "gemm_ms_per_step": round(ms / nprobe, 3), "gemm_gflop_per_step": round(flops / nprobe / 1e9, 1)}
@@ -292,11 +401,18 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
+        if args.workload == "stages":
+            wl = ("BASELINE.json configs[2]: %s supernet over the AutoProg stages (l,r) = %s, %s, batch %d, on-device resize from %d px"
+                  % (args.variant, [(s[0], s[1]) for s in STAGES], "uniform random (l,r) per step" if args.search_mix else "a quarter of the steps each", B, res))
+        else:
+            wl = "BASELINE.json configs[1]: %s (VOLO-D1) %dpx token-label training step" % (args.variant, res)
         line = {"metric": "images/sec/GPU (fwd+bwd) VOLO-D1 224px AutoProg step", "value": round(value, 2), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "value_semantics": "whole-job aggregate over n_gpus (per-GPU rate in images_per_sec_per_gpu)",
                 "images_per_sec_per_gpu": round(value / world, 2),
-                "config": {"workload": "BASELINE.json configs[1]: %s (VOLO-D1) %dpx token-label training step" % (args.variant, res),
+                "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "allreduce_ms_standalone": None if allreduce_ms is None else round(allreduce_ms, 3),
+                "config": {"workload": wl,
                            "model": args.variant, "global_batch": B * world, "per_gpu_batch": B, "res": res, "parallelism": "dp%d" % world,
                            "step": "fwd+loss+bwd" + ("" if args.no_optimizer else "+AdamW+4xEMA") + ("+RCCL grad all-reduce" if world > 1 else ""),
                            "final_loss": round(final_loss, 4),

@@ -45,6 +45,11 @@ int ap_cast_bf16_f32(const ap_bf16* src, float* dst, int64_t n, ap_stream_t stre
 /* dst[c*ld_dst + r] = bf16(src[r*cols + c]); columns rows..ld_dst-1 of dst are zeroed */
 int ap_cast_transpose_f32_bf16(const float* src, ap_bf16* dst, int rows, int cols, int ld_dst, ap_stream_t stream);
 
+/* ---- per-step input resize of progressive / supernet training (main_prog.py:973-974,1908-1910:
+ * F.interpolate(input, size=(r,r), mode='bilinear', align_corners=False)) fused with the stem's NCHW fp32 -> NHWC bf16 conversion:
+ * x [B,C,Hi,Wi] fp32 -> y [B,Ho,Wo,C] bf16.  Ho = Hi, Wo = Wi is the plain layout change + cast. */
+int ap_resize_bilinear_nhwc(const float* x, ap_bf16* y, int B, int C, int Hi, int Wi, int Ho, int Wo, ap_stream_t stream);
+
 /* ---- LayerNorm (nn.LayerNorm: models/volo.py:122,131,213,221,290,297,550) ------------- */
 int ap_layernorm_fwd(const ap_bf16* x, const float* gamma, const float* beta, ap_bf16* y,
                      float* mean, float* rstd, int64_t rows, int C, float eps, ap_stream_t stream);

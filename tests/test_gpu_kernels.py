@@ -44,7 +44,7 @@ def dev(t):
 # ------------------------------------------------------------------------------------------
 def test_abi_loaded(ops):
     from autoprog_amd._lib import lib, LIB_PATH
-    assert lib.ap_abi_version() == 1
+    assert lib.ap_abi_version() == 2
     assert LIB_PATH.endswith("libautoprog_hip.so")
 
 
@@ -338,6 +338,20 @@ def test_small_elementwise(ops):
     out = torch.zeros(7 * 7 * 64, device="cuda")
     ops.sum_reps_acc(dev(a), out, 4)
     assert rel(out, a.double().sum(0).reshape(-1)) < 1e-3
+
+
+@pytest.mark.parametrize("B,r_in,r_out", [(3, 224, 128), (2, 224, 160), (2, 224, 192), (2, 224, 224), (2, 64, 96), (1, 37, 20)])
+def test_resize_bilinear(ops, B, r_in, r_out):
+    """per-step input resize (main_prog.py:973): against torch's own F.interpolate on the CPU (the reference calls exactly that),
+    output bf16 NHWC: <= 1 bf16 ulp of the fp32 result"""
+    x = torch.randn(B, 3, r_in, r_in, generator=torch.Generator().manual_seed(r_out))
+    ref = torch.nn.functional.interpolate(x, size=(r_out, r_out), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    y = ops.resize_bilinear_nhwc(dev(x), r_out)
+    assert y.shape == (B, r_out, r_out, 3) and y.dtype == torch.bfloat16
+    err = (y.float().cpu() - ref).abs()
+    assert float((err / (ref.abs() * 2 ** -8 + 1e-6)).max()) <= 1.01, float(err.max())
+    if r_in == r_out:
+        assert torch.equal(y.cpu(), ref.to(torch.bfloat16))
 
 
 def test_errors_are_loud(ops):

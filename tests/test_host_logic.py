@@ -133,5 +133,33 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(LIB_PATH)
     for sym in declared:
         assert hasattr(raw, sym), sym
-    assert lib.ap_abi_version() == 1
+    assert lib.ap_abi_version() == 2
     assert lib.ap_error_string(-2).decode().startswith("configuration not supported")
+
+
+def test_bench_self_launch_two_ranks_gloo():
+    """`python bench.py --gpus 2` without a launcher starts torch.distributed.run itself (the reference starts its ranks from
+    distributed_train_prog.sh:4); --launch-check runs only the rendezvous and the bucketed gradient exchange (CPU, gloo)"""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["launch_check"] == "ok" and d["rccl_ranks"] == 2 and abs(d["grad_mean"] - 1.5) < 1e-6
+
+
+def test_drop_path_rates_follow_the_active_blocks():
+    """set_drop_path_rate on a supernet config == the rates the reference constructor gives the extracted network"""
+    from autoprog_amd.models import create_model
+    from autoprog_amd.models.volo import Transformer
+    m = create_model("model_variant", variant="volo_h12_l18", drop_path_rate=0.1)
+    m.set_sample_config(dict(layer_num=12, min_layer_num=9, max_layer_num=18))
+    m.set_drop_path_rate(0.0667)
+    ext = create_model("model_variant", variant="volo_h12_l12", drop_path_rate=0.0667)
+    got = [b.drop_prob for s in m.network if isinstance(s, torch.nn.Sequential) for b in s if isinstance(b, Transformer) and not b.is_identity_layer]
+    want = [b.drop_prob for s in ext.network if isinstance(s, torch.nn.Sequential) for b in s if isinstance(b, Transformer)]
+    assert len(got) == len(want) == 8 and all(abs(a - b) < 1e-12 for a, b in zip(got, want)), (got, want)
