@@ -147,6 +147,37 @@ class FlatAdamWEma:
                 for d, bufs in zip(self.ema_decays, self.ema_buffers):
                     torch._foreach_lerp_(bufs, self._buffers, 1.0 - d)
 
+    def grow(self, old_mask, new_mask):
+        """stage transition of a progressive run ON the live slabs (prog/elastic.py; reference: create_stage_model_and_optimizer,
+        main_prog.py:1300-1430 -- load_slice_clone_ema for the model from the LAST EMA copy, load_slice_clone for EMA copy i from
+        EMA copy i, fresh optimizer, BatchNorm statistics back to their defaults).  The caller switches the model to the new stage
+        with set_sample_config afterwards."""
+        from .prog.elastic import growth_sources
+        where = {name: (off, shape) for name, off, shape in self._views}
+        src_of = growth_sources(list(where), old_mask, new_mask)
+        with torch.no_grad():
+            old = [e.clone() for e in self.ema] if self.ema else [self.p.clone()]
+            for name, (off, shape) in where.items():
+                sname = src_of.get(name)
+                if sname is None:
+                    continue                           # slot inactive in the new stage: untouched
+                soff, sshape = where[sname]
+                n = 1
+                for d in shape:
+                    n *= d
+                if tuple(sshape) != tuple(shape):
+                    raise ValueError("%s <- %s: shapes differ (width growth is a state-dict operation, prog/growth.py)" % (name, sname))
+                self.p[off:off + n].copy_(old[-1][soff:soff + n])
+                for e, eo in zip(self.ema, old):
+                    e[off:off + n].copy_(eo[soff:soff + n])
+            for m in self.model.modules():            # the reference's new network starts with default BatchNorm statistics
+                if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                    m.reset_running_stats()
+            for bufs in self.ema_buffers:
+                for dst, src in zip(bufs, self._buffers):
+                    dst.copy_(src)
+        self.resync(reset_ema=False, reset_moments=True)
+
     def zero_grad(self, set_to_none=False):
         """gradients are views of the reducer's slab and stay attached (prog/scaler.py:60-68 step contract)"""
         self.reducer.zero_grad()

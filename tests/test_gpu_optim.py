@@ -143,3 +143,56 @@ def test_deferred_mean_is_folded_into_the_update():
         opt.step()
         outs.append(net.weight.detach().clone())
     assert torch.allclose(outs[0], outs[1], atol=1e-7)
+
+
+def test_stage_transition_on_live_slabs():
+    """FlatAdamWEma.grow: depth grows 3 -> 5 on ONE volo_h2_l6 supernet.  The active sub-network
+    afterwards equals what the reference's route builds (extract the previous stage's EMA state dicts, grow_clone_ema them into a
+    5-layer network -- prog/growth.py, pinned bit-exact against the reference's load_slice_clone_ema), the EMA copies follow
+    load_slice_clone, the optimizer restarts, BatchNorm statistics are back at their defaults, and the next steps train."""
+    from autoprog_amd.dist import GradientBucketReducer
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    from autoprog_amd.models import create_model
+    from autoprog_amd.optim import FlatAdamWEma
+    from autoprog_amd.prog import elastic, growth
+    torch.manual_seed(0)
+    model = create_model("model_variant", variant="volo_h2_l6", num_classes=16, img_size=64, stem_hidden_dim=16).cuda().train()
+    red = GradientBucketReducer(list(model.parameters()), world_size=1)
+    red.install_sink(model)
+    opt = FlatAdamWEma(model, red, lr=1e-3, weight_decay=0.05, ema_decays=[0.5, 0.6, 0.7, 0.8])
+    loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=16)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(4, 3, 64, 64, generator=g).cuda()
+    target = torch.softmax(torch.randn(4, 16, 18, generator=g) * 2, dim=1).cuda()
+    try:
+        old_mask = model.set_sample_config(dict(layer_num=3, min_layer_num=3, max_layer_num=6))
+        np.random.seed(0)
+        for _ in range(3):
+            _step(model, red, opt, loss_fn, x, target)
+        ema_before = [{k: v.detach().clone() for k, v in opt.ema_state_dict(i).items()} for i in range(4)]
+        new_mask = elastic.make_mask(5, 3, 6)
+        opt.grow(old_mask, new_mask)
+        model.set_sample_config(dict(layer_num=5, min_layer_num=3, max_layer_num=6))
+        # reference route on state dicts
+        prev = [elastic.export_state_dict(e, old_mask) for e in ema_before]
+        shape5 = create_model("model_variant", variant="volo_h2_l5", num_classes=16, img_size=64, stem_hidden_dim=16).state_dict()
+        want = growth.grow_clone_ema(shape5, prev[3], prev[:3])
+        got = elastic.export_state_dict({k: v.detach() for k, v in model.state_dict().items()}, new_mask)
+        assert set(got) == set(want)
+        for k, v in want.items():
+            if k.rsplit(".", 1)[-1] in ("running_mean", "running_var", "num_batches_tracked"):
+                continue
+            assert torch.equal(got[k].cpu(), v.cpu()), k
+        want_e1 = growth.grow_clone_ema(shape5, prev[1], [prev[1]] * 3)
+        got_e1 = elastic.export_state_dict(opt.ema_state_dict(1), new_mask)
+        for k, v in want_e1.items():
+            if k.rsplit(".", 1)[-1] not in ("running_mean", "running_var", "num_batches_tracked"):
+                assert torch.equal(got_e1[k].cpu(), v.cpu()), k
+        assert float(opt.m.abs().sum()) == 0.0 and float(opt.v.abs().sum()) == 0.0 and opt.step_count == 0
+        bn = model.patch_embed.conv[1]
+        assert float(bn.running_mean.abs().sum()) == 0.0 and torch.equal(bn.running_var, torch.ones_like(bn.running_var))
+        # the bf16 copies follow the slabs: the forward uses the grown weights, and training goes on
+        losses = [_step(model, red, opt, loss_fn, x, target) for _ in range(3)]
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0] + 0.5
+    finally:
+        red.remove()
