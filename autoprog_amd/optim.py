@@ -178,6 +178,32 @@ class FlatAdamWEma:
                     dst.copy_(src)
         self.resync(reset_ema=False, reset_moments=True)
 
+    def ema_weights(self, i):
+        """context manager: the model computes with EMA copy i (parameters and BatchNorm statistics) -- the reference evaluates /
+        probes its ModelEma modules (main_prog.py:1698-1760); here the slabs trade places for the duration of the block"""
+        opt = self
+
+        class _Swap:
+            def _swap(self_inner):
+                with torch.no_grad():
+                    tmp = opt.p.clone()
+                    opt.p.copy_(opt.ema[i])
+                    opt.ema[i].copy_(tmp)
+                    for b, e in zip(opt._buffers, opt.ema_buffers[i]):
+                        t = b.detach().clone()
+                        b.copy_(e)
+                        e.copy_(t)
+                opt.resync()
+
+            def __enter__(self_inner):
+                self_inner._swap()
+                return opt
+
+            def __exit__(self_inner, *exc):
+                self_inner._swap()
+                return False
+        return _Swap()
+
     def zero_grad(self, set_to_none=False):
         """gradients are views of the reducer's slab and stay attached (prog/scaler.py:60-68 step contract)"""
         self.reducer.zero_grad()

@@ -1,0 +1,156 @@
+"""The AutoProg grow / search loop over ONE supernet.
+
+Reference: main_prog.py:786-857 (the epoch loop: at a grow epoch either take the scheduled (r, l) or search for it),
+main_prog.py:1558-1821 `auto_grow` (train the search supernet with a random sub-network per step, probe every candidate with the
+first EMA copy, rank by loss * time^w) and main_prog.py:1300-1430 `create_stage_model_and_optimizer`.
+
+What is different here, by design (north_star: "elastic depth / num_tokens ... as kernel launch-time shape parameters rather than
+weight copies"): the reference builds a new network + optimizer + EMA list at every grow epoch and again for every search; this
+driver keeps ONE network sized for the deepest stage with its flat parameter / moment / EMA slabs (optim.FlatAdamWEma) and moves
+between stages with `FlatAdamWEma.grow` (prog/elastic.py) and `set_sample_config` -- a candidate of a search is a mask and a
+resolution, nothing is copied to evaluate it.  The per-step input resize runs on the device (ap_resize_bilinear_nhwc).
+
+Out of scope: data loading, augmentation strength schedules (only DropPath lives in the model), LR scheduler,
+checkpoint files, validation -- the caller supplies `get_batch(r) -> (images, target)` and reads `history`.
+"""
+import random
+import time
+
+import torch
+
+from . import search as S
+from .helpers import ActiveLayerMask
+
+
+class AutoProgDriver:
+    def __init__(self, model, loss_fn, optimizer, reducer, get_batch, r_list, l_list, dp_list, grow_epochs, steps_per_epoch,
+                 search_epochs=2, auto_grow=True, probe_batches=4, time_steps=4, seed=0, log=None):
+        """model: supernet sized for l_list[-1] (e.g. volo_h12_l18); optimizer: FlatAdamWEma over it; reducer: its
+        GradientBucketReducer; r_list / l_list / dp_list / grow_epochs: the stage schedule (prog/progressive.py:4-31);
+        get_batch(r): a training batch (images at ANY size -- the stem resizes to r -- and a token-label target for r // 16)."""
+        self.model, self.loss_fn, self.opt, self.reducer, self.get_batch = model, loss_fn, optimizer, reducer, get_batch
+        self.r_list, self.l_list, self.dp_list, self.grow_epochs = list(r_list), list(l_list), list(dp_list), list(grow_epochs)
+        self.steps_per_epoch, self.search_epochs, self.auto_grow = steps_per_epoch, search_epochs, auto_grow
+        self.probe_batches, self.time_steps = probe_batches, time_steps
+        self.l_min, self.l_max = min(l_list), max(l_list)
+        self.rng = random.Random(seed)
+        self.log = log or (lambda *a: None)
+        self.history = []                     # one dict per epoch: stage, (r, l), mean loss, search decisions
+        self.current_r, self.current_l, self.current_dp = None, None, 0.0
+        self.mask = None
+
+    # ------------------------------------------------------------------ elastic plumbing
+    def _config(self, l, r):
+        return dict(layer_num=l, min_layer_num=self.l_min, max_layer_num=self.l_max, input_size=r, token_label_size=r // 16)
+
+    def _activate(self, l, r, dp):
+        mask = self.model.set_sample_config(self._config(l, r))
+        self.model.set_drop_path_rate(dp)
+        return mask
+
+    def _transition(self, l, r, dp):
+        """move the live slabs to depth l (prog/elastic.py), then select (l, r, dp)"""
+        new_mask = ActiveLayerMask(l, self.l_min, self.l_max)
+        if self.mask is not None and l != self.current_l:
+            self.opt.grow(self.mask, new_mask)
+        self.mask = self._activate(l, r, dp)
+        self.current_l, self.current_r, self.current_dp = l, r, dp
+
+    def _train_step(self, l, r, dp):
+        self._activate(l, r, dp)
+        images, target = self.get_batch(r)
+        self.reducer.zero_grad()
+        loss = self.loss_fn(self.model(images), target)
+        loss.backward()
+        self.reducer.finish()
+        self.opt.step()
+        return loss.detach()
+
+    # ------------------------------------------------------------------ search (main_prog.py:1558-1821)
+    def _probe(self, cands, ema_index=0):
+        """train-mode, no-grad loss of EMA copy `ema_index` on `probe_batches` batches per candidate (the reference's taylor0)"""
+        out = {}
+        with self.opt.ema_weights(ema_index), torch.no_grad():
+            for (r, l) in cands:
+                self._activate(l, r, 0.0)
+                tot = 0.0
+                for _ in range(self.probe_batches):
+                    images, target = self.get_batch(r)
+                    tot += float(self.loss_fn(self.model(images), target))
+                out[(r, l)] = tot / self.probe_batches
+        return out
+
+    def _time(self, cands):
+        """mean forward+backward seconds per candidate, measured once at search start (main_prog.py:1886-1902)"""
+        out = {}
+        for (r, l) in cands:
+            self._activate(l, r, self.current_dp)
+            images, target = self.get_batch(r)
+            for i in range(self.time_steps + 1):
+                if i == 1:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                self.reducer.zero_grad()
+                self.loss_fn(self.model(images), target).backward()
+                self.reducer.finish()
+                self.reducer.take_pending_scale()
+            torch.cuda.synchronize()
+            out[(r, l)] = (time.perf_counter() - t0) / self.time_steps
+        return out
+
+    def search(self, stage, epoch):
+        """-> chosen (r, l).  The search supernet is the largest candidate; its sub-networks are trained with one random candidate
+        per step for `search_epochs` epochs under the FINAL DropPath strength (main_prog.py:814-815), probed, and ranked by
+        loss * time^w (prog/search.py converge_speed)."""
+        rs, _, ls = S.search_space(stage, self.r_list, [0] * len(self.r_list), self.l_list, self.current_r or self.r_list[0], 0,
+                                   self.current_l or self.l_list[0])
+        if ls[-1] > 2 * ls[0]:
+            raise ValueError("a search over more than 2x depth is not defined (main_prog.py:1562)")
+        cands = [(r, l) for r in rs for l in ls]
+        dp_final = self.dp_list[-1]
+        self._transition(ls[-1], rs[-1], dp_final)                    # grow the live slabs to the search supernet
+        times = self._time(cands)
+        losses = []
+        for e in range(self.search_epochs):
+            probes = 1 if e == 0 else 4                               # main_prog.py:1617: probe points per search epoch
+            per = max(1, self.steps_per_epoch // probes)
+            for p in range(probes):
+                losses.append(self._probe(cands))
+                for _ in range(per):
+                    r, l = self.rng.choice(rs), self.rng.choice(ls)   # one config per step, identical on every rank (seeded)
+                    self._train_step(l, r, dp_final)
+        losses.append(self._probe(cands))
+        mean_loss = {"r%d_l%d" % c: sum(p[c] for p in losses) / len(losses) for c in cands}
+        step_time = {"r%d_l%d" % c: times[c] for c in cands}
+        if len(cands) >= 2 and len({round(t, 9) for t in step_time.values()}) >= 2:
+            w, scores, order = S.converge_speed(mean_loss, step_time)
+        else:
+            w, scores, order = 0.0, dict(mean_loss), sorted(mean_loss, key=mean_loss.get)
+        best = order[0]
+        r, l = (int(v[1:]) for v in best.split("_"))
+        self.log("search @%d: w=%.3f scores=%s -> %s" % (epoch, w, {k: round(v, 4) for k, v in scores.items()}, best))
+        self.history.append(dict(epoch=epoch, kind="search", candidates=["r%d_l%d" % c for c in cands], w=w, scores=scores, chosen=(r, l),
+                                 step_time=step_time, mean_loss=mean_loss))
+        return r, l
+
+    # ------------------------------------------------------------------ epoch loop (main_prog.py:786-857)
+    def run(self, num_epochs):
+        skip = set()
+        for epoch in range(num_epochs):
+            if epoch in self.grow_epochs:
+                stage = self.grow_epochs.index(epoch)
+                if self.auto_grow and stage < len(self.grow_epochs) - 1:
+                    r, l = self.search(stage, epoch)
+                    skip.update(range(epoch, epoch + self.search_epochs))      # the search consumed these epochs (main_prog.py:856-857)
+                else:
+                    r, l = self.r_list[stage], self.l_list[stage]
+                self._transition(l, r, self.dp_list[stage])
+            if epoch in skip:
+                continue
+            tot = 0.0
+            for _ in range(self.steps_per_epoch):
+                tot += float(self._train_step(self.current_l, self.current_r, self.current_dp))
+            self.history.append(dict(epoch=epoch, kind="train", r=self.current_r, l=self.current_l, dp=self.current_dp,
+                                     loss=tot / self.steps_per_epoch))
+            self.log("epoch %d: r=%d l=%d loss %.4f" % (epoch, self.current_r, self.current_l, tot / self.steps_per_epoch))
+        return self.history

@@ -84,9 +84,9 @@ def growth_sources(names, old_mask, new_mask):
             continue
         j = new_p[net].index(slot)
         prev, new = len(old_p[net]), len(new_p[net])
-        if new < prev:
-            raise ValueError("network.%d shrinks from %d to %d layers: a stage transition only grows" % (net, prev, new))
-        src_slot = old_p[net][new_idx(j, prev, new)] if new > prev else old_p[net][j]
+        # growth: the reference's source layer; same depth or a SHALLOWER stage (the sub-network chosen by a search out of its
+        # supernet, load='super', main_prog.py:830-837): the active sets are nested, so every kept layer is its own source
+        src_slot = old_p[net][new_idx(j, prev, new)] if new > prev else slot
         out[k] = "network.%d.%d.%s" % (net, src_slot, m.group(3))
     return out
 

@@ -196,3 +196,42 @@ def test_stage_transition_on_live_slabs():
         assert all(np.isfinite(losses)) and losses[-1] < losses[0] + 0.5
     finally:
         red.remove()
+
+
+def test_autoprog_driver_two_stage_search():
+    """prog/driver.py: a miniature AutoProg run -- stage 0 opens with a search over r in {64, 96} x
+    l in {3, 6} on one volo_h2_l6 supernet (random sub-network per step, EMA probes, loss * time^w ranking), the run continues at
+    the chosen point, the last stage takes the scheduled (l, r); EMA probing leaves the live weights untouched."""
+    from autoprog_amd.dist import GradientBucketReducer
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    from autoprog_amd.models import create_model
+    from autoprog_amd.optim import FlatAdamWEma
+    from autoprog_amd.prog.driver import AutoProgDriver
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = create_model("model_variant", variant="volo_h2_l6", num_classes=16, img_size=96, stem_hidden_dim=16).cuda().train()
+    red = GradientBucketReducer(list(model.parameters()), world_size=1, defer_mean=True)
+    red.install_sink(model)
+    opt = FlatAdamWEma(model, red, lr=1e-3, weight_decay=0.05, ema_decays=[0.9, 0.99])
+    loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=16)
+    g = torch.Generator().manual_seed(1)
+    images = torch.randn(8, 3, 96, 96, generator=g).cuda()
+    targets = {r: torch.softmax(torch.randn(8, 16, 2 + (r // 16) ** 2, generator=g) * 2, dim=1).cuda() for r in (64, 96)}
+    logs = []
+    drv = AutoProgDriver(model, loss_fn, opt, red, lambda r: (images, targets[r]), r_list=[64, 96], l_list=[3, 6], dp_list=[0.0, 0.05],
+                         grow_epochs=[0, 3], steps_per_epoch=4, search_epochs=1, auto_grow=True, probe_batches=2, time_steps=2, log=logs.append)
+    try:
+        hist = drv.run(5)
+        searches = [h for h in hist if h["kind"] == "search"]
+        trains = [h for h in hist if h["kind"] == "train"]
+        assert len(searches) == 1 and set(searches[0]["candidates"]) == {"r64_l3", "r64_l6", "r96_l3", "r96_l6"}
+        assert searches[0]["chosen"] in [(64, 3), (64, 6), (96, 3), (96, 6)] and searches[0]["w"] >= 0
+        assert [t["epoch"] for t in trains] == [1, 2, 3, 4]                       # epoch 0 was the search epoch
+        assert (trains[0]["r"], trains[0]["l"]) == searches[0]["chosen"] and (trains[-1]["r"], trains[-1]["l"]) == (96, 6)
+        assert all(np.isfinite(t["loss"]) for t in trains)
+        before = opt.p.clone()
+        with opt.ema_weights(0):
+            assert not torch.equal(opt.p, before)
+        assert torch.equal(opt.p, before)
+    finally:
+        red.remove()
