@@ -33,6 +33,7 @@ _SIGNATURES = {
     "ap_cast_bf16_f32": (_I, [_P, _P, _L, _P]),
     "ap_cast_transpose_f32_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
     "ap_resize_bilinear_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ap_droppath_masks": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ap_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "ap_layernorm_bwd_workspace": (ctypes.c_size_t, [_L, _I]),
     "ap_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, _P]),
@@ -48,10 +49,11 @@ _SIGNATURES = {
     "ap_mhsa_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P]),
     "ap_mhsa_bwd_workspace": (ctypes.c_size_t, [_I, _I, _I, _I]),
     "ap_mhsa_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, ctypes.c_size_t, _P]),
-    "ap_class_attn_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
-    "ap_class_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "ap_class_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "ap_class_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "ap_mix_token_swap": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "ap_soft_ce_fwd_bwd": (_I, [_P, _I, _P, _L, _L, _L, _I, _P, _P, _F, _L, _I, _P]),
+    "ap_soft_ce_fwd_bwd": (_I, [_P, _I, _P, _L, _L, _L, _I, _P, _P, _F, _L, _I, _F, _I, _P]),
+    "ap_loss_combine": (_I, [_P, _L, _F, _P, _L, _F, _P, _P]),
     "ap_row_scale": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "ap_add_bcast": (_I, [_P, _P, _P, _L, _L, _P]),
     "ap_sum_reps_acc": (_I, [_P, _L, _L, _I, _P]),

@@ -229,6 +229,24 @@ k_resize_bilinear_nhwc(const float* __restrict__ x, bf16_t* __restrict__ y, int 
     }
 }
 
+// ---------------------------------------------------------------------------- DropPath masks
+// timm DropPath: mask = floor(keep + U[0,1)), factor = mask / keep.  One launch produces, for every DropPath site of
+// a forward pass: the per-sample factors, the 0/1 masks and the per-token bf16 masks the bias gradients read (16-byte aligned rows).
+__global__ void __launch_bounds__(256)
+k_droppath_masks(const float* __restrict__ u, const float* __restrict__ keep, float* __restrict__ factor, float* __restrict__ mask,
+                 bf16_t* __restrict__ tokmask, int sites, int B, int tokens, int row) {
+    const int64_t total = (int64_t)sites * row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int s = (int)(i / row), t = (int)(i - (int64_t)s * row);
+        const int b = tokens > 0 ? t / tokens : t;
+        const bool valid = b < B && (tokens > 0 ? t < B * tokens : true);
+        const float k = keep[s];
+        const float m = valid ? floorf(k + u[s * B + b]) : 0.f;
+        if (tokmask) tokmask[i] = f2bf(m);
+        if (valid && (tokens > 0 ? t == b * tokens : true)) { mask[s * B + b] = m; factor[s * B + b] = m / k; }
+    }
+}
+
 extern "C" {
 
 int ap_abi_version(void) { return 2; }
@@ -272,6 +290,17 @@ int ap_resize_bilinear_nhwc(const float* x, ap_bf16* y, int B, int C, int Hi, in
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_resize_bilinear_nhwc, dim3(grid_for((int64_t)B * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, y, B, C, Hi, Wi, Ho, Wo,
                        (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    return ap_check_launch();
+}
+
+int ap_droppath_masks(const float* uniform, const float* keep, float* factor, float* mask, ap_bf16* token_mask, int sites, int B,
+                      int tokens, int token_row, ap_stream_t stream) {
+    if (!uniform || !keep || !factor || !mask) return AP_ERR_NULL;
+    if (sites <= 0 || B <= 0 || tokens < 0 || (tokens > 0 && (!token_mask || token_row < B * tokens || (token_row & 7)))) return AP_ERR_SHAPE;
+    const int row = tokens > 0 ? token_row : B;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_droppath_masks, dim3(grid_for((int64_t)sites * row)), dim3(256), 0, (hipStream_t)stream, uniform, keep, factor, mask,
+                       tokens > 0 ? token_mask : nullptr, sites, B, tokens, row);
     return ap_check_launch();
 }
 

@@ -317,7 +317,7 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
 template <int PARTS>
 __global__ void __launch_bounds__(256)
 k_class_attn_fwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, bf16_t* __restrict__ out,
-                 float* __restrict__ probs, int N, int heads, int hd, float scale) {
+                 float* __restrict__ probs, int N, int heads, int hd, float scale, const bf16_t* __restrict__ kv0) {
     extern __shared__ __attribute__((aligned(16))) float sm[];     // scores[N] | red[KS*HDP]
     constexpr int KS = 256 / PARTS, HDP = PARTS * 8;               // keys per pass, padded head dim
     float* sc = sm;
@@ -329,14 +329,18 @@ k_class_attn_fwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, bf
     const bool pok = part * 8 < hd;
     float qv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (pok) unpack8(ld16(q + (int64_t)b * C + h * hd + part * 8), qv);
-    const bf16_t* kb = kv + (int64_t)b * N * 2 * C + h * hd + part * 8;
+    // split layout (kv0 != nullptr): key 0 (the class token) lives in kv0 [B, 2C], keys 1..N-1 are the N-1 token rows of kv -- the
+    // caller never concatenates the class token with the tokens (models/volo.py:304-308 does, a 19 MB copy per block at B = 128)
+    const int shift = kv0 ? 1 : 0;
+    const bf16_t* kb = kv + ((int64_t)b * (N - shift) - shift) * 2 * C + h * hd + part * 8;      // kb + key*2C is row `key` for key >= shift
+    const bf16_t* krow0 = kv0 ? kv0 + (int64_t)b * 2 * C + h * hd + part * 8 : kb;
     float mx = -1.0e30f;
     for (int k0 = 0; k0 < N; k0 += KS) {
         const int key = k0 + kslot;
         float d = 0.f;
         if (key < N && pok) {
             float kk[8];
-            unpack8(ld16(kb + (int64_t)key * 2 * C), kk);
+            unpack8(ld16((kv0 && key == 0) ? krow0 : kb + (int64_t)key * 2 * C), kk);
 #pragma unroll
             for (int i = 0; i < 8; ++i) d += qv[i] * kk[i];
         }
@@ -364,7 +368,7 @@ k_class_attn_fwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, bf
             if (part == 0) probs[((int64_t)b * heads + h) * N + key] = p;
             if (pok) {
                 float vv[8];
-                unpack8(ld16(kb + (int64_t)key * 2 * C + C), vv);
+                unpack8(ld16(((kv0 && key == 0) ? krow0 : kb + (int64_t)key * 2 * C) + C), vv);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[i] += p * vv[i];
             }
@@ -384,7 +388,7 @@ template <int PARTS>
 __global__ void __launch_bounds__(256)
 k_class_attn_bwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, const float* __restrict__ probs,
                  const bf16_t* __restrict__ dout, bf16_t* __restrict__ dq, bf16_t* __restrict__ dkv,
-                 int N, int heads, int hd, float scale) {
+                 int N, int heads, int hd, float scale, const bf16_t* __restrict__ kv0, bf16_t* __restrict__ dkv0) {
     extern __shared__ __attribute__((aligned(16))) float sm[];     // dp[N] | red[KS*HDP]
     constexpr int KS = 256 / PARTS, HDP = PARTS * 8;
     float* dps = sm;
@@ -399,8 +403,11 @@ k_class_attn_bwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, co
         unpack8(ld16(q + (int64_t)b * C + h * hd + part * 8), qv);
         unpack8(ld16(dout + (int64_t)b * C + h * hd + part * 8), gv);
     }
-    const bf16_t* kb = kv + (int64_t)b * N * 2 * C + h * hd + part * 8;
-    bf16_t* db = dkv + (int64_t)b * N * 2 * C + h * hd + part * 8;
+    const int shift = kv0 ? 1 : 0;                                  // split layout, see k_class_attn_fwd
+    const bf16_t* kb = kv + ((int64_t)b * (N - shift) - shift) * 2 * C + h * hd + part * 8;
+    bf16_t* db = dkv + ((int64_t)b * (N - shift) - shift) * 2 * C + h * hd + part * 8;
+    const bf16_t* krow0 = kv0 ? kv0 + (int64_t)b * 2 * C + h * hd + part * 8 : kb;
+    bf16_t* drow0 = kv0 ? dkv0 + (int64_t)b * 2 * C + h * hd + part * 8 : db;
     const float* pr = probs + ((int64_t)b * heads + h) * N;
     // dp_k = <dout, V_k>;  dV_k = p_k * dout;  dot = sum_k p_k dp_k
     float dot = 0.f;
@@ -409,11 +416,12 @@ k_class_attn_bwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, co
         float d = 0.f;
         if (key < N && pok) {
             float vv[8], o8[8];
-            unpack8(ld16(kb + (int64_t)key * 2 * C + C), vv);
+            const bool first = kv0 && key == 0;
+            unpack8(ld16((first ? krow0 : kb + (int64_t)key * 2 * C) + C), vv);
             const float p = pr[key];
 #pragma unroll
             for (int i = 0; i < 8; ++i) { d += gv[i] * vv[i]; o8[i] = p * gv[i]; }
-            st16(db + (int64_t)key * 2 * C + C, pack8(o8));
+            st16((first ? drow0 : db + (int64_t)key * 2 * C) + C, pack8(o8));
         }
         d += __shfl_xor(d, 1, 64);
         d += __shfl_xor(d, 2, 64);
@@ -430,10 +438,11 @@ k_class_attn_bwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv, co
         if (key < N && pok) {
             const float ds = pr[key] * (dps[key] - dot) * scale;       // d(score)/d(q.k)
             float kk[8], o8[8];
-            unpack8(ld16(kb + (int64_t)key * 2 * C), kk);
+            const bool first = kv0 && key == 0;
+            unpack8(ld16(first ? krow0 : kb + (int64_t)key * 2 * C), kk);
 #pragma unroll
             for (int i = 0; i < 8; ++i) { acc[i] += ds * kk[i]; o8[i] = ds * qv[i]; }
-            st16(db + (int64_t)key * 2 * C, pack8(o8));
+            st16(first ? drow0 : db + (int64_t)key * 2 * C, pack8(o8));
         }
     }
 #pragma unroll
@@ -515,7 +524,7 @@ int ap_mhsa_bwd(const ap_bf16* qkv, const ap_bf16* out, const ap_bf16* dout, con
     return ap_check_launch();
 }
 
-int ap_class_attn_fwd(const ap_bf16* q, const ap_bf16* kv, ap_bf16* out, float* probs, int B, int N, int heads, int hd,
+int ap_class_attn_fwd(const ap_bf16* q, const ap_bf16* kv, const ap_bf16* kv_cls, ap_bf16* out, float* probs, int B, int N, int heads, int hd,
                       float scale, ap_stream_t stream) {
     if (!q || !kv || !out || !probs) return AP_ERR_NULL;
     if (B <= 0 || N <= 0 || heads <= 0) return AP_ERR_SHAPE;
@@ -523,21 +532,21 @@ int ap_class_attn_fwd(const ap_bf16* q, const ap_bf16* kv, ap_bf16* out, float* 
     const size_t lds = ((size_t)((N + 63) & ~63) + 64 * 32) * sizeof(float);          // KS * HDP = 2048 floats for both PARTS
     if (lds > 64 * 1024) return AP_ERR_UNSUPPORTED;
     (void)hipGetLastError();
-    if (hd == 32) hipLaunchKernelGGL(k_class_attn_fwd<4>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, out, probs, N, heads, hd, scale);
-    else hipLaunchKernelGGL(k_class_attn_fwd<8>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, out, probs, N, heads, hd, scale);
+    if (hd == 32) hipLaunchKernelGGL(k_class_attn_fwd<4>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, out, probs, N, heads, hd, scale, kv_cls);
+    else hipLaunchKernelGGL(k_class_attn_fwd<8>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, out, probs, N, heads, hd, scale, kv_cls);
     return ap_check_launch();
 }
 
-int ap_class_attn_bwd(const ap_bf16* q, const ap_bf16* kv, const float* probs, const ap_bf16* dout, ap_bf16* dq, ap_bf16* dkv,
-                      int B, int N, int heads, int hd, float scale, ap_stream_t stream) {
-    if (!q || !kv || !probs || !dout || !dq || !dkv) return AP_ERR_NULL;
+int ap_class_attn_bwd(const ap_bf16* q, const ap_bf16* kv, const ap_bf16* kv_cls, const float* probs, const ap_bf16* dout, ap_bf16* dq, ap_bf16* dkv,
+                      ap_bf16* dkv_cls, int B, int N, int heads, int hd, float scale, ap_stream_t stream) {
+    if (!q || !kv || !probs || !dout || !dq || !dkv || ((kv_cls == nullptr) != (dkv_cls == nullptr))) return AP_ERR_NULL;
     if (B <= 0 || N <= 0 || heads <= 0) return AP_ERR_SHAPE;
     if (hd != 32 && hd != 48 && hd != 64) return AP_ERR_UNSUPPORTED;
     const size_t lds = ((size_t)((N + 63) & ~63) + 64 * 32) * sizeof(float);
     if (lds > 64 * 1024) return AP_ERR_UNSUPPORTED;
     (void)hipGetLastError();
-    if (hd == 32) hipLaunchKernelGGL(k_class_attn_bwd<4>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, probs, dout, dq, dkv, N, heads, hd, scale);
-    else hipLaunchKernelGGL(k_class_attn_bwd<8>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, probs, dout, dq, dkv, N, heads, hd, scale);
+    if (hd == 32) hipLaunchKernelGGL(k_class_attn_bwd<4>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, probs, dout, dq, dkv, N, heads, hd, scale, kv_cls, dkv_cls);
+    else hipLaunchKernelGGL(k_class_attn_bwd<8>, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, q, kv, probs, dout, dq, dkv, N, heads, hd, scale, kv_cls, dkv_cls);
     return ap_check_launch();
 }
 

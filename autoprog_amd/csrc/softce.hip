@@ -16,7 +16,7 @@
 __global__ void __launch_bounds__(256)
 k_soft_ce(const bf16_t* __restrict__ logits, int ldx, const float* __restrict__ target, int64_t t_sb, int64_t t_sc,
           int64_t t_sn, int rows_per_batch, float* __restrict__ row_loss, bf16_t* __restrict__ dlogits,
-          float gscale, int64_t M, int C, int tiles_per_batch) {
+          float gscale, int64_t M, int C, int tiles_per_batch, float mix_lam, int mix_batches) {
     extern __shared__ __attribute__((aligned(16))) float tt[];      // [CE_TN][Cp] Cp odd
     const int Cp = C | 1;
     const int64_t b = blockIdx.x / tiles_per_batch;
@@ -26,6 +26,9 @@ k_soft_ce(const bf16_t* __restrict__ logits, int ldx, const float* __restrict__ 
     {
         const int tn = threadIdx.x & (CE_TN - 1), cl = threadIdx.x / CE_TN;     // 16 classes per pass
         const float* tb = target + b * t_sb + (int64_t)(n0 + tn) * t_sn;
+        // mix-token: the image-level label of sample b is lam * t[b] + (1 - lam) * t[B-1-b] (loss/cross_entropy.py:151-152)
+        const float* tb2 = mix_batches > 0 ? target + (int64_t)(mix_batches - 1 - b) * t_sb + (int64_t)(n0 + tn) * t_sn : tb;
+        const float lam2 = mix_batches > 0 ? 1.0f - mix_lam : 0.f, lam1 = mix_batches > 0 ? mix_lam : 1.0f;
         // 8 independent loads in flight per thread (the one-load-per-iteration loop waited a full memory latency 63 times)
         constexpr int CSTEP = 256 / CE_TN;
         for (int c0 = cl; c0 < C; c0 += 8 * CSTEP) {
@@ -33,7 +36,7 @@ k_soft_ce(const bf16_t* __restrict__ logits, int ldx, const float* __restrict__ 
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int c = c0 + u * CSTEP;
-                v[u] = (tn < ntok && c < C) ? tb[(int64_t)c * t_sc] : 0.f;
+                v[u] = (tn < ntok && c < C) ? lam1 * tb[(int64_t)c * t_sc] + lam2 * tb2[(int64_t)c * t_sc] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -96,10 +99,37 @@ k_soft_ce(const bf16_t* __restrict__ logits, int ldx, const float* __restrict__ 
     }
 }
 
+// loss = wa * sum(a[0:na]) + wb * sum(b[0:nb]) in one workgroup (the two CE terms of the token-label loss, loss/cross_entropy.py:154-156)
+__global__ void __launch_bounds__(1024)
+k_loss_combine(const float* __restrict__ a, int64_t na, float wa, const float* __restrict__ b, int64_t nb, float wb, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < na; i += 1024) s += wa * a[i];
+    for (int64_t i = threadIdx.x; i < nb; i += 1024) s += wb * b[i];
+    s = group_sum<64>(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w];
+        out[0] = t;
+    }
+}
+
+extern "C" int ap_loss_combine(const float* a, int64_t na, float wa, const float* b, int64_t nb, float wb, float* out, ap_stream_t stream) {
+    if (!a || !out || (nb > 0 && !b)) return AP_ERR_NULL;
+    if (na < 0 || nb < 0) return AP_ERR_SHAPE;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_loss_combine, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, na, wa, b, nb, wb, out);
+    return ap_check_launch();
+}
+
 extern "C" int ap_soft_ce_fwd_bwd(const ap_bf16* logits, int ldx, const float* target, int64_t t_sb, int64_t t_sc,
                                   int64_t t_sn, int rows_per_batch, float* row_loss, ap_bf16* dlogits,
-                                  float grad_scale, int64_t M, int C, ap_stream_t stream) {
+                                  float grad_scale, int64_t M, int C, float mix_lam, int mix_batches, ap_stream_t stream) {
     if (!logits || !target || !row_loss || !dlogits) return AP_ERR_NULL;
+    if (mix_batches != 0 && (mix_batches < 0 || (int64_t)mix_batches * rows_per_batch != M)) return AP_ERR_SHAPE;
     if (C <= 0 || ldx < C || (ldx & 7) || rows_per_batch <= 0 || M % rows_per_batch) return AP_ERR_SHAPE;
     if (ldx > 64 * 2 * CE_MAXV) return AP_ERR_UNSUPPORTED;
     if (M == 0) return AP_OK;
@@ -108,6 +138,6 @@ extern "C" int ap_soft_ce_fwd_bwd(const ap_bf16* logits, int ldx, const float* t
     const size_t lds = (size_t)CE_TN * (C | 1) * sizeof(float);
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_soft_ce, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, logits, ldx, target, t_sb, t_sc,
-                       t_sn, rows_per_batch, row_loss, dlogits, grad_scale, M, C, tiles);
+                       t_sn, rows_per_batch, row_loss, dlogits, grad_scale, M, C, tiles, mix_lam, mix_batches);
     return ap_check_launch();
 }

@@ -274,6 +274,63 @@ class TransformerBlockFn(torch.autograd.Function):
         return (dx.view(dy.shape), None, None, *_finish_param_grads(params, bufs, sunk), None, None, None, None, None, None, None, None, None)
 
 
+# ----------------------------------------------------------------------------- class block
+class ClassBlockFn(torch.autograd.Function):
+    """ClassBlock.forward (models/volo.py:304-308) on SEPARATE class token [B,C] and tokens [B*N,C]:
+        cls += proj(class_attn(LN1([cls; tokens])));  cls += fc2(gelu(fc1(LN2(cls))))
+    The reference concatenates [cls; tokens] before every class block and slices the result apart again; LayerNorm and the kv
+    projection act per row, so both run on the two pieces separately and the attention kernel reads key 0 from the class-token
+    piece (split layout of ap_class_attn_*): no concatenation, no slicing, and the residual adds sit in the GEMM epilogues."""
+
+    @staticmethod
+    def forward(ctx, cls, tok, n1w, n1b, kv_w, kv_b, q_w, q_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, B, N, heads, eps):
+        C = cls.shape[-1]
+        c0 = cls.reshape(B, C).contiguous()
+        t0 = tok.reshape(B * N, C).contiguous()
+        inner = q_w.shape[0]
+        scale = (inner // heads) ** -0.5
+        nc, mc, rc = ops.layernorm_fwd(c0, n1w, n1b, eps)
+        nt, mt, rt = ops.layernorm_fwd(t0, n1w, n1b, eps)
+        kv_t = ops.gemm_nt(nt, bank.get(kv_w), bias=kv_b)
+        kv_c = ops.gemm_nt(nc, bank.get(kv_w), bias=kv_b)
+        q = ops.gemm_nt(nc, bank.get(q_w), bias=q_b)
+        o, probs = ops.class_attn_fwd(q, kv_t, B, N + 1, heads, scale, kv_cls=kv_c)
+        c1 = ops.gemm_nt(o, bank.get(proj_w), bias=proj_b, residual=c0)
+        n2, m2, r2 = ops.layernorm_fwd(c1, n2w, n2b, eps)
+        h = torch.empty((B, fc1_w.shape[0]), dtype=BF16, device=cls.device)
+        a = ops.gemm_nt(n2, bank.get(fc1_w), bias=fc1_b, gelu=True, preact_out=h)
+        c2 = ops.gemm_nt(a, bank.get(fc2_w), bias=fc2_b, residual=c1)
+        ctx.save_for_backward(c0, t0, mc, rc, mt, rt, nc, nt, kv_t, kv_c, q, o, probs, c1, m2, r2, n2, h, a,
+                              n1w, n1b, kv_w, kv_b, q_w, q_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
+        ctx.cfg = (B, N, heads, scale)
+        ctx.shapes = (cls.shape, tok.shape)
+        return c2
+
+    @staticmethod
+    def backward(ctx, dc2):
+        (c0, t0, mc, rc, mt, rt, nc, nt, kv_t, kv_c, q, o, probs, c1, m2, r2, n2, h, a,
+         n1w, n1b, kv_w, kv_b, q_w, q_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b) = ctx.saved_tensors
+        B, N, heads, scale = ctx.cfg
+        params = (n1w, n1b, kv_w, kv_b, q_w, q_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
+        bufs, sunk = _param_grad_buffers(params)
+        (dn1w, dn1b, dkv_w, dkv_b, dq_w, dq_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = bufs
+        g = dc2.contiguous()
+        with wgrad_batch():
+            dh = _linear_bwd(g, a, fc2_w, dfc2_w, dfc2_b, dgelu_of=h)
+            dn2 = _linear_bwd(dh, n2, fc1_w, dfc1_w, dfc1_b)
+            dc1 = ops.layernorm_bwd(dn2, c1, n2w, m2, r2, g, dn2w, dn2b)
+            do = _linear_bwd(dc1, o, proj_w, dproj_w, dproj_b)
+            dq, dkv_t, dkv_c = ops.class_attn_bwd(q, kv_t, probs, do, B, N + 1, heads, scale, kv_cls=kv_c)
+            dnt = _linear_bwd(dkv_t, nt, kv_w, dkv_w, dkv_b)
+            dnc_kv = _linear_bwd(dkv_c, nc, kv_w, dkv_w, dkv_b)                 # second contribution to the same weight gradient
+            _linear_bwd(dq, nc, q_w, dq_w, dq_b, need_dx=False)
+            wq_t = bank.get_t(q_w)
+            dnc = ops.gemm_nt(dq, wq_t, n=wq_t.shape[0], k=wq_t.shape[1], residual=dnc_kv)      # dq Wq + dkv_c Wkv in one epilogue
+            dcls = ops.layernorm_bwd(dnc, c0, n1w, mc, rc, dc1, dn1w, dn1b)
+            dtok = ops.layernorm_bwd(dnt, t0, n1w, mt, rt, None, dn1w, dn1b)
+        return (dcls.view(ctx.shapes[0]), dtok.view(ctx.shapes[1]), *_finish_param_grads(params, bufs, sunk), None, None, None, None)
+
+
 # ------------------------------------------------------------------------- outlooker block
 class OutlookerBlockFn(torch.autograd.Function):
     """Outlooker.forward (models/volo.py:140-144) with OutlookAttention (models/volo.py:77-103):
@@ -463,6 +520,46 @@ class SoftTargetCEFn(torch.autograd.Function):
         return (out if out.shape[1] == ctx.C else out[:, :ctx.C]), None, None, None, None, None
 
 
+class TokenLabelCEFn(torch.autograd.Function):
+    """TokenLabelCrossEntropy.forward with a token-label target [B,C,2+N] (loss/cross_entropy.py:136-156) in three launches:
+    dense CE of the aux logits against target[:,:,2:], CE of the class logits against the (mix-token blended) target[:,:,1],
+    and cls_weight * mean + dense_weight * mean.  The reference's version of this is ~20 small tensor ops on the loss path; both
+    gradients come out of the forward kernels and only take the incoming scalar in backward."""
+
+    @staticmethod
+    def forward(ctx, x_cls, x_aux, target, lam, cls_weight, dense_weight):
+        B, N, C = x_aux.shape
+        ld = ops.round_up(C, 8)
+
+        def padded(x2d):
+            if ld == C and x2d.is_contiguous():
+                return x2d
+            xp = torch.zeros((x2d.shape[0], ld), dtype=BF16, device=x2d.device)
+            xp[:, :C] = x2d
+            return xp
+        aux2d = padded(x_aux.reshape(B * N, C))
+        cls2d = padded(x_cls.reshape(B, C))
+        sb, sc, sn = target.stride()
+        rl_aux, d_aux = ops.soft_ce_fwd_bwd(aux2d, C, target[:, :, 2:], sb, sc, sn, N, dense_weight / (B * N))
+        mixed = lam < 1
+        rl_cls, d_cls = ops.soft_ce_fwd_bwd(cls2d, C, target[:, :, 1], sb, sc, 0, 1, cls_weight / B,
+                                            mix_lam=lam if mixed else 1.0, mix_batches=B if mixed else 0)
+        ctx.save_for_backward(d_cls, d_aux)
+        ctx.dims = (B, N, C)
+        return ops.loss_combine(rl_cls, cls_weight / B, rl_aux, dense_weight / (B * N))
+
+    @staticmethod
+    def backward(ctx, g):
+        d_cls, d_aux = ctx.saved_tensors
+        B, N, C = ctx.dims
+        gs = g.reshape(1).float().contiguous()
+        dc = ops.row_scale(d_cls, gs, d_cls.shape[0])
+        da = ops.row_scale(d_aux, gs, d_aux.shape[0])
+        dc = dc if dc.shape[1] == C else dc[:, :C]
+        da = da if da.shape[1] == C else da[:, :C]
+        return dc, da.reshape(B, N, C), None, None, None, None
+
+
 class OutlookCoreFn(torch.autograd.Function):
     """unfold -> softmax -> attn@v -> fold (models/volo.py:83-98) on v [B,H,W,C], logits [B*h*w, ld]."""
 
@@ -532,9 +629,9 @@ class BNReLUFn(torch.autograd.Function):
         xc, weight, bias, mean, rstd = ctx.saved_tensors
         if not ctx.training:
             raise AutoProgHipError("BNReLUFn backward is implemented for training mode (batch statistics) only")
-        dg = torch.zeros_like(weight)
-        db = torch.zeros_like(bias)
-        dx = ops.bn_relu_bwd(dy.contiguous(), xc, weight, bias, mean, rstd, dg, db)
+        bufs, sunk = _param_grad_buffers((weight, bias))      # with a gradient sink: accumulate straight into param.grad
+        dx = ops.bn_relu_bwd(dy.contiguous(), xc, weight, bias, mean, rstd, bufs[0], bufs[1])
+        dg, db = _finish_param_grads((weight, bias), bufs, sunk)
         return dx, dg, db, None, None, None, None, None
 
 

@@ -60,8 +60,13 @@ class _TokenLabelBase(nn.Module):
         output, aux_output, bb = x
         bbx1, bby1, bbx2, bby2 = bb
         B, N, C = aux_output.shape
-        aux2d = aux_output.reshape(B * N, C).to(torch.bfloat16)
         target = target.float()
+        if target.dim() == 3 and type(self)._adjust_cls is _TokenLabelBase._adjust_cls and target.is_cuda:
+            # the production case (TokenLabelCrossEntropy with token labels): three launches, see functional.TokenLabelCEFn
+            lam = 1 - ((bbx2 - bbx1) * (bby2 - bby1) / N)
+            return AF.TokenLabelCEFn.apply(output.to(torch.bfloat16), aux_output.to(torch.bfloat16), target, float(lam),
+                                           float(self.cls_weight), float(self.dense_weight))
+        aux2d = aux_output.reshape(B * N, C).to(torch.bfloat16)
         if target.dim() == 2:
             target_cls = target
             t = target.contiguous()

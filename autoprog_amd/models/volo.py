@@ -67,13 +67,9 @@ class DropPathRng:
             if len(self._keep_cache) > 64:
                 self._keep_cache.clear()
             k = self._keep_cache[key] = torch.tensor(keeps, dtype=torch.float32, device=device).unsqueeze(1)
-        m = (torch.rand(len(keeps), batch, device=device) + k).floor_()                 # 0/1 keep masks
-        f = m / k
-        tm = None
-        if tokens:
-            row = (batch * tokens + 7) // 8 * 8                        # 16-byte aligned rows
-            tm = torch.zeros(len(keeps), row, dtype=BF16, device=device)
-            tm[:, :batch * tokens] = m.to(BF16).repeat_interleave(tokens, dim=1)
+        from .. import ops
+        # one uniform draw + ONE kernel for the factors, the 0/1 masks and the per-token masks of every site
+        f, m, tm = ops.droppath_masks(torch.rand(len(keeps), batch, device=device), k.reshape(-1), tokens)
         self._pool = [(keeps[i], f[i], m[i], tm[i] if tm is not None else None, tokens) for i in range(len(keeps))]
 
     def draw(self, batch, keep, device, tokens=0):
@@ -264,11 +260,19 @@ class ClassBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
 
+    def forward_split(self, cls, tokens):
+        """class token [B,C] and tokens [B,N,C] kept apart -> updated class token [B,C] (one fused forward / backward pair)"""
+        cls, tokens = _bf16(cls), _bf16(tokens)
+        B, N, C = tokens.shape
+        a, m = self.attn, self.mlp
+        return AF.ClassBlockFn.apply(cls, tokens, self.norm1.weight, self.norm1.bias, a.kv.weight, a.kv.bias, a.q.weight, a.q.bias,
+                                     a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
+                                     m.fc2.weight, m.fc2.bias, B, N, a.num_heads, self.norm1.eps)
+
     def forward_cls(self, x):
         """x [B,1+N,C] -> updated class token [B,1,C]"""
         x = _bf16(x)
-        cls = x[:, :1] + self.attn(AF.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps))
-        return cls + self.mlp(AF.layer_norm(cls, self.norm2.weight, self.norm2.bias, self.norm2.eps))
+        return self.forward_split(x[:, 0], x[:, 1:]).unsqueeze(1)
 
     def forward(self, x):
         return torch.cat([self.forward_cls(x), x[:, 1:]], dim=1)
@@ -335,6 +339,7 @@ class PatchEmbed(nn.Module):
         with torch.autocast("cuda", dtype=BF16, enabled=fused):
             if self.stem_conv:
                 if fused:
+                    counters = []
                     for i in (0, 3, 6):
                         conv, bn = self.conv[i], self.conv[i + 1]
                         x = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
@@ -342,8 +347,10 @@ class PatchEmbed(nn.Module):
                         nhwc = AF.BNReLUFn.apply(x.permute(0, 2, 3, 1), bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                                  self.training, bn.momentum, bn.eps)
                         if self.training and bn.num_batches_tracked is not None:
-                            bn.num_batches_tracked += 1
+                            counters.append(bn.num_batches_tracked)
                         x = nhwc.permute(0, 3, 1, 2)                                    # NCHW view, channels_last strides
+                    if counters:
+                        torch._foreach_add_(counters, 1)                                # one launch for the three counters
                 else:
                     x = self.conv(x)
             x = self.proj(x)
@@ -538,11 +545,12 @@ class VOLO(nn.Module):
         return x.reshape(B, H * W, C)
 
     def forward_cls(self, x):
+        """class blocks on the (class token, tokens) pair without ever concatenating them (models/volo.py:636-642 does)"""
         B = x.shape[0]
-        cls = self.cls_token.expand(B, -1, -1).to(BF16)
+        cls = self.cls_token.to(BF16).reshape(1, -1).expand(B, -1)
         for block in self.post_network:
-            cls = block.forward_cls(torch.cat([cls, x], dim=1))
-        return cls, x
+            cls = block.forward_split(cls, x)
+        return cls.unsqueeze(1), x
 
     def forward(self, x):
         x = self.forward_embeddings(x)

@@ -68,6 +68,19 @@ def resize_bilinear_nhwc(x, size):
     return y
 
 
+def droppath_masks(uniform, keep, tokens=0):
+    """uniform fp32 [sites,B], keep fp32 [sites] -> (factor [sites,B], mask [sites,B], token_mask bf16 [sites,row] or None): one launch"""
+    _req(uniform, torch.float32, "uniform"); _req(keep, torch.float32, "keep")
+    sites, B = uniform.shape
+    factor = torch.empty_like(uniform)
+    mask = torch.empty_like(uniform)
+    row = round_up(B * tokens, 8) if tokens else 0
+    tm = torch.empty((sites, row), dtype=BF16, device=uniform.device) if tokens else None
+    check(lib.ap_droppath_masks(uniform.data_ptr(), keep.data_ptr(), factor.data_ptr(), mask.data_ptr(), tm.data_ptr() if tm is not None else None,
+                                sites, B, int(tokens), row, _stream()), "ap_droppath_masks")
+    return factor, mask, tm
+
+
 # -------------------------------------------------------------------------------- layernorm
 def layernorm_fwd(x, gamma, beta, eps):
     _req(x, BF16, "x"); _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
@@ -234,24 +247,28 @@ def mhsa_bwd(qkv, out, dout, lse, B, N, heads, scale):
     return dqkv
 
 
-def class_attn_fwd(q, kv, B, N, heads, scale):
+def class_attn_fwd(q, kv, B, N, heads, scale, kv_cls=None):
+    """kv_cls given: split layout -- key 0 is kv_cls[b], keys 1..N-1 the N-1 rows of kv (see include/autoprog_hip.h)"""
     _req(q, BF16, "q"); _req(kv, BF16, "kv")
     C = q.shape[-1]
     out = torch.empty((B, C), dtype=BF16, device=q.device)
     probs = torch.empty((B, heads, N), dtype=torch.float32, device=q.device)
-    check(lib.ap_class_attn_fwd(q.data_ptr(), kv.data_ptr(), out.data_ptr(), probs.data_ptr(), B, N, heads, C // heads, float(scale),
-                                _stream()), "ap_class_attn_fwd")
+    check(lib.ap_class_attn_fwd(q.data_ptr(), kv.data_ptr(), kv_cls.data_ptr() if kv_cls is not None else None, out.data_ptr(), probs.data_ptr(),
+                                B, N, heads, C // heads, float(scale), _stream()), "ap_class_attn_fwd")
     return out, probs
 
 
-def class_attn_bwd(q, kv, probs, dout, B, N, heads, scale):
+def class_attn_bwd(q, kv, probs, dout, B, N, heads, scale, kv_cls=None):
+    """-> (dq, dkv) or, in the split layout, (dq, dkv_tokens, dkv_cls)"""
     _req(dout, BF16, "dout")
-    C = q.shape[-1]
     dq = torch.empty_like(q)
     dkv = torch.empty_like(kv)
-    check(lib.ap_class_attn_bwd(q.data_ptr(), kv.data_ptr(), probs.data_ptr(), dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(),
+    dkv_cls = torch.empty_like(kv_cls) if kv_cls is not None else None
+    C = q.shape[-1]
+    check(lib.ap_class_attn_bwd(q.data_ptr(), kv.data_ptr(), kv_cls.data_ptr() if kv_cls is not None else None, probs.data_ptr(), dout.data_ptr(),
+                                dq.data_ptr(), dkv.data_ptr(), dkv_cls.data_ptr() if dkv_cls is not None else None,
                                 B, N, heads, C // heads, float(scale), _stream()), "ap_class_attn_bwd")
-    return dq, dkv
+    return (dq, dkv) if kv_cls is None else (dq, dkv, dkv_cls)
 
 
 # ------------------------------------------------------------------------------ misc fused
@@ -263,8 +280,17 @@ def mix_token_swap(x, r0, r1, c0, c1):
     return y
 
 
-def soft_ce_fwd_bwd(logits, C, target, t_sb, t_sc, t_sn, rows_per_batch, grad_scale):
-    """returns (row_loss fp32 [M], dlogits bf16 like logits)."""
+def loss_combine(a, wa, b=None, wb=0.0):
+    """fp32 scalar tensor wa * sum(a) + wb * sum(b) (one launch)"""
+    _req(a, torch.float32, "a")
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    check(lib.ap_loss_combine(a.data_ptr(), a.numel(), float(wa), b.data_ptr() if b is not None else None, b.numel() if b is not None else 0,
+                              float(wb), out.data_ptr(), _stream()), "ap_loss_combine")
+    return out
+
+
+def soft_ce_fwd_bwd(logits, C, target, t_sb, t_sc, t_sn, rows_per_batch, grad_scale, mix_lam=1.0, mix_batches=0):
+    """returns (row_loss fp32 [M], dlogits bf16 like logits); mix_batches = B: target of batch b is lam*t[b] + (1-lam)*t[B-1-b]."""
     _req(logits, BF16, "logits")
     if not (target.is_cuda and target.dtype == torch.float32):
         raise AutoProgHipError("target must be a CUDA fp32 tensor (any strides; pass them explicitly)")
@@ -272,7 +298,8 @@ def soft_ce_fwd_bwd(logits, C, target, t_sb, t_sc, t_sn, rows_per_batch, grad_sc
     row_loss = torch.empty(M, dtype=torch.float32, device=logits.device)
     dlogits = torch.empty_like(logits)
     check(lib.ap_soft_ce_fwd_bwd(logits.data_ptr(), ldx, target.data_ptr(), int(t_sb), int(t_sc), int(t_sn), int(rows_per_batch),
-                                 row_loss.data_ptr(), dlogits.data_ptr(), float(grad_scale), M, C, _stream()), "ap_soft_ce_fwd_bwd")
+                                 row_loss.data_ptr(), dlogits.data_ptr(), float(grad_scale), M, C, float(mix_lam), int(mix_batches), _stream()),
+          "ap_soft_ce_fwd_bwd")
     return row_loss, dlogits
 
 

@@ -50,6 +50,12 @@ int ap_cast_transpose_f32_bf16(const float* src, ap_bf16* dst, int rows, int col
  * x [B,C,Hi,Wi] fp32 -> y [B,Ho,Wo,C] bf16.  Ho = Hi, Wo = Wi is the plain layout change + cast. */
 int ap_resize_bilinear_nhwc(const float* x, ap_bf16* y, int B, int C, int Hi, int Wi, int Ho, int Wo, ap_stream_t stream);
 
+/* ---- DropPath masks of a whole forward pass (timm DropPath behind models/volo.py:128,218: mask = floor(keep + U), y = x * mask / keep):
+ * uniform [sites,B] in [0,1), keep [sites] -> factor [sites,B] = mask/keep, mask [sites,B] in {0,1}, and (tokens > 0) token_mask
+ * [sites, token_row] bf16 with token_mask[s, b*tokens + t] = mask[s,b], zero padding up to token_row (a multiple of 8 >= B*tokens) */
+int ap_droppath_masks(const float* uniform, const float* keep, float* factor, float* mask, ap_bf16* token_mask, int sites, int B,
+                      int tokens, int token_row, ap_stream_t stream);
+
 /* ---- LayerNorm (nn.LayerNorm: models/volo.py:122,131,213,221,290,297,550) ------------- */
 int ap_layernorm_fwd(const ap_bf16* x, const float* gamma, const float* beta, ap_bf16* y,
                      float* mean, float* rstd, int64_t rows, int C, float eps, ap_stream_t stream);
@@ -135,11 +141,14 @@ int ap_mhsa_bwd(const ap_bf16* qkv, const ap_bf16* out, const ap_bf16* dout, con
                 void* workspace, size_t ws_bytes, ap_stream_t stream);
 
 /* ---- Class attention core (models/volo.py:264-274): one query per image ----------------
- * q [B,C] (un-scaled), kv [B,N,2C] (channel = which*C + head*hd + d), out [B,C], probs [B,heads,N] */
-int ap_class_attn_fwd(const ap_bf16* q, const ap_bf16* kv, ap_bf16* out, float* probs,
+ * q [B,C] (un-scaled), kv [B,N,2C] (channel = which*C + head*hd + d), out [B,C], probs [B,heads,N]; head_dim 32 / 48 / 64.
+ * Split layout (kv_cls != NULL): key 0 -- the class token -- is row b of kv_cls [B,2C] and keys 1..N-1 are the N-1 token rows of
+ * kv [B,N-1,2C]: the reference concatenates the class token with the tokens before every class block (models/volo.py:304-308),
+ * here that copy never happens.  dkv_cls must be given exactly when kv_cls is. */
+int ap_class_attn_fwd(const ap_bf16* q, const ap_bf16* kv, const ap_bf16* kv_cls /*nullable*/, ap_bf16* out, float* probs,
                       int B, int N, int heads, int hd, float scale, ap_stream_t stream);
-int ap_class_attn_bwd(const ap_bf16* q, const ap_bf16* kv, const float* probs, const ap_bf16* dout,
-                      ap_bf16* dq, ap_bf16* dkv, int B, int N, int heads, int hd, float scale,
+int ap_class_attn_bwd(const ap_bf16* q, const ap_bf16* kv, const ap_bf16* kv_cls /*nullable*/, const float* probs, const ap_bf16* dout,
+                      ap_bf16* dq, ap_bf16* dkv, ap_bf16* dkv_cls /*nullable*/, int B, int N, int heads, int hd, float scale,
                       ap_stream_t stream);
 
 /* ---- Mix-token region swap (models/volo.py:654-658, 685-689) ----------------------------
@@ -151,10 +160,16 @@ int ap_mix_token_swap(const ap_bf16* x, ap_bf16* y, int B, int H, int W, int C,
  * logits [M,ldx] (C valid classes); target element (row,c) =
  *   target[(row / rows_per_batch)*t_sb + c*t_sc + (row % rows_per_batch)*t_sn]   (fp32)
  * row_loss[row] = -sum_c t*log_softmax(x);  dlogits = grad_scale*(softmax*sum_c t - t)
- * (columns C..ldx-1 of dlogits are zeroed).                                               */
+ * (columns C..ldx-1 of dlogits are zeroed).
+ * mix_batches = B > 0: the target of batch b is mix_lam * t[b] + (1 - mix_lam) * t[B-1-b] (the mix-token image label,
+ * loss/cross_entropy.py:151-152) -- no mixed copy of the target is materialised; 0: plain.       */
 int ap_soft_ce_fwd_bwd(const ap_bf16* logits, int ldx, const float* target, int64_t t_sb,
                        int64_t t_sc, int64_t t_sn, int rows_per_batch, float* row_loss,
-                       ap_bf16* dlogits, float grad_scale, int64_t M, int C, ap_stream_t stream);
+                       ap_bf16* dlogits, float grad_scale, int64_t M, int C,
+                       float mix_lam, int mix_batches, ap_stream_t stream);
+/* out[0] = wa * sum(a[0:na]) + wb * sum(b[0:nb]): cls_weight * mean(row losses) + dense_weight * mean(row losses)
+ * of the token-label loss (loss/cross_entropy.py:154-156) in one launch */
+int ap_loss_combine(const float* a, int64_t na, float wa, const float* b, int64_t nb, float wb, float* out, ap_stream_t stream);
 
 /* ---- small fused elementwise helpers ---------------------------------------------------- */
 /* y[m,:] = x[m,:] * scale[m / rows_per_scale] */

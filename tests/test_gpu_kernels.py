@@ -354,6 +354,21 @@ def test_resize_bilinear(ops, B, r_in, r_out):
         assert torch.equal(y.cpu(), ref.to(torch.bfloat16))
 
 
+def test_droppath_masks(ops):
+    """all DropPath sites of a forward pass in one launch == timm's floor(keep + U) / keep per site, plus the per-token masks"""
+    g = torch.Generator().manual_seed(0)
+    sites, B, tokens = 5, 7, 13
+    u = torch.rand(sites, B, generator=g)
+    keep = torch.tensor([1.0, 0.9, 0.5, 0.97, 0.3])
+    f, m, tm = ops.droppath_masks(dev(u), dev(keep), tokens)
+    m_ref = torch.floor(keep[:, None] + u)
+    assert torch.equal(m.cpu(), m_ref) and torch.allclose(f.cpu(), m_ref / keep[:, None])
+    assert tm.shape == (sites, 96) and torch.equal(tm[:, :B * tokens].float().cpu(), m_ref.repeat_interleave(tokens, dim=1))
+    assert float(tm[:, B * tokens:].float().abs().sum()) == 0.0
+    f2, m2, none = ops.droppath_masks(dev(u), dev(keep), 0)
+    assert none is None and torch.equal(m2.cpu(), m_ref)
+
+
 def test_errors_are_loud(ops):
     from autoprog_amd._lib import AutoProgHipError
     with pytest.raises(AutoProgHipError):

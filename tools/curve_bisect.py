@@ -30,6 +30,21 @@ def run(mode):
     model = model.cuda().train()
     if mode == "stem32":
         model.patch_embed.compute_dtype = torch.float32
+    if mode in ("oldcls", "oldboth"):                     # the concatenating class-block path (pre-ClassBlockFn)
+        from autoprog_amd import functional as AF
+        from autoprog_amd.models import volo as V
+
+        def block_cls(self, xx):
+            cls = xx[:, :1] + self.attn(AF.layer_norm(xx, self.norm1.weight, self.norm1.bias, self.norm1.eps))
+            return cls + self.mlp(AF.layer_norm(cls, self.norm2.weight, self.norm2.bias, self.norm2.eps))
+
+        def forward_cls(self, xx):
+            B = xx.shape[0]
+            cls = self.cls_token.expand(B, -1, -1).to(torch.bfloat16)
+            for block in self.post_network:
+                cls = block_cls(block, torch.cat([cls, xx], dim=1))
+            return cls, xx
+        V.VOLO.forward_cls = forward_cls
     x = torch.from_numpy(d["x"]).cuda()
     target = torch.from_numpy(d["target"]).cuda()
     decay, no_decay = [], []
@@ -37,6 +52,11 @@ def run(mode):
         (no_decay if (p.dim() == 1 or n.endswith(".bias") or n in ("pos_embed", "cls_token")) else decay).append(p)
     opt = torch.optim.AdamW([{"params": decay, "weight_decay": float(d["wd"])}, {"params": no_decay, "weight_decay": 0.0}], lr=float(d["lr"]))
     loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=classes)
+    if mode in ("oldloss", "oldboth"):                    # the unfused loss path (pre-TokenLabelCEFn)
+        class Unfused(TokenLabelCrossEntropy):
+            def _adjust_cls(self, *a, **k):
+                return super()._adjust_cls(*a, **k)
+        loss_fn = Unfused(dense_weight=0.5, cls_weight=1.0, classes=classes)
     np.random.seed(int(d["np_seed"]))
     losses, errs = [], {}
     for step in range(10):

@@ -13,7 +13,7 @@ dev = torch.device("cuda", 0)
 torch.manual_seed(42); np.random.seed(42)
 model = create_model("model_variant", variant="volo_h12_l18", drop_path_rate=0.1).to(dev).train()
 loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=1000)
-reducer = GradientBucketReducer(list(model.parameters()), world_size=1); reducer.install_sink()
+reducer = GradientBucketReducer(list(model.parameters()), world_size=1); reducer.install_sink(model)
 opt = FlatAdamWEma(model, reducer, lr=1.6e-3, weight_decay=0.05, ema_decays=[0.998, 0.9986, 0.999, 0.9996])
 gen = torch.Generator().manual_seed(42)
 images = torch.randn(128, 3, 224, 224, generator=gen).to(dev)

@@ -359,11 +359,14 @@ def gen_step_curve_init(ns):
     target = make_target(B, classes, (r // 16) ** 2, gen)
     out = {"x": npy(x), "target": npy(target), "np_seed": np.array(123), "lr": np.array(1e-3), "wd": np.array(0.05),
            "init_seed": np.array(seed), "classes": np.array(classes)}
-    for dt, tag in ((torch.float64, ""), (torch.float32, "_fp32"), (torch.float32, "_fp16_autocast")):
+    for dt, tag in ((torch.float64, ""), (torch.float32, "_fp32"), (torch.float32, "_fp16_autocast"),
+                    (torch.float32, "_bf16_autocast")):
         # "_fp16_autocast": the reference model under torch.autocast("cpu", float16) -- the closest thing to its apex-O1 training
         # path that runs here (16-bit GEMM/conv operands, fp32 master weights and loss): the reference's own mixed-precision
         # deviation from its exact curve, recorded as the yardstick for any 16-bit-activation implementation
-        amp = tag == "_fp16_autocast"
+        # "_bf16_autocast": the same under torch.autocast("cpu", bfloat16) -- the reference's own network in the arithmetic class
+        # of the HIP path (bf16 operands, fp32 accumulation): how far bf16 rounding alone moves THIS curve
+        amp = {"_fp16_autocast": torch.float16, "_bf16_autocast": torch.bfloat16}.get(tag)
         net = tiny_volo(ns, "volo_h4_l6", r, classes).train()
         net.load_state_dict(init_state_dict(net.state_dict(), seed), strict=True)
         net = net.to(dt)
@@ -377,7 +380,7 @@ def gen_step_curve_init(ns):
         g0 = None
         for step in range(10):
             if amp:
-                with torch.autocast("cpu", dtype=torch.float16):
+                with torch.autocast("cpu", dtype=amp):
                     outp = net(x)
                 outp = (outp[0].float(), outp[1].float(), outp[2])
             else:
