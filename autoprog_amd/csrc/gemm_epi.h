@@ -13,7 +13,10 @@ struct EpiArgs {
 // epilogue of 8 consecutive output columns [n, n+8) of row m held in v[] (fp32 accumulators):
 // +bias; GELU (storing the pre-activation); * gelu'(h); * DropPath row scale; + residual; bf16 store.
 // All global accesses are 16-byte when the chunk is complete and the leading dimensions allow it.
-__device__ __forceinline__ void epi_chunk(float* v, int m, int n, int N, int ldc, bool vec_ok, const EpiArgs& ep, bf16_t* __restrict__ C) {
+// `pre` (used when has_pre): the chunk's 16 bytes of ep.dgelu_of -- or, when that is null, of ep.residual -- already loaded by the
+// caller (k_gemm_nt issues these loads under its last K step so that their latency is hidden behind the MFMAs).
+__device__ __forceinline__ void epi_chunk(float* v, int m, int n, int N, int ldc, bool vec_ok, const EpiArgs& ep, bf16_t* __restrict__ C,
+                                          u32x4 pre = u32x4{0u, 0u, 0u, 0u}, bool has_pre = false) {
     const int nval = min(8, N - n);
     const bool full = (nval == 8) && vec_ok;
     if (ep.bias) {
@@ -44,7 +47,8 @@ __device__ __forceinline__ void epi_chunk(float* v, int m, int n, int N, int ldc
     if (ep.dgelu_of) {
         const bf16_t* hp = ep.dgelu_of + (int64_t)m * ldc + n;
         float h[8];
-        if (full) unpack8(ld16(hp), h);
+        if (has_pre) unpack8(pre, h);
+        else if (full) unpack8(ld16(hp), h);
         else {
 #pragma unroll
             for (int q = 0; q < 8; ++q) h[q] = (q < nval) ? bf2f(hp[q]) : 0.f;
@@ -60,7 +64,8 @@ __device__ __forceinline__ void epi_chunk(float* v, int m, int n, int N, int ldc
     if (ep.residual) {
         const bf16_t* rp = ep.residual + (int64_t)m * ep.ldr + n;
         float h[8];
-        if (full) unpack8(ld16(rp), h);
+        if (has_pre && !ep.dgelu_of) unpack8(pre, h);
+        else if (full) unpack8(ld16(rp), h);
         else {
 #pragma unroll
             for (int q = 0; q < 8; ++q) h[q] = (q < nval) ? bf2f(rp[q]) : 0.f;
