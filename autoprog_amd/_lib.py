@@ -63,6 +63,12 @@ _SIGNATURES = {
     "ap_adamw_ema_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, POINTER(c_void_p), POINTER(c_float), _I, _P, _P]),
     "ap_batched_transpose_bf16": (_I, [_P, _P, _P, _I, _I, _P]),
 }
+_SIGNATURES["ap_bn_relu_fwd_partials"] = (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P])
+_SIGNATURES["ap_conv3x3_c64_stat_rows"] = (_I, [_I, _I, _I])
+_SIGNATURES["ap_conv3x3_c64_pack"] = (_I, [_P, _P, _P, _P])
+_SIGNATURES["ap_conv3x3_c64"] = (_I, [_P, _P, _P, _I, _I, _I, _P, _P])
+_SIGNATURES["ap_conv3x3_c64_wgrad_workspace"] = (ctypes.c_size_t, [_I, _I, _I])
+_SIGNATURES["ap_conv3x3_c64_wgrad"] = (_I, [_P, _P, _P, _I, _I, _I, _P, ctypes.c_size_t, _P])
 # ap_sum_reps_acc(x, out, n, reps, stream)
 _SIGNATURES["ap_sum_reps_acc"] = (_I, [_P, _P, _L, _I, _P])
 

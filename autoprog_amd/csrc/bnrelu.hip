@@ -220,6 +220,18 @@ int ap_bn_relu_fwd(const ap_bf16* x, const float* gamma, const float* beta, floa
     return ap_check_launch();
 }
 
+int ap_bn_relu_fwd_partials(const ap_bf16* x, const float* partial, int n_partial, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, ap_bf16* y, float* mean, float* rstd,
+                            int64_t T, int C, ap_stream_t stream) {
+    if (!x || !partial || !gamma || !beta || !y || !mean || !rstd) return AP_ERR_NULL;
+    if (!bn_shape_ok(C) || T <= 0 || n_partial <= 0) return AP_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(BN_BLOCK), 0, s, partial, n_partial, T, C, eps, momentum, mean, rstd, running_mean, running_var);
+    hipLaunchKernelGGL(k_bn_relu_apply, dim3(bn_grid(T, C)), dim3(BN_BLOCK), 0, s, x, mean, rstd, gamma, beta, y, T, C);
+    return ap_check_launch();
+}
+
 int ap_bn_relu_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* beta, const float* mean,
                    const float* rstd, ap_bf16* dx, float* dgamma, float* dbeta, int64_t T, int C,
                    void* workspace, size_t ws_bytes, ap_stream_t stream) {

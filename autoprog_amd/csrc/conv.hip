@@ -1,0 +1,479 @@
+// 3x3 / stride 1 / pad 1 convolution of the VOLO stem on NHWC bf16 feature maps with 64 channels in and out
+// (reference models/volo.py:355-367: the two `nn.Conv2d(hidden, hidden, 3, 1, 1, bias=False)` of PatchEmbed), forward,
+// input gradient (the same kernel on flipped / transposed weights) and weight gradient.
+//
+// Forward is an implicit GEMM: M = B*H*W pixels, N = 64 output channels, K = 9 taps x 64 input channels, with NO im2col
+// buffer -- a tap is an address offset into the input patch held in LDS.
+//   workgroup   : 256 threads (4 waves), PERSISTENT over the 32 x 16 pixel output tiles of the batch
+//   LDS         : all 9 x 64 x 64 weights (72 KB, loaded once per workgroup) + the 34 x 18 pixel input patch of the
+//                 current tile (76.5 KB); 16-byte chunks XOR-swizzled so that the MFMA fragment reads are conflict free
+//   wave        : tile rows w, w+4, ... (8 rows of 16 pixels) x all 64 output channels: 8 x 4 accumulator tiles; per
+//                 (tap, 32-channel K step) it reads 4 weight fragments + 8 pixel fragments for 32 MFMAs (96 B/clk of LDS
+//                 traffic per CU at full MFMA rate, against a 128 B/clk LDS)
+//   pipelining  : the next tile's patch is loaded into registers (20 x 16 B per thread) before the current tile is
+//                 computed and written to LDS after it -- one workgroup per CU, so the overlap is within the workgroup
+// HBM traffic: input 1.22x (tile halo), output 1x; 118 GFLOP per D1 call (B = 128, 112 x 112) = 47 us at the dense bf16 peak,
+// 70 us at 6 TB/s: the kernel is bound by neither until the MFMA issue rate of 4 waves per CU is reached.
+#include "common.h"
+#include "gemm_epi.h"
+#include <cstdlib>
+#include <type_traits>
+
+#define CV_C 64
+#define CV_TR 32                  // tile rows
+#define CV_TW 16                  // tile columns (one MFMA fragment of 16 pixels per row)
+#define CV_PH (CV_TR + 2)
+#define CV_PW (CV_TW + 2)
+#define CV_NPIX (CV_PH * CV_PW)                       // 612 patch pixels
+#define CV_NCHUNK (CV_NPIX * 8)                       // 16-byte chunks of the patch
+#define CV_NPRE ((CV_NCHUNK + 255) / 256)             // chunks per thread (20)
+#define CV_WELEMS (9 * CV_C * CV_C)
+#define CV_PSTR 72                                    // patch pixel stride in elements: 64 channels + 16 B of padding -- consecutive pixels start
+                                                      // 4 banks apart, so the 8 lanes of a ds_read_b128 group cover all 32 banks, and a tap is a
+                                                      // CONSTANT byte offset (an XOR swizzle keyed on the pixel would need address math per tap)
+#define CV_LDS_BYTES ((CV_WELEMS + CV_NPIX * CV_PSTR) * 2)
+
+// fp32 OIHW [64][64][3][3] -> bf16 [tap][co][ci] (forward) and [tap'][ci][co] with the taps flipped (input gradient:
+// dx = conv3x3(dy, W^T flipped)); one thread per weight
+__global__ void __launch_bounds__(256)
+k_conv3x3_pack(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __restrict__ wb) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= CV_WELEMS) return;
+    const int tap = idx % 9, ci = (idx / 9) % CV_C, co = idx / (9 * CV_C);
+    const bf16_t v = f2bf(w[idx]);
+    wf[(tap * CV_C + co) * CV_C + ci] = v;
+    wb[((8 - tap) * CV_C + ci) * CV_C + co] = v;
+}
+
+// STATS: every workgroup also stores the per-channel sum / sum of squares of its (bf16-rounded) outputs to stats[blockIdx.x][2][64]
+// -- the partial sums of the BatchNorm that follows (models/volo.py:356-366), in the layout k_bn_finalize reads.
+//
+// Per tile the wave runs 18 fenced steps (9 taps x 2 K halves) of 32 MFMAs.  Everything else rides in their shadow: step s
+// reads the fragments of step s+1 from LDS, issues the global load of chunk s of the NEXT tile's patch (20 chunks per thread)
+// and stores chunk s of the PREVIOUS tile's output (16 chunks per thread, kept packed in registers) -- with one workgroup per
+// CU, a load phase, a compute phase and a store phase of their own would run one after the other on every CU at once
+// (measured: 151 us with the phases apart, 84 us for the MFMAs alone).
+template <bool STATS, int ABL = 0>
+__global__ void __launch_bounds__(256)
+k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_t* __restrict__ y, int H, int W,
+              int tiles_x, int tiles_y, int ntiles, float* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t cv_smem[];
+    bf16_t* Wl = cv_smem;                       // [9][64 co][64 ci], chunk ^ key_b(co)
+    bf16_t* P = cv_smem + CV_WELEMS;            // [612 px][64 ci + 8 pad]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // per-lane element offsets of the MFMA fragments: pixel (row wave, column fr) chunk g of the patch; weight row r(q, fr) chunk g / 4 + g
+    const int abase = (wave * CV_PW + fr) * CV_PSTR + g * 8;
+    int wbase[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 32 * (q >> 1) + 8 * (fr >> 2) + 4 * (q & 1) + (fr & 3);       // N-permuted rows: see gemm.hip "direct epilogue"
+        wbase[q][0] = r * CV_C + ((g ^ key_b(r)) << 3);
+        wbase[q][1] = r * CV_C + (((4 + g) ^ key_b(r)) << 3);
+    }
+    for (int idx = tid; idx < CV_WELEMS / 8; idx += 256) {
+        const int row = idx >> 3, c = idx & 7;
+        st16(Wl + row * CV_C + ((c ^ key_b(row & (CV_C - 1))) << 3), ld16(wp + (int64_t)idx * 8));
+    }
+
+    auto tile_origin = [&](int t, int& b, int& ty0, int& tx0) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
+        b = t / (tiles_x * tiles_y); ty0 = ty * CV_TR; tx0 = tx * CV_TW;
+    };
+    // patch chunk i of this thread: pixel (tid >> 3) + 32 i, chunk tid & 7 -- its position in the patch is the same for every
+    // tile: one packed (py, px) word per chunk
+    u32x4 pre[CV_NPRE];
+    const int c8 = (tid & 7) * 8;
+    int tl = tid >> 3;                           // laundered once per tile: keeps the 20 per-chunk offsets from being hoisted out of the
+                                                 // tile loop into 20 registers held for the whole kernel (they are 3 VALU each)
+    // The load is UNCONDITIONAL (halo pixels outside the image read a clamped, valid address) and the zero padding is applied
+    // when the chunk is written to LDS: a predicated load (zero-initialise, then an exec-masked load into the same registers)
+    // made the compiler drain vmcnt(0) in every step.
+    auto pvalid = [&](int i, int ty0, int tx0) {
+        const int pix = tl + 32 * i;                                 // < 640
+        const int py = (pix * 3641) >> 16, px = pix - py * CV_PW;    // pix / 18 (exact below 1170)
+        const unsigned gy = (unsigned)(ty0 - 1 + py), gx = (unsigned)(tx0 - 1 + px);
+        return pix < CV_NPIX && gy < (unsigned)H && gx < (unsigned)W;
+    };
+    auto gload1 = [&](int i, const bf16_t* img, int ty0, int tx0) {
+        const int pix = tl + 32 * i;
+        const int py = (pix * 3641) >> 16, px = pix - py * CV_PW;
+        const int gy = min(max(ty0 - 1 + py, 0), H - 1), gx = min(max(tx0 - 1 + px, 0), W - 1);
+        pre[i] = ld16(img + (unsigned)((gy * W + gx) * CV_C + c8));  // uniform base + 32-bit lane offset
+    };
+    auto patch_org = [&](int b, int ty0, int tx0) { return x + (int64_t)b * H * W * CV_C; };
+    float ssum[2][8], ssq[2][8];                 // STATS: this lane's channels 32 pr + 8 g .. +7
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ssum[pr][k] = 0.f; ssq[pr][k] = 0.f; }
+
+    u32x4 outp[16];                              // the previous tile's output, packed bf16: chunk 2 i + pr
+    const bf16_t* out_prev = nullptr;            // UNIFORM: the previous tile's first pixel; null: nothing pending
+    int nrow_prev = 0;
+    bool col_ok_prev = false;
+    const unsigned out_lane = (unsigned)((wave * W + fr) * CV_C + 8 * g);       // this lane's pixel (row wave, column fr), channel 8 g
+    auto store1 = [&](int s) {                   // chunk s = 2 i + pr of the pending output
+        const int i = s >> 1, pr = s & 1;
+        if (out_prev != nullptr && i < nrow_prev && col_ok_prev && (!(ABL & 1) || outp[s][0] == 0x12345678u))
+            st16(const_cast<bf16_t*>(out_prev) + ((int64_t)(4 * i) * W * CV_C + 32 * pr) + out_lane, outp[s]);
+    };
+
+    int t = blockIdx.x;
+    if (t < ntiles) {
+        int b, ty0, tx0;
+        tile_origin(t, b, ty0, tx0);
+        const bf16_t* org = patch_org(b, ty0, tx0);
+#pragma unroll
+        for (int i = 0; i < CV_NPRE; ++i) gload1(i, org, ty0, tx0);
+    }
+    for (; t < ntiles; t += gridDim.x) {
+        int bc, ty0c, tx0c;
+        tile_origin(t, bc, ty0c, tx0c);
+#pragma unroll
+        for (int i = 0; i < CV_NPRE; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < CV_NCHUNK && (!(ABL & 2) || t == (int)blockIdx.x))
+                st16(P + ((tid >> 3) + 32 * i) * CV_PSTR + c8, pvalid(i, ty0c, tx0c) ? pre[i] : zero4);
+        }
+        __syncthreads();
+        asm volatile("" : "+v"(tl));
+        const int tn = t + gridDim.x;
+        const bool have_next = !(ABL & 2) && tn < ntiles;
+        int bn = 0, ty0n = 0, tx0n = 0;
+        if (have_next) tile_origin(tn, bn, ty0n, tx0n);
+        const bf16_t* orgn = patch_org(bn, ty0n, tx0n);
+
+        int b, ty0, tx0;
+        tile_origin(t, b, ty0, tx0);
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // rows of this wave: r = wave + 4 i; rows below the image are skipped (wave-uniform)
+        const int nrow = (H - ty0 - wave + 3) >> 2;                   // number of i with ty0 + wave + 4 i < H
+        // fragments of one step: 4 weight fragments (double-buffered by hand) + 8 pixel fragments, each refilled for the next step
+        // right behind the 4 MFMAs that read it (one wave per SIMD -- nothing else hides the LDS latency).  Kept as u32x4: bf16x8
+        // values crossing the pipeline stages get legalised element-wise.  Every LDS address is a per-lane base + a constant.
+        auto bload = [&](u32x4* fb, int s) {
+            if ((ABL & 4) && s) return;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fb[q] = ld16(Wl + wbase[q][s & 1] + (s >> 1) * CV_C * CV_C);
+        };
+        auto aload = [&](u32x4& fa, int i, int s) {
+            if ((ABL & 4) && s) return;
+            const int tap = s >> 1, dy = tap / 3, dx = tap - 3 * dy;
+            fa = ld16(P + abase + (4 * i + dy) * CV_PW * CV_PSTR + dx * CV_PSTR + (s & 1) * 32);
+        };
+        // the memory work of step s.  Program order: the previous tile's 16 output chunks first (steps 0-3), then the 20 chunk
+        // loads of the next tile (steps 4-8): vmcnt counts loads and stores in one in-order counter, so the wait for the loads at
+        // the top of the next tile also covers everything issued before them -- stores issued AFTER a load would sit in front of
+        // that wait -- and the last load still has ten steps (~3 us) to land.  (One load + one store in every step: 200 us.)
+        auto side = [&](int s) {
+            if (s < 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) store1(4 * s + k);
+            } else if (s < 9 && have_next) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gload1(4 * (s - 4) + k, orgn, ty0n, tx0n);
+            }
+        };
+        auto compute = [&](auto full) {
+            u32x4 fb[2][4], fa[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = zero4;
+            bload(fb[0], 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (full.value || i < nrow) aload(fa[i], i, 0);
+#pragma unroll
+            for (int s = 0; s < 18; ++s) {
+                if (s + 1 < 18) bload(fb[(s + 1) & 1], s + 1);
+                side(s);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (full.value || i < nrow) {
+                        if (!(ABL & 8)) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(fb[s & 1][q]), as_bf16x8(fa[i]), acc[i][q], 0, 0, 0);
+                        }
+                        if (s + 1 < 18) aload(fa[i], i, s + 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);            // keep the hand-made pipeline: without fences the scheduler hoists
+            }                                                 // dozens of LDS reads and spills (516 us instead of 170)
+        };
+        if (nrow >= 8) compute(std::true_type{}); else compute(std::false_type{});
+        // pack: lane (fr, g) holds, per fragment pair pr, channels 32 pr + 8 g .. +7 of pixel (row ty0 + wave + 4 i, column tx0 + fr)
+        out_prev = y + (((int64_t)b * H + ty0) * W + tx0) * CV_C;
+        nrow_prev = nrow;
+        col_ok_prev = tx0 + fr < W;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                float v[8];
+                v[0] = acc[i][2 * pr][0]; v[1] = acc[i][2 * pr][1]; v[2] = acc[i][2 * pr][2]; v[3] = acc[i][2 * pr][3];
+                v[4] = acc[i][2 * pr + 1][0]; v[5] = acc[i][2 * pr + 1][1]; v[6] = acc[i][2 * pr + 1][2]; v[7] = acc[i][2 * pr + 1][3];
+                outp[2 * i + pr] = pack8(v);
+                if constexpr (STATS) {
+                    if (i < nrow && col_ok_prev) {
+                        float r8[8];
+                        unpack8(outp[2 * i + pr], r8);        // statistics of what is stored (the BatchNorm input is the bf16 tensor)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { ssum[pr][k] += r8[k]; ssq[pr][k] += r8[k] * r8[k]; }
+                    }
+                }
+            }
+        }
+        __syncthreads();                       // every wave is done with the patch before the next one overwrites it
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) store1(s);    // the last tile's output
+    if constexpr (STATS) {
+        // lanes with the same g hold the same channels: butterfly over fr, then the 4 waves meet in LDS (the patch is free)
+        float* red = reinterpret_cast<float*>(P);                    // [4 waves][2][64]
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { ssum[pr][k] += __shfl_xor(ssum[pr][k], o, 64); ssq[pr][k] += __shfl_xor(ssq[pr][k], o, 64); }
+            }
+        if (fr == 0) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    red[(wave * 2 + 0) * CV_C + 32 * pr + 8 * g + k] = ssum[pr][k];
+                    red[(wave * 2 + 1) * CV_C + 32 * pr + 8 * g + k] = ssq[pr][k];
+                }
+        }
+        __syncthreads();
+        if (tid < 2 * CV_C)                    // this workgroup's partial row [2][64]: plain store, summed (in fp64) by the BatchNorm finalize
+            stats[(int64_t)blockIdx.x * 2 * CV_C + tid] = red[tid] + red[2 * CV_C + tid] + red[4 * CV_C + tid] + red[6 * CV_C + tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[co][ci][ky][kx] = sum over pixels of dy[p][co] * x[p + (ky-1, kx-1)][ci]  (zero padding).  Per tap a 64 x 64 matrix product
+// whose reduction axis is the PIXEL axis -- the slow axis of both NHWC operands -- so the MFMA fragments are fetched with
+// ds_read_b64_tr_b16 (hardware transpose) from pixel-major LDS images, as in k_gemm_tn.
+//   workgroup : 256 threads, persistent over 16 x 16 pixel tiles; LDS = dy tile (32 KB) + 18 x 18 input patch (40.5 KB): two
+//               workgroups per CU, whose load and compute phases overlap each other
+//   wave w    : input channels 16 w .. 16 w + 15, ALL 64 output channels, ALL 9 taps: 9 x 4 accumulator tiles (144 registers).
+//               Per 32-pixel K step: 4 dy^T fragments (shared by the taps) + 9 shifted input fragments for 36 MFMAs.
+//   swizzle   : 16-byte chunk ^ key(column) -- a function of the pixel COLUMN only, so that a tap (dy: a row shift, dx: three
+//               columns per lane) and a K step (two rows) are constant byte offsets from six per-lane bases
+//   output    : every workgroup STORES its partial 9 x 64 x 64 sums to its own slab; k_conv3x3_wgrad_reduce adds the slabs in
+//               order into dW (fp32 OIHW, +=): no atomics, bit-reproducible
+#define CW_T 16
+#define CW_PW (CW_T + 2)
+#define CW_DPIX (CW_T * CW_T)
+#define CW_APIX (CW_PW * CW_PW)
+#define CW_LDS_BYTES ((CW_DPIX + CW_APIX) * CV_C * 2)
+#define CW_ND (CW_DPIX * 8 / 256)                     // dy chunks per thread (8)
+#define CW_NA ((CW_APIX * 8 + 255) / 256)             // patch chunks per thread (11)
+__device__ __forceinline__ int cw_key(int col) { return (((col >> 1) & 1) << 1) | (((col >> 3) & 1) << 2); }
+
+__global__ void __launch_bounds__(256, 2)
+k_conv3x3_c64_wgrad(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ slab, int H, int W,
+                    int tiles_x, int tiles_y, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t cw_smem[];
+    bf16_t* D = cw_smem;                        // [256 px][64 co]
+    bf16_t* A = cw_smem + CW_DPIX * CV_C;       // [324 px][64 ci]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4, q = fr >> 2, p = fr & 3;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const int c8 = (tid & 7) * 8, cidx = tid & 7;
+
+    // per-lane fragment bases (elements).  Lane (g, q, p) addresses 4 channels (8 B) of pixel row g >> 1, column 8 (g & 1) + q (+4 for
+    // the second read of a fragment) of the current two-row K step; the transpose hands lane i = 4 q + p channel i of the tile.
+    int dbase[4][2], abase[3][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int col = 8 * (g & 1) + q + 4 * hf;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            dbase[t][hf] = ((g >> 1) * CW_T + col) * CV_C + (((2 * t + (p >> 1)) ^ cw_key(col)) << 3) + (p & 1) * 4;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int pc = col + dx;
+            abase[dx][hf] = ((g >> 1) * CW_PW + pc) * CV_C + (((2 * wave + (p >> 1)) ^ cw_key(pc)) << 3) + (p & 1) * 4;
+        }
+    }
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    auto trfrag = [&](const bf16_t* base0, const bf16_t* base1) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base1));
+        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+        const int ty0 = ty * CW_T, tx0 = tx * CW_T;
+        const bf16_t* ximg = x + (int64_t)b * H * W * CV_C;
+        const bf16_t* dimg = dy + (int64_t)b * H * W * CV_C;
+        // two batches (dy tile, then input patch) of unconditional loads at clamped addresses; pixels outside the image become
+        // zeros on the way into LDS.  (One batch of all 19 chunks on top of the 144 accumulators spills.)
+        {
+            u32x4 rd[CW_ND];
+#pragma unroll
+            for (int i = 0; i < CW_ND; ++i) {
+                const int px = (tid >> 3) + 32 * i, r = px >> 4, c = px & 15;
+                const int gy = min(ty0 + r, H - 1), gx = min(tx0 + c, W - 1);
+                rd[i] = ld16(dimg + (unsigned)((gy * W + gx) * CV_C + c8));
+            }
+#pragma unroll
+            for (int i = 0; i < CW_ND; ++i) {
+                const int px = (tid >> 3) + 32 * i, r = px >> 4, c = px & 15;
+                const bool ok = (ty0 + r < H) && (tx0 + c < W);
+                st16(D + px * CV_C + ((cidx ^ cw_key(c)) << 3), ok ? rd[i] : zero4);
+            }
+        }
+        {
+            u32x4 ra[CW_NA];
+#pragma unroll
+            for (int i = 0; i < CW_NA; ++i) {
+                const int px = min((tid >> 3) + 32 * i, CW_APIX - 1), r = px / CW_PW, c = px - r * CW_PW;
+                const int gy = min(max(ty0 - 1 + r, 0), H - 1), gx = min(max(tx0 - 1 + c, 0), W - 1);
+                ra[i] = ld16(ximg + (unsigned)((gy * W + gx) * CV_C + c8));
+            }
+#pragma unroll
+            for (int i = 0; i < CW_NA; ++i) {
+                const int px = (tid >> 3) + 32 * i, r = px / CW_PW, c = px - r * CW_PW;
+                const unsigned gy = (unsigned)(ty0 - 1 + r), gx = (unsigned)(tx0 - 1 + c);
+                if (px < CW_APIX) st16(A + px * CV_C + ((cidx ^ cw_key(c)) << 3), (gy < (unsigned)H && gx < (unsigned)W) ? ra[i] : zero4);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CW_T / 2; ++k) {                 // K step: tile rows 2k, 2k+1 (32 pixels)
+            bf16x8 df[4];
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) df[tq] = trfrag(D + dbase[tq][0] + 2 * k * CW_T * CV_C, D + dbase[tq][1] + 2 * k * CW_T * CV_C);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dyy = tap / 3, dxx = tap - 3 * dyy;
+                const bf16x8 af = trfrag(A + abase[dxx][0] + (2 * k + dyy) * CW_PW * CV_C, A + abase[dxx][1] + (2 * k + dyy) * CW_PW * CV_C);
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) acc[tap][tq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[tq], af, acc[tap][tq], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    // partial sums: slab[wg][tap][co][ci]; lane holds co = 16 tq + 4 g + r, ci = 16 wave + fr
+    float* mine = slab + (int64_t)blockIdx.x * CV_WELEMS;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                mine[(tap * CV_C + 16 * tq + 4 * g + r) * CV_C + 16 * wave + fr] = acc[tap][tq][r];
+}
+
+// dW[co][ci][tap] (fp32 OIHW) += sum over the workgroup slabs, in slab order
+__global__ void __launch_bounds__(256)
+k_conv3x3_wgrad_reduce(const float* __restrict__ slab, int nslab, float* __restrict__ dw) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // slab element (tap, co, ci)
+    if (idx >= CV_WELEMS) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = 0;
+    for (; w + 3 < nslab; w += 4) {
+        s0 += slab[(int64_t)w * CV_WELEMS + idx]; s1 += slab[(int64_t)(w + 1) * CV_WELEMS + idx];
+        s2 += slab[(int64_t)(w + 2) * CV_WELEMS + idx]; s3 += slab[(int64_t)(w + 3) * CV_WELEMS + idx];
+    }
+    for (; w < nslab; ++w) s0 += slab[(int64_t)w * CV_WELEMS + idx];
+    const int ci = idx % CV_C, co = (idx / CV_C) % CV_C, tap = idx / (CV_C * CV_C);
+    dw[(co * CV_C + ci) * 9 + tap] += (s0 + s1) + (s2 + s3);
+}
+
+extern "C" {
+
+int ap_conv3x3_c64_pack(const float* w_oihw, ap_bf16* w_fwd, ap_bf16* w_bwd, ap_stream_t stream) {
+    if (!w_oihw || !w_fwd || !w_bwd) return AP_ERR_NULL;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_conv3x3_pack, dim3((CV_WELEMS + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, w_fwd, w_bwd);
+    return ap_check_launch();
+}
+
+static int cv_grid(int ntiles) {
+    static int grid_cap = 0;
+    if (grid_cap == 0) { const char* e = getenv("AP_CONV_GRID"); grid_cap = e ? atoi(e) : 256; if (grid_cap < 1) grid_cap = 256; }
+    return ntiles < grid_cap ? ntiles : grid_cap;
+}
+
+int ap_conv3x3_c64_stat_rows(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const int64_t nt = (int64_t)B * ((W + CV_TW - 1) / CV_TW) * ((H + CV_TR - 1) / CV_TR);
+    return cv_grid((int)(nt > 0x7fffffff ? 0x7fffffff : nt));
+}
+
+int ap_conv3x3_c64(const ap_bf16* x, const ap_bf16* w_packed, ap_bf16* y, int B, int H, int W, float* stats, ap_stream_t stream) {
+    if (!x || !w_packed || !y) return AP_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return AP_ERR_SHAPE;
+    const int tiles_x = (W + CV_TW - 1) / CV_TW, tiles_y = (H + CV_TR - 1) / CV_TR;
+    const int64_t nt64 = (int64_t)B * tiles_x * tiles_y;
+    if (nt64 > 0x7fffffff) return AP_ERR_SHAPE;
+    const int ntiles = (int)nt64;
+    static int attr_done = 0;
+    (void)hipGetLastError();
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES) != hipSuccess) return AP_ERR_LAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES) != hipSuccess) return AP_ERR_LAUNCH;
+        attr_done = 1;
+    }
+    const int grid = cv_grid(ntiles);
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("AP_CONV_ABL"); abl = e ? atoi(e) : 0; }
+#define CV_ABL_LAUNCH(A) case A: hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64<false, A>), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES); \
+        hipLaunchKernelGGL((k_conv3x3_c64<false, A>), dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats); return ap_check_launch();
+    switch (abl) { CV_ABL_LAUNCH(1) CV_ABL_LAUNCH(2) CV_ABL_LAUNCH(3) CV_ABL_LAUNCH(4) CV_ABL_LAUNCH(7) CV_ABL_LAUNCH(8) CV_ABL_LAUNCH(11) default: break; }
+    if (stats) hipLaunchKernelGGL((k_conv3x3_c64<true>), dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats);
+    else hipLaunchKernelGGL((k_conv3x3_c64<false>), dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats);
+    return ap_check_launch();
+}
+
+static int cw_grid(int ntiles) {
+    static int cap = 0;
+    if (cap == 0) { const char* e = getenv("AP_CONV_WGRAD_GRID"); cap = e ? atoi(e) : 512; if (cap < 1) cap = 512; }
+    return ntiles < cap ? ntiles : cap;
+}
+
+size_t ap_conv3x3_c64_wgrad_workspace(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const int64_t nt = (int64_t)B * ((W + CW_T - 1) / CW_T) * ((H + CW_T - 1) / CW_T);
+    return (size_t)cw_grid((int)(nt > 0x7fffffff ? 0x7fffffff : nt)) * CV_WELEMS * sizeof(float);
+}
+
+int ap_conv3x3_c64_wgrad(const ap_bf16* x, const ap_bf16* dy, float* dw_oihw, int B, int H, int W, void* workspace, size_t ws_bytes,
+                         ap_stream_t stream) {
+    if (!x || !dy || !dw_oihw || !workspace) return AP_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return AP_ERR_SHAPE;
+    const int tiles_x = (W + CW_T - 1) / CW_T, tiles_y = (H + CW_T - 1) / CW_T;
+    const int64_t nt64 = (int64_t)B * tiles_x * tiles_y;
+    if (nt64 > 0x7fffffff) return AP_ERR_SHAPE;
+    if (ws_bytes < ap_conv3x3_c64_wgrad_workspace(B, H, W)) return AP_ERR_SHAPE;
+    const int ntiles = (int)nt64, grid = cw_grid(ntiles);
+    static int attr_done = 0;
+    (void)hipGetLastError();
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES) != hipSuccess) return AP_ERR_LAUNCH;
+        attr_done = 1;
+    }
+    hipLaunchKernelGGL(k_conv3x3_c64_wgrad, dim3(grid), dim3(256), CW_LDS_BYTES, (hipStream_t)stream, x, dy, static_cast<float*>(workspace), H, W, tiles_x, tiles_y, ntiles);
+    int rc = ap_check_launch();
+    if (rc != AP_OK) return rc;
+    hipLaunchKernelGGL(k_conv3x3_wgrad_reduce, dim3((CV_WELEMS + 255) / 256), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(workspace), grid, dw_oihw);
+    return ap_check_launch();
+}
+
+}  // extern "C"

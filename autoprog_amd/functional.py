@@ -635,6 +635,39 @@ class BNReLUFn(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None
 
 
+class Conv3x3BNReLUFn(torch.autograd.Function):
+    """conv3x3(64 -> 64, stride 1, pad 1, no bias) -> BatchNorm2d -> ReLU on an NHWC bf16 tensor: the second and third triple of the
+    VOLO stem (models/volo.py:359-366) on the HIP convolution kernels of csrc/conv.hip.  The convolution's epilogue also produces the
+    partial batch statistics, so BatchNorm reads the convolution output once (apply) instead of twice (statistics + apply)."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, weight, bias, running_mean, running_var, training, momentum, eps):
+        xc = x.contiguous()
+        wf, wb = ops.conv3x3_pack(conv_w.detach().float().contiguous())
+        if training:
+            z, partials = ops.conv3x3_c64(xc, wf, True)
+            y, mean, rstd = ops.bn_relu_fwd(z, weight, bias, running_mean, running_var, True, momentum, eps, partials=partials)
+        else:
+            z = ops.conv3x3_c64(xc, wf)
+            y, mean, rstd = ops.bn_relu_fwd(z, weight, bias, running_mean, running_var, False, momentum, eps)
+        ctx.save_for_backward(xc, z, wb, conv_w, weight, bias, mean, rstd)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, z, wb, conv_w, weight, bias, mean, rstd = ctx.saved_tensors
+        if not ctx.training:
+            raise AutoProgHipError("Conv3x3BNReLUFn backward is implemented for training mode (batch statistics) only")
+        params = (conv_w, weight, bias)
+        bufs, sunk = _param_grad_buffers(params)
+        dz = ops.bn_relu_bwd(dy.contiguous(), z, weight, bias, mean, rstd, bufs[1], bufs[2])
+        dx = ops.conv3x3_c64(dz, wb) if ctx.needs_input_grad[0] else None
+        ops.conv3x3_c64_wgrad(xc, dz, bufs[0])
+        dw, dg, db = _finish_param_grads(params, bufs, sunk)
+        return dx, dw, dg, db, None, None, None, None, None
+
+
 def to_bf16(x):
     """fp32/bf16 torch tensor -> contiguous bf16 (autograd-aware torch cast: stem boundary)"""
     return x.to(BF16).contiguous()

@@ -14,6 +14,8 @@ bf16 -- SURVEY.md section 8 row A8/N3 schedules a hand-written implicit-GEMM for
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -317,6 +319,7 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(hidden_dim, embed_dim, kernel_size=patch_size // stem_stride, stride=patch_size // stem_stride)
         self.num_patches = (img_size // patch_size) * (img_size // patch_size)
         self.compute_dtype = BF16          # torch.float32 runs the MIOpen stem un-autocast (parity debugging)
+        self.hip_conv = os.environ.get("AP_STEM_HIP_CONV", "1") == "1"    # 3x3 / 64-channel stem convolutions on csrc/conv.hip (0: MIOpen)
         self.resize_to = None              # elastic input size: a fp32 batch of another size is resized on the way in (main_prog.py:973)
 
     def forward(self, x):
@@ -342,10 +345,15 @@ class PatchEmbed(nn.Module):
                     counters = []
                     for i in (0, 3, 6):
                         conv, bn = self.conv[i], self.conv[i + 1]
-                        x = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
-                        x = x.contiguous(memory_format=torch.channels_last)          # no-op when MIOpen kept NHWC
-                        nhwc = AF.BNReLUFn.apply(x.permute(0, 2, 3, 1), bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                                 self.training, bn.momentum, bn.eps)
+                        if i and tuple(conv.weight.shape) == (64, 64, 3, 3) and self.hip_conv:
+                            # the two 3x3 convolutions at 64 channels: HIP implicit GEMM with the BatchNorm statistics in its epilogue
+                            nhwc = AF.Conv3x3BNReLUFn.apply(x.permute(0, 2, 3, 1), conv.weight, bn.weight, bn.bias, bn.running_mean,
+                                                            bn.running_var, self.training, bn.momentum, bn.eps)
+                        else:
+                            x = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+                            x = x.contiguous(memory_format=torch.channels_last)          # no-op when MIOpen kept NHWC
+                            nhwc = AF.BNReLUFn.apply(x.permute(0, 2, 3, 1), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                     self.training, bn.momentum, bn.eps)
                         if self.training and bn.num_batches_tracked is not None:
                             counters.append(bn.num_batches_tracked)
                         x = nhwc.permute(0, 3, 1, 2)                                    # NCHW view, channels_last strides

@@ -325,12 +325,23 @@ def sum_reps_acc(x, out, reps):
 
 
 # ---------------------------------------------------------------------------- stem BN + ReLU
-def bn_relu_fwd(x, gamma, beta, running_mean, running_var, training, momentum, eps):
-    """x: bf16 [..., C] NHWC rows.  returns (y, mean, rstd)"""
+def bn_relu_fwd(x, gamma, beta, running_mean, running_var, training, momentum, eps, partials=None):
+    """x: bf16 [..., C] NHWC rows.  returns (y, mean, rstd).  partials (training only): fp32 [rows,2,C] partial sums / sums of squares
+    of x from the kernel that produced it (conv3x3_c64 want_stats) -- the statistics pass over x is skipped"""
     _req(x, BF16, "x")
     C = x.shape[-1]
     T = x.numel() // C
     y = torch.empty_like(x)
+    if training and partials is not None:
+        _req(partials, torch.float32, "partials")
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        check(lib.ap_bn_relu_fwd_partials(x.data_ptr(), partials.data_ptr(), partials.shape[0], gamma.data_ptr(), beta.data_ptr(),
+                                          running_mean.data_ptr() if running_mean is not None else None,
+                                          running_var.data_ptr() if running_var is not None else None,
+                                          float(momentum), float(eps), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), T, C, _stream()),
+              "ap_bn_relu_fwd_partials")
+        return y, mean, rstd
     if training:
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         rstd = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -357,3 +368,41 @@ def bn_relu_bwd(dy, x, gamma, beta, mean, rstd, dgamma, dbeta):
     check(lib.ap_bn_relu_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                              dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), T, C, ws.data_ptr(), ws_bytes, _stream()), "ap_bn_relu_bwd")
     return dx
+
+
+# ------------------------------------------------------------------------------------- stem 3x3 convolution (C = 64)
+def conv3x3_pack(weight):
+    """fp32 [64,64,3,3] -> (w_fwd, w_bwd) bf16 operand layouts of conv3x3_c64"""
+    _req(weight, torch.float32, "weight")
+    if tuple(weight.shape) != (64, 64, 3, 3):
+        raise AutoProgHipError("conv3x3_c64 handles 64 -> 64 channels, 3x3 (got %s)" % (tuple(weight.shape),))
+    wf = torch.empty(9 * 64 * 64, dtype=BF16, device=weight.device)
+    wb = torch.empty_like(wf)
+    check(lib.ap_conv3x3_c64_pack(weight.contiguous().data_ptr(), wf.data_ptr(), wb.data_ptr(), _stream()), "ap_conv3x3_c64_pack")
+    return wf, wb
+
+
+def conv3x3_c64(x, w_packed, want_stats=False):
+    """x [B,H,W,64] bf16 (NHWC, contiguous) -> conv3x3 / stride 1 / pad 1.  want_stats: also return the partial BatchNorm
+    statistics of the output (fp32 [rows,2,64], for bn_relu_fwd(..., partials=))"""
+    _req(x, BF16, "x"); _req(w_packed, BF16, "w_packed")
+    B, H, W, C = x.shape
+    if C != 64:
+        raise AutoProgHipError("conv3x3_c64: 64 channels (got %d)" % C)
+    y = torch.empty_like(x)
+    stats = torch.empty((lib.ap_conv3x3_c64_stat_rows(B, H, W), 2, 64), dtype=torch.float32, device=x.device) if want_stats else None
+    check(lib.ap_conv3x3_c64(x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), B, H, W,
+                             stats.data_ptr() if want_stats else None, _stream()), "ap_conv3x3_c64")
+    return (y, stats) if want_stats else y
+
+
+def conv3x3_c64_wgrad(x, dy, dw):
+    """dw (fp32 [64,64,3,3], contiguous) += weight gradient of conv3x3_c64 for input x and output gradient dy"""
+    _req(x, BF16, "x"); _req(dy, BF16, "dy"); _req(dw, torch.float32, "dw")
+    B, H, W, C = x.shape
+    if C != 64 or tuple(dy.shape) != tuple(x.shape) or tuple(dw.shape) != (64, 64, 3, 3):
+        raise AutoProgHipError("conv3x3_c64_wgrad: shapes %s %s %s" % (tuple(x.shape), tuple(dy.shape), tuple(dw.shape)))
+    ws_bytes = lib.ap_conv3x3_c64_wgrad_workspace(B, H, W)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    check(lib.ap_conv3x3_c64_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), ws_bytes, _stream()), "ap_conv3x3_c64_wgrad")
+    return dw

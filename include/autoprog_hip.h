@@ -188,10 +188,32 @@ size_t ap_bn_relu_workspace(int64_t T, int C);
 int ap_bn_relu_fwd(const ap_bf16* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                    int training, float momentum, float eps, ap_bf16* y, float* mean, float* rstd, int64_t T, int C,
                    void* workspace, size_t ws_bytes, ap_stream_t stream);
+/* training-mode ap_bn_relu_fwd whose batch statistics come from `partial`: n_partial rows [2][C] of per-channel sums and sums
+ * of squares of x, produced by the kernel that wrote x (ap_conv3x3_c64 with stats != NULL) -- saves the pass over x */
+int ap_bn_relu_fwd_partials(const ap_bf16* x, const float* partial, int n_partial, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, ap_bf16* y, float* mean, float* rstd,
+                            int64_t T, int C, ap_stream_t stream);
 /* dx = d(relu(bn(x)))/dx . dy ; dgamma/dbeta accumulated (+=) */
 int ap_bn_relu_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* beta, const float* mean,
                    const float* rstd, ap_bf16* dx, float* dgamma, float* dbeta, int64_t T, int C,
                    void* workspace, size_t ws_bytes, ap_stream_t stream);
+
+/* ---- stem 3x3 convolutions in HIP (reference models/volo.py:355-367: the two
+ * nn.Conv2d(hidden, hidden, 3, 1, 1, bias=False) of PatchEmbed at hidden = 64).  NHWC bf16 feature maps. */
+/* fp32 OIHW [64][64][3][3] -> the two bf16 operand layouts of ap_conv3x3_c64: w_fwd [tap][co][ci] and
+ * w_bwd [8 - tap][ci][co] (input gradient = the same convolution on flipped, transposed weights); 9*64*64 elements each */
+int ap_conv3x3_c64_pack(const float* w_oihw, ap_bf16* w_fwd, ap_bf16* w_bwd, ap_stream_t stream);
+/* y[B,H,W,64] = conv3x3(x[B,H,W,64], stride 1, zero pad 1) with packed weights (w_fwd: forward; w_bwd with x = dy: dx).
+ * stats (nullable): float[ap_conv3x3_c64_stat_rows(B,H,W)][2][64]; every workgroup stores the per-channel sum and sum of
+ * squares of its bf16 outputs to its row (the partial batch statistics of the BatchNorm that follows: ap_bn_relu_fwd_partials) */
+int ap_conv3x3_c64_stat_rows(int B, int H, int W);
+int ap_conv3x3_c64(const ap_bf16* x, const ap_bf16* w_packed, ap_bf16* y, int B, int H, int W, float* stats, ap_stream_t stream);
+
+/* dw_oihw[64][64][3][3] (fp32) += weight gradient of ap_conv3x3_c64: x the layer input, dy the output gradient (both
+ * [B,H,W,64] NHWC bf16).  Per-workgroup partial sums go to `workspace` and are added in a fixed order: no atomics. */
+size_t ap_conv3x3_c64_wgrad_workspace(int B, int H, int W);
+int ap_conv3x3_c64_wgrad(const ap_bf16* x, const ap_bf16* dy, float* dw_oihw, int B, int H, int W, void* workspace, size_t ws_bytes,
+                         ap_stream_t stream);
 
 /* ---- fused optimizer step: AdamW (torch.optim.AdamW semantics, main_prog.py:484)
  * + n_ema <= 4 ModelEmaV2 updates (main_prog.py:1030-1033) over one flat fp32 slab of n parameters

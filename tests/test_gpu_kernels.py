@@ -508,3 +508,65 @@ def test_c_abi_error_codes_and_empty_inputs(ops):
     assert lib.ap_mhsa_fwd(P(q), None, P(f), 2, 16, 1, 32, ctypes.c_float(0.1), None, st) == -4
     assert lib.ap_outlook_fwd(P(x), P(x), 88, P(x), 1, 8, 8, 1, 16, ctypes.c_float(0.25), st) == -2     # outlook head_dim != 32
     torch.cuda.synchronize()                                                                          # nothing above may have faulted
+
+
+# ------------------------------------------------------------------ stem 3x3 convolution (csrc/conv.hip)
+@pytest.mark.parametrize("B,H,W", [(2, 20, 37), (3, 33, 16), (1, 7, 5), (4, 112, 112)])
+def test_conv3x3_c64_fwd_dgrad_wgrad_vs_torch_fp32(B, H, W):
+    """ap_conv3x3_c64 / _wgrad against torch's fp32 convolution on the same bf16-rounded operands (reference stem:
+    models/volo.py:359-366, nn.Conv2d(64, 64, 3, 1, 1, bias=False)).  Ragged sizes exercise the tile edges (32 x 16 forward
+    tiles, 16 x 16 weight-gradient tiles).  Tolerances: outputs 5e-3 rel-L2 (bf16 store rounding), the partial BatchNorm sums
+    1e-5, the fp32 weight gradient 1e-5 (exact fp32 accumulation of bf16 products, summation order aside)."""
+    import torch.nn.functional as F
+    from autoprog_amd import ops
+    torch.manual_seed(B * 1000 + H)
+    x = torch.randn(B, H, W, 64, device="cuda").to(torch.bfloat16)
+    dy = torch.randn(B, H, W, 64, device="cuda").to(torch.bfloat16)
+    w = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
+    w16 = w.to(torch.bfloat16).float()
+    wf, wb = ops.conv3x3_pack(w)
+    y, st = ops.conv3x3_c64(x, wf, True)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w16, None, 1, 1).permute(0, 2, 3, 1)
+    assert rel(y, ref) < 5e-3
+    assert torch.equal(y, ops.conv3x3_c64(x, wf))                         # the statistics epilogue does not change the output
+    sums = st.double().sum(0)
+    assert rel(sums[0], y.double().sum((0, 1, 2))) < 1e-5 and rel(sums[1], y.double().pow(2).sum((0, 1, 2))) < 1e-5
+    dx = ops.conv3x3_c64(dy, wb)
+    refdx = F.conv_transpose2d(dy.float().permute(0, 3, 1, 2), w16, None, 1, 1).permute(0, 2, 3, 1)
+    assert rel(dx, refdx) < 5e-3
+    dw = torch.full((64, 64, 3, 3), 0.5, device="cuda")                   # accumulates (+=)
+    ops.conv3x3_c64_wgrad(x, dy, dw)
+    refdw = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (64, 64, 3, 3), dy.float().permute(0, 3, 1, 2), stride=1, padding=1)
+    assert rel(dw - 0.5, refdw) < 1e-5
+    dw2 = torch.full((64, 64, 3, 3), 0.5, device="cuda")
+    ops.conv3x3_c64_wgrad(x, dy, dw2)
+    assert torch.equal(dw, dw2)                                           # ordered slab reduction: bit-reproducible
+
+
+def test_conv3x3_bn_relu_fn_vs_torch():
+    """Conv3x3BNReLUFn (conv -> BatchNorm(batch stats) -> ReLU) forward / backward against the same triple in torch fp32"""
+    import torch.nn.functional as F
+    from autoprog_amd import functional as AF
+    torch.manual_seed(5)
+    B, H, W = 4, 24, 40
+    x = torch.randn(B, H, W, 64, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    cw = (torch.randn(64, 64, 3, 3, device="cuda") * 0.05).requires_grad_(True)
+    g = (1 + 0.1 * torch.randn(64, device="cuda")).requires_grad_(True)
+    b = (0.1 * torch.randn(64, device="cuda")).requires_grad_(True)
+    rm, rv = torch.zeros(64, device="cuda"), torch.ones(64, device="cuda")
+    y = AF.Conv3x3BNReLUFn.apply(x, cw, g, b, rm, rv, True, 0.1, 1e-5)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    x2 = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    cw2 = cw.detach().to(torch.bfloat16).float().requires_grad_(True)
+    g2, b2 = g.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    rm2, rv2 = torch.zeros(64, device="cuda"), torch.ones(64, device="cuda")
+    z = F.conv2d(x2, cw2, None, 1, 1)
+    z = z.detach().to(torch.bfloat16).float() + (z - z.detach())         # the HIP path stores the convolution output in bf16 (value only)
+    y2 = F.relu(F.batch_norm(z, rm2, rv2, g2, b2, True, 0.1, 1e-5))
+    y2.backward(dy.float().permute(0, 3, 1, 2))
+    assert rel(y, y2.permute(0, 2, 3, 1)) < 6e-3
+    assert rel(rm, rm2) < 1e-4 and rel(rv, rv2) < 1e-4
+    errs = dict(dx=rel(x.grad, x2.grad.permute(0, 2, 3, 1)), dw=rel(cw.grad, cw2.grad), dg=rel(g.grad, g2.grad), db=rel(b.grad, b2.grad))
+    print("Conv3x3BNReLUFn gradient rel-L2 errors:", errs)
+    assert errs["dx"] < 6e-3 and errs["dw"] < 6e-3 and errs["dg"] < 1e-3 and errs["db"] < 1e-3, errs      # measured 2.3e-3 / 1.7e-3 / 1.5e-6 / 3e-8
