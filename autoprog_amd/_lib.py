@@ -21,7 +21,12 @@ class GemmEpilogue(Structure):
 class TnProblem(Structure):
     """ap_tn_problem (include/autoprog_hip.h)"""
     _fields_ = [("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int), ("C", c_void_p), ("ldc", c_int),
-                ("M", c_int), ("N1", c_int), ("N2", c_int), ("alpha", c_float), ("colsum_A", c_void_p), ("colsum_weight", c_void_p), ("colsum_scale", c_float)]
+                ("M", c_int), ("N1", c_int), ("N2", c_int), ("alpha", c_float), ("colsum_A", c_void_p), ("colsum_weight", c_void_p), ("colsum_scale", c_float), ("b_patch", c_void_p)]
+
+
+class PatchMap(Structure):
+    """ap_patch_map (include/autoprog_hip.h)"""
+    _fields_ = [("group", c_int), ("group_stride", c_int), ("row_stride", c_int), ("kseg", c_int), ("kseg_stride", c_int)]
 
 
 TN_MAX_GROUP = 8
@@ -63,6 +68,7 @@ _SIGNATURES = {
     "ap_adamw_ema_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, POINTER(c_void_p), POINTER(c_float), _I, _P, _P]),
     "ap_batched_transpose_bf16": (_I, [_P, _P, _P, _I, _I, _P]),
 }
+_SIGNATURES["ap_gemm_nt_patch"] = (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, POINTER(PatchMap), _I, _P])
 _SIGNATURES["ap_bn_relu_fwd_partials"] = (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P])
 _SIGNATURES["ap_conv3x3_c64_stat_rows"] = (_I, [_I, _I, _I])
 _SIGNATURES["ap_conv3x3_c64_pack"] = (_I, [_P, _P, _P, _P])

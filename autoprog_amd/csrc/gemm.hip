@@ -40,7 +40,9 @@
 // tile is prefetched under the last K step (see "epilogue input prefetch" below).  PRE = false is the plain kernel, unchanged.
 // amdgpu_waves_per_eu: the PRE kernel keeps the register budget of the plain one (three workgroups of the 128x128 tile per CU);
 // without the hint the scheduler spends a wave of occupancy on interleaving the erf evaluations of the epilogue chunks.
-template <int TM, int TN, int WGM, int WGN, bool DEPI = true, int PF = 1, bool PRE = false>
+// PATCH = 1: the rows of A are patches of an NHWC feature map (PatchMap, gemm_epi.h); PATCH = 2: the rows of C are (the input gradient
+// of such a patch convolution, written straight into the feature-map layout; plain epilogue only).
+template <int TM, int TN, int WGM, int WGN, bool DEPI = true, int PF = 1, bool PRE = false, int PATCH = 0>
 __global__ void __launch_bounds__(WGM * WGN * 64) __attribute__((amdgpu_waves_per_eu((PRE && TM * TN == 128 * 128 && WGM * WGN == 4) ? 3 : 1)))
 k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
           int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
@@ -51,6 +53,7 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
     constexpr int EROWS = EROWS_RAW < TM ? EROWS_RAW : TM;
     constexpr int PASSES = (TM + EROWS - 1) / EROWS;
     static_assert(TM * 8 % NTH == 0 && TN * 8 % NTH == 0, "staging split");
+    static_assert(PATCH != 2 || (!DEPI && !PRE), "patch-addressed C rows: staged plain epilogue only");
     static_assert((TM / WGM) % 16 == 0 && (TN / WGN) % 16 == 0, "wave tile");
     static_assert(EROWS >= 16 && EROWS % 16 == 0, "epilogue pass split");
     __shared__ __attribute__((aligned(16))) bf16_t smem_nt[(TM + TN) * SBK];       // A tile | B tile; reused by the epilogue
@@ -70,7 +73,7 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int r = srow + (NTH / 8) * i;
-        ga[i] = A + (int64_t)min(m0 + r, M - 1) * lda + kc * 8;
+        ga[i] = A + (PATCH == 1 ? patch_row(ep.pm, min(m0 + r, M - 1)) : (int64_t)min(m0 + r, M - 1) * lda) + kc * 8;
         soffa[i] = r * SBK + ((kc ^ (r & 7)) << 3);
     }
 #pragma unroll
@@ -90,8 +93,9 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
     const bool kfull = (K & (SBK - 1)) == 0;
     auto gload = [&](u32x4* ra, u32x4* rb, int k0) {
         if (kfull) {
+            const int ka = PATCH == 1 ? patch_col(ep.pm, k0) : k0;      // uniform: a 64-wide K step never straddles a kernel row
 #pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = ld16(ga[i] + k0);
+            for (int i = 0; i < NA; ++i) ra[i] = ld16(ga[i] + ka);
 #pragma unroll
             for (int i = 0; i < NB; ++i) rb[i] = ld16(gb[i] + k0);
         } else {
@@ -248,7 +252,8 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(ctile + r * TN + (((2 * j) ^ (r & 7)) << 2));
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(ctile + r * TN + (((2 * j + 1) ^ (r & 7)) << 2));
                 v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-                epi_chunk(v, m, n, N, ldc, vec_ok, ep, C);
+                if constexpr (PATCH == 2) st16(C + patch_row(ep.pm, m) + patch_col(ep.pm, n), pack8(v));      // N % 8 == 0, plain epilogue (host-checked)
+                else epi_chunk(v, m, n, N, ldc, vec_ok, ep, C);
             }
         } else {
             // UNR chunks at a time in a ROLLED loop (a fully unrolled sweep holds 4 chunks of erf / gelu' temporaries); the
@@ -758,16 +763,19 @@ struct TnArgs {
     float alpha;                // factor applied to the product
     float* slab;                // deterministic mode: partial tiles [splits][N1][N2] (+ [splits][N1] column sums behind them), else nullptr
     int splits;
+    PatchMap pb;                // pb.group != 0: the rows of B are patches of an NHWC feature map (gemm_epi.h)
 };
 // deterministic mode: partial results are STORED per token split and summed in split order by k_tn_reduce
 struct TnDet { float* slab; float* cs_slab; };
 #define TN_MAX_GROUP 8
 struct TnGroup { TnArgs p[TN_MAX_GROUP]; int count; };
 
+template <bool BPATCH = false>
 __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
                                         int M, int N1, int N2, int steps_per_split, float* __restrict__ colsum, int t1, int t2, int nblocks, int block,
                                         bf16_t* sA, bf16_t* sB, const bf16_t* __restrict__ cs_weight = nullptr, float cs_scale = 1.0f,
-                                        float* __restrict__ slab = nullptr, int splits = 1, float alpha = 1.0f) {
+                                        float* __restrict__ slab = nullptr, int splits = 1, float alpha = 1.0f,
+                                        const PatchMap pb = PatchMap{0, 0, 0, 0, 0, 0u, 0u}) {
     // XCD-aware decode: workgroups that share an XCD (and its L2) get consecutive ids, i.e. all output
     // tiles of the SAME token split, so each token range is fetched from HBM by one L2 only
     // (before: 347 MB of beyond-L2 traffic for 77 MB of operands on the qkv shape)
@@ -807,13 +815,19 @@ __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, c
             for (int ks = 0; ks < 2; ++ks) rw[ks] = ld16(wsrc + min(step * TM + ks * 32 + 8 * (lane >> 4), wmax));
         }
     };
+    // patch-addressed B (the weight gradient of a k x k / stride k convolution: B rows are patches of the layer input): the column part
+    // of the address is fixed per thread, the row part costs one multiply-high per load
+    // (a separate instantiation: the extra address registers cost the grouped kernel its second workgroup per CU)
+    constexpr bool b_patch = BPATCH;
+    const int cbp = b_patch ? patch_col(pb, min(k0 + j * 8, N2 - 8)) : 0;
+    auto brow = [&](int m) { return b_patch ? patch_row(pb, m) + cbp : (int64_t)m * ldb + cb; };
     auto gload = [&](u32x4* ra, u32x4* rb, int step) {
         if (step < step_end && (step + 1) * TM <= M) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = step * TM + srow + 16 * i;
                 ra[i] = ld16(A + (int64_t)m * lda + ca);
-                rb[i] = ld16(B + (int64_t)m * ldb + cb);
+                rb[i] = ld16(B + brow(m));
             }
             return;
         }
@@ -822,7 +836,7 @@ __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, c
             const int m = step * TM + srow + 16 * i;
             const bool ok = (m < M) && (step < step_end);
             ra[i] = (ok && a_ok) ? ld16(A + (int64_t)m * lda + n0 + j * 8) : zero4;
-            rb[i] = (ok && b_ok) ? ld16(B + (int64_t)m * ldb + k0 + j * 8) : zero4;
+            rb[i] = (ok && b_ok) ? ld16(B + (b_patch ? brow(min(m, M - 1)) : (int64_t)m * ldb + k0 + j * 8)) : zero4;
         }
     };
     f32x4 acc[4][4];     // [nt][kt]
@@ -963,6 +977,15 @@ k_gemm_tn_grouped(TnGroup grp) {
     const TnArgs& a = grp.p[pi];
     tn_tile(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N1, a.N2, a.steps_per_split, a.colsum, a.t1, a.t2, a.nblocks,
             (int)blockIdx.x - a.start, sA, sB, a.cs_weight, a.cs_scale, a.slab, a.splits, a.alpha);
+}
+
+// one weight gradient whose B rows are patches of an NHWC feature map (PatchMap): a k x k / stride k convolution's dW
+__global__ void __launch_bounds__(256)
+k_gemm_tn_patch(TnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t sA[TM * 128];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[TM * 128];
+    tn_tile<true>(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N1, a.N2, a.steps_per_split, a.colsum, a.t1, a.t2, a.nblocks,
+                  (int)blockIdx.x, sA, sB, a.cs_weight, a.cs_scale, a.slab, a.splits, a.alpha, a.pb);
 }
 
 // deterministic mode, second pass: C[n][k] += sum over splits (in split order) of the stored partial tiles; same for the column sums
@@ -1107,7 +1130,7 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     if (!A || !B || !C) return AP_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0) return AP_ERR_SHAPE;
     if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N) return AP_ERR_SHAPE;
-    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr};
+    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}};
     { const char* e = getenv("AP_GEMM_DBG"); if (e) ep.dbg = atoi(e); }
     if (epi) {
         ep.bias = epi->bias; ep.gelu = epi->gelu; ep.preact = epi->preact_out; ep.dgelu_of = epi->dgelu_of;
@@ -1293,6 +1316,35 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     return ap_check_launch();
 }
 
+static bool patch_map_device(const ap_patch_map* map, PatchMap& pm) {
+    if (!map || map->group < 1 || map->kseg < 1) return false;
+    pm.group = map->group; pm.gstride = map->group_stride; pm.rstride = map->row_stride; pm.kseg = map->kseg; pm.kstride = map->kseg_stride;
+    pm.gmagic = map->group == 1 ? 0xFFFFFFFFu : (unsigned)(0xFFFFFFFFu / (unsigned)map->group) + 1u;      // group 1: q = m - (m != 0 ? 0 : 0) handled below
+    pm.kmagic = map->kseg == 1 ? 0xFFFFFFFFu : (unsigned)(0xFFFFFFFFu / (unsigned)map->kseg) + 1u;
+    return map->group > 1 && map->kseg > 1;         // d = 1 has no exact 32-bit magic; no caller needs it
+}
+
+int ap_gemm_nt_patch(const ap_bf16* A, const ap_bf16* B, int ldb, ap_bf16* C, int ld, int M, int N, int K,
+                     const float* bias, const ap_patch_map* map, int side, ap_stream_t stream) {
+    if (!A || !B || !C || !map) return AP_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (ldb & 7) || ldb < K) return AP_ERR_SHAPE;
+    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}};
+    if (!patch_map_device(map, ep.pm)) return AP_ERR_SHAPE;
+    if ((int64_t)M >= (int64_t)(0xFFFFFFFFu / (unsigned)map->group)) return AP_ERR_SHAPE;       // exactness bound of the magic division
+    (void)hipGetLastError();
+    if (side == 1) {            // A rows are patches; C plain [M, ld]
+        if ((K & 63) || (map->kseg & 63) || K % map->kseg || ld < N) return AP_ERR_SHAPE;
+        ep.bias = bias;
+        const int tm = (M + 127) / 128, tn = (N + 63) / 64, nt = tm * tn;
+        hipLaunchKernelGGL((k_gemm_nt<128, 64, 2, 2, true, 1, false, 1>), dim3(nt), dim3(256), 0, (hipStream_t)stream, A, K, B, ldb, C, ld, M, N, K, tn, nt, ep);
+    } else if (side == 2) {     // C rows are patches (input gradient); A plain [M, ld]
+        if (bias || (N & 7) || (map->kseg & 7) || N % map->kseg || (ld & 7) || ld < K) return AP_ERR_SHAPE;
+        const int tm = (M + 127) / 128, tn = (N + 127) / 128, nt = tm * tn;
+        hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, false, 1, false, 2>), dim3(nt), dim3(256), 0, (hipStream_t)stream, A, ld, B, ldb, C, N, M, N, K, tn, nt, ep);
+    } else return AP_ERR_SHAPE;
+    return ap_check_launch();
+}
+
 int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* C, int ldc, int M, int N1, int N2,
                    float* colsum_A, ap_stream_t stream) {
     if (!A || !B || !C) return AP_ERR_NULL;
@@ -1353,7 +1405,8 @@ static int tn_plan(const ap_tn_problem* problems, int count, TnGroup& grp, int& 
         const ap_tn_problem& q = problems[i];
         if (!q.A || !q.B || !q.C) return AP_ERR_NULL;
         if (q.M <= 0 || q.N1 <= 0 || q.N2 <= 0) return AP_ERR_SHAPE;
-        if ((q.lda & 7) || (q.ldb & 7) || q.lda < q.N1 || q.ldb < q.N2 || q.ldc < q.N2) return AP_ERR_SHAPE;
+        if ((q.lda & 7) || q.lda < q.N1 || q.ldc < q.N2) return AP_ERR_SHAPE;
+        if (!q.b_patch && ((q.ldb & 7) || q.ldb < q.N2)) return AP_ERR_SHAPE;         // patch-addressed B has no leading dimension
         const int steps = (q.M + TM - 1) / TM;
         if (steps > max_steps) max_steps = steps;
     }
@@ -1391,6 +1444,11 @@ static int tn_plan(const ap_tn_problem* problems, int count, TnGroup& grp, int& 
         a.cs_scale = q.colsum_weight ? q.colsum_scale : 1.0f;
         a.alpha = q.alpha != 0.0f ? q.alpha : 1.0f;
         a.slab = nullptr; a.splits = splits;
+        a.pb = PatchMap{0, 0, 0, 0, 0, 0u, 0u};
+        if (q.b_patch) {
+            if (!patch_map_device(q.b_patch, a.pb) || (q.N2 & 7) || (q.b_patch->kseg & 7) || q.N2 % q.b_patch->kseg ||
+                (int64_t)q.M >= (int64_t)(0xFFFFFFFFu / (unsigned)q.b_patch->group)) return AP_ERR_SHAPE;
+        }
         slab_floats += (size_t)splits * ((size_t)q.N1 * q.N2 + (q.colsum_A ? (size_t)q.N1 : 0));
         start += a.nblocks;
     }
@@ -1418,7 +1476,12 @@ int ap_gemm_tn_acc_grouped(const ap_tn_problem* problems, int count, void* works
         }
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_gemm_tn_grouped, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
+    bool any_patch = false;
+    for (int i = 0; i < count; ++i) any_patch = any_patch || problems[i].b_patch != nullptr;
+    if (any_patch) {
+        if (count != 1) return AP_ERR_UNSUPPORTED;                  // a patch-addressed problem is launched on its own
+        hipLaunchKernelGGL(k_gemm_tn_patch, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp.p[0]);
+    } else hipLaunchKernelGGL(k_gemm_tn_grouped, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
     if (workspace) hipLaunchKernelGGL(k_tn_reduce, dim3(1024), dim3(256), 0, (hipStream_t)stream, grp);
     return ap_check_launch();
 }

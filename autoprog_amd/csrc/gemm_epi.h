@@ -5,9 +5,29 @@
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
+// Patch addressing (non-overlapping k x k / stride k convolutions as GEMMs without a gathered copy: PatchEmbed.proj and
+// Downsample, models/volo.py:368-372,383-396).  GEMM row m = (image row group, output column) and GEMM column kk = (kernel row,
+// kernel column x channel) of an NHWC feature map sit at element offset
+//     (m / group) * gstride + (m % group) * rstride  +  (kk / kseg) * kstride + (kk % kseg)
+// group = output columns per image row, gstride = k image rows, rstride = k pixels, kseg = k pixels, kstride = one image row.
+// The divisions are multiplications by ceil(2^32 / d) (exact for m < 2^32 / d).
+struct PatchMap {
+    int group, gstride, rstride, kseg, kstride;
+    unsigned gmagic, kmagic;
+};
+__device__ __forceinline__ int64_t patch_row(const PatchMap& p, int m) {
+    const int q = (int)__umulhi((unsigned)m, p.gmagic);
+    return (int64_t)q * p.gstride + (int64_t)(m - q * p.group) * p.rstride;
+}
+__device__ __forceinline__ int patch_col(const PatchMap& p, int kk) {
+    const int q = (int)__umulhi((unsigned)kk, p.kmagic);
+    return q * p.kstride + (kk - q * p.kseg);
+}
+
 struct EpiArgs {
     const float* bias; int gelu; bf16_t* preact; const bf16_t* dgelu_of; const float* row_scale;
     int rows_per_scale; const bf16_t* residual; int ldr; int dbg; unsigned long long* stamps;
+    PatchMap pm;                // used by the PATCH instantiations of k_gemm_nt only
 };
 
 // epilogue of 8 consecutive output columns [n, n+8) of row m held in v[] (fp32 accumulators):

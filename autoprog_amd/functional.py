@@ -635,6 +635,58 @@ class BNReLUFn(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None
 
 
+class PatchConvFn(torch.autograd.Function):
+    """k x k / stride k convolution on an NHWC bf16 feature map as ONE GEMM per direction with patch addressing (PatchEmbed.proj and
+    Downsample, models/volo.py:368-372,383-396): forward, input gradient and weight gradient read / write the feature map in place --
+    no gathered [tokens, k*k*C] matrix and no scatter of its gradient.  x [B,H,W,C] (H, W multiples of k), weight [N,C,k,k] fp32,
+    bias [N] or None -> [B, H/k, W/k, N] bf16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, k):
+        xc = x.contiguous()
+        B, H, W, C = xc.shape
+        N = weight.shape[0]
+        wmat = weight.detach().permute(0, 2, 3, 1).reshape(N, k * k * C).to(BF16)            # columns ordered (dy, dx, c)
+        y = ops.gemm_nt_patch_fwd(xc, wmat, bias, k)
+        ctx.save_for_backward(xc, weight, bias, wmat)
+        ctx.k = k
+        out = y.view(B, H // k, W // k, y.shape[-1])
+        return out if y.shape[-1] == N else out[..., :N]
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, weight, bias, wmat = ctx.saved_tensors
+        k = ctx.k
+        B, H, W, C = xc.shape
+        N, K = wmat.shape
+        ld = ops.round_up(N, 8)
+        g = dy.reshape(-1, N)
+        if ld != N:
+            gp = torch.zeros((g.shape[0], ld), dtype=BF16, device=g.device)
+            gp[:, :N] = g
+            g = gp
+        g = g.contiguous()
+        params = (weight, bias)
+        bufs, sunk = _param_grad_buffers(params)
+        dwmat = torch.zeros((N, K), dtype=torch.float32, device=g.device)
+        _launch_wgrads([(g, xc, dwmat, N, K, bufs[1], None, 1.0, 1.0, ops.patch_map(H, W, C, k))])
+        join_wgrad_stream()
+        bufs[0].add_(dwmat.view(N, k, k, C).permute(0, 3, 1, 2))                              # back to OIHW
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.zeros((K, ld), dtype=BF16, device=g.device) if ld != N else torch.empty((K, N), dtype=BF16, device=g.device)
+            wt[:, :N] = wmat.t()
+            dx = ops.gemm_nt_patch_dgrad(g, wt, (B, H, W, C), k)
+        dw, db = _finish_param_grads(params, bufs, sunk)
+        return dx, dw, db, None
+
+
+def patch_conv_ok(x, weight, k):
+    """the shapes PatchConvFn's kernels take: NHWC bf16, H and W multiples of k, k*C a multiple of 64"""
+    return (x.dim() == 4 and x.dtype == BF16 and x.is_cuda and x.shape[1] % k == 0 and x.shape[2] % k == 0 and (k * x.shape[3]) % 64 == 0
+            and weight.shape[2] == k and weight.shape[3] == k)
+
+
 class Conv3x3BNReLUFn(torch.autograd.Function):
     """conv3x3(64 -> 64, stride 1, pad 1, no bias) -> BatchNorm2d -> ReLU on an NHWC bf16 tensor: the second and third triple of the
     VOLO stem (models/volo.py:359-366) on the HIP convolution kernels of csrc/conv.hip.  The convolution's epilogue also produces the

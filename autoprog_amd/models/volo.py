@@ -361,7 +361,13 @@ class PatchEmbed(nn.Module):
                         torch._foreach_add_(counters, 1)                                # one launch for the three counters
                 else:
                     x = self.conv(x)
-            x = self.proj(x)
+            k = self.proj.kernel_size[0]
+            nhwc = x.permute(0, 2, 3, 1)
+            if fused and self.hip_conv and self.proj.stride[0] == k and nhwc.is_contiguous() and AF.patch_conv_ok(nhwc, self.proj.weight, k):
+                # the patch projection: one patch-addressed GEMM per direction (csrc/gemm.hip PATCH instantiations), no MIOpen
+                x = AF.PatchConvFn.apply(nhwc, self.proj.weight, self.proj.bias, k).permute(0, 3, 1, 2)
+            else:
+                x = self.proj(x)
         return x
 
 
@@ -379,6 +385,8 @@ class Downsample(nn.Module):
         B, H, W, C = x.shape
         k = self.k
         h, w = H // k, W // k
+        if AF.patch_conv_ok(x, self.proj.weight, k):
+            return AF.PatchConvFn.apply(x, self.proj.weight, self.proj.bias, k)               # patches addressed in place
         patches = x[:, :h * k, :w * k].reshape(B, h, k, w, k, C).permute(0, 1, 3, 2, 4, 5).reshape(B, h, w, k * k * C)
         wmat = self.proj.weight.permute(0, 2, 3, 1).reshape(self.proj.weight.shape[0], k * k * C)     # (ky,kx,cin)
         return AF.linear(patches, wmat, self.proj.bias)

@@ -150,19 +150,63 @@ def gemm_tn_acc(a, b, c, n1=None, n2=None, colsum=None):
 deterministic = os.environ.get("AP_DETERMINISTIC", "0") == "1"
 
 
+def patch_map(H, W, C, k):
+    """ap_patch_map of a k x k / stride k convolution on a contiguous NHWC [B,H,W,C] feature map (H, W multiples of k)"""
+    from ._lib import PatchMap
+    if H % k or W % k:
+        raise AutoProgHipError("patch addressing needs H, W divisible by the patch size (got %dx%d / %d)" % (H, W, k))
+    return PatchMap(W // k, k * W * C, k * C, k * C, W * C)
+
+
+def gemm_nt_patch_fwd(x, wmat, bias, k):
+    """x [B,H,W,C] bf16 NHWC, wmat [N, k*k*C] bf16 (columns ordered (dy, dx, c)) -> [B*(H/k)*(W/k), round_up(N, 8)] bf16:
+    the forward of a k x k / stride k convolution, its input read in place (no gathered patch matrix)"""
+    _req(x, BF16, "x"); _req(wmat, BF16, "wmat")
+    B, H, W, C = x.shape
+    pm = patch_map(H, W, C, k)
+    M, N, K = B * (H // k) * (W // k), wmat.shape[0], k * k * C
+    ld = round_up(N, 8)
+    out = torch.empty((M, ld), dtype=BF16, device=x.device)
+    check(lib.ap_gemm_nt_patch(x.data_ptr(), wmat.data_ptr(), wmat.shape[1], out.data_ptr(), ld, M, N, K,
+                               bias.data_ptr() if bias is not None else None, ctypes.byref(pm), 1, _stream()), "ap_gemm_nt_patch")
+    return out
+
+
+def gemm_nt_patch_dgrad(dy, wmat_t, shape, k):
+    """dy [M, ld >= N] bf16, wmat_t [k*k*C, >= N] bf16 (the transposed weight matrix) -> dx [B,H,W,C] bf16 written in feature-map layout"""
+    _req(dy, BF16, "dy"); _req(wmat_t, BF16, "wmat_t")
+    B, H, W, C = shape
+    pm = patch_map(H, W, C, k)
+    M, Kc = B * (H // k) * (W // k), k * k * C
+    dx = torch.empty(shape, dtype=BF16, device=dy.device)
+    check(lib.ap_gemm_nt_patch(dy.data_ptr(), wmat_t.data_ptr(), wmat_t.shape[1], dx.data_ptr(), dy.shape[1], M, Kc, wmat_t.shape[1],
+                               None, ctypes.byref(pm), 2, _stream()), "ap_gemm_nt_patch")
+    return dx
+
+
 def gemm_tn_acc_grouped(problems):
-    """problems: list of (a, b, c, n1, n2, colsum[, colsum_weight, colsum_scale[, alpha]]) as for gemm_tn_acc; ONE launch for the whole
-    list (chunks of 8).  colsum_weight: bf16 per-token weights of the column sum (DropPath keep mask), colsum_scale its factor;
-    alpha: factor of the product (c += alpha * a^T b)."""
+    """problems: list of (a, b, c, n1, n2, colsum[, colsum_weight, colsum_scale[, alpha[, b_patch]]]) as for gemm_tn_acc; ONE launch for
+    the whole list (chunks of 8).  colsum_weight: bf16 per-token weights of the column sum (DropPath keep mask), colsum_scale its factor;
+    alpha: factor of the product (c += alpha * a^T b); b_patch: PatchMap -- b is then an NHWC feature map whose patches are the rows."""
     from ._lib import TnProblem, TN_MAX_GROUP
     for i0 in range(0, len(problems), TN_MAX_GROUP):
         chunk = problems[i0:i0 + TN_MAX_GROUP]
         arr = (TnProblem * len(chunk))()
+        keep = []
         for q, prob in zip(arr, chunk):
             a, b, c, n1, n2, colsum = prob[:6]
             csw, css = (prob[6], prob[7]) if len(prob) > 6 else (None, 1.0)
             q.alpha = float(prob[8]) if len(prob) > 8 else 1.0
+            bp = prob[9] if len(prob) > 9 else None
             _req(a, BF16, "a"); _req(b, BF16, "b"); _req(c, torch.float32, "c")
+            if bp is not None:
+                keep.append(bp)
+                q.b_patch = ctypes.addressof(bp)
+                q.A, q.lda, q.B, q.ldb, q.C, q.ldc = a.data_ptr(), a.shape[1], b.data_ptr(), 0, c.data_ptr(), c.shape[1]
+                q.M, q.N1, q.N2 = a.shape[0], (c.shape[0] if n1 is None else n1), (c.shape[1] if n2 is None else n2)
+                q.colsum_A = colsum.data_ptr() if colsum is not None else None
+                q.colsum_weight, q.colsum_scale = None, 1.0
+                continue
             if a.shape[0] != b.shape[0]:
                 raise ValueError("gemm_tn_acc_grouped: token counts differ")
             q.A, q.lda, q.B, q.ldb, q.C, q.ldc = a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1], c.data_ptr(), c.shape[1]

@@ -72,6 +72,16 @@ int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, co
  * C[M,N] = epilogue( A[M,K] . B[N,K]^T )   bf16 in, fp32 MFMA accumulate, bf16 out
  * epilogue order: +bias[n]; GELU (optionally also storing the pre-activation); * gelu'(h[m,n]);
  * * row_scale[m / rows_per_scale] (DropPath, timm); + residual[m,n]                         */
+/* Patch addressing: a k x k / stride k convolution on an NHWC feature map [B,H,W,C] (PatchEmbed.proj, Downsample:
+ * models/volo.py:368-372,383-396) is a GEMM whose row m = (b, i, j) and column kk = (dy, dx, c) live at element offset
+ *   (m / group) * group_stride + (m % group) * row_stride + (kk / kseg) * kseg_stride + (kk % kseg)
+ * with group = W/k output columns, group_stride = k*W*C, row_stride = k*C, kseg = k*C, kseg_stride = W*C (H % k == 0). */
+typedef struct ap_patch_map { int group, group_stride, row_stride, kseg, kseg_stride; } ap_patch_map;
+/* side 1: C[M, ld] = A_patches[M, K] . B[N, K]^T + bias   (forward; K % 64 == 0, kseg % 64 == 0)
+ * side 2: C_patches[M, N] = A[M, ld >= K] . B[N, K]^T        (input gradient written in place of the feature map; bias NULL) */
+int ap_gemm_nt_patch(const ap_bf16* A, const ap_bf16* B, int ldb, ap_bf16* C, int ld, int M, int N, int K,
+                     const float* bias, const ap_patch_map* map, int side, ap_stream_t stream);
+
 typedef struct ap_gemm_epilogue {
     const float* bias;          /* [N] or NULL */
     int gelu;                   /* 1: out = gelu_erf(v) (models/volo.py:157) */
@@ -102,6 +112,8 @@ typedef struct ap_tn_problem {
     const ap_bf16* colsum_weight;   /* per-token weights w (bf16, ceil(M/8)*8 elements readable, 16-byte aligned), NULL = ones: the DropPath keep mask of the
                                      * bias gradient d/db of x + (mask/keep) * (y W^T + b), models/volo.py:230-234 */
     float colsum_scale;             /* used with colsum_weight only (1/keep) */
+    const struct ap_patch_map* b_patch;   /* non-NULL: the rows of B are patches of an NHWC feature map (ldb ignored) -- the weight
+                                           * gradient of a k x k / stride k convolution without a gathered copy of its input */
 } ap_tn_problem;
 /* `workspace` NULL: partial tiles of the token splits are added with fp32 atomics (results vary in the last bits from run to run).
  * `workspace` of >= ap_gemm_tn_grouped_workspace() bytes: DETERMINISTIC -- every split stores its partial tile and a second kernel adds

@@ -570,3 +570,29 @@ def test_conv3x3_bn_relu_fn_vs_torch():
     errs = dict(dx=rel(x.grad, x2.grad.permute(0, 2, 3, 1)), dw=rel(cw.grad, cw2.grad), dg=rel(g.grad, g2.grad), db=rel(b.grad, b2.grad))
     print("Conv3x3BNReLUFn gradient rel-L2 errors:", errs)
     assert errs["dx"] < 6e-3 and errs["dw"] < 6e-3 and errs["dg"] < 1e-3 and errs["db"] < 1e-3, errs      # measured 2.3e-3 / 1.7e-3 / 1.5e-6 / 3e-8
+
+
+@pytest.mark.parametrize("B,H,W,C,N,k", [(2, 16, 24, 64, 192, 4), (3, 28, 28, 192, 384, 2), (1, 8, 8, 32, 20, 2), (4, 112, 112, 64, 192, 4)])
+def test_patch_conv_fn_vs_torch_fp32(B, H, W, C, N, k):
+    """PatchConvFn (k x k / stride k convolution as patch-addressed GEMMs: PatchEmbed.proj, Downsample -- models/volo.py:368-372,383-396)
+    against torch's fp32 convolution on the same bf16-rounded operands: output, input gradient, weight gradient, bias gradient.
+    Tolerances: bf16 outputs / input gradient 5e-3 rel-L2, fp32 weight and bias gradients 1e-4 (fp32 atomics: order varies)."""
+    import torch.nn.functional as F
+    from autoprog_amd import functional as AF
+    torch.manual_seed(C + N)
+    x = torch.randn(B, H, W, C, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(N, C, k, k, device="cuda") * 0.05).requires_grad_(True)
+    b = (0.1 * torch.randn(N, device="cuda")).requires_grad_(True)
+    assert AF.patch_conv_ok(x, w, k)
+    y = AF.PatchConvFn.apply(x, w, b, k)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    x2 = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    w2 = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    b2 = b.detach().clone().requires_grad_(True)
+    y2 = F.conv2d(x2, w2, b2, stride=k)
+    y2.backward(dy.float().permute(0, 3, 1, 2))
+    assert y.shape == (B, H // k, W // k, N)
+    assert rel(y, y2.permute(0, 2, 3, 1)) < 5e-3
+    assert rel(x.grad, x2.grad.permute(0, 2, 3, 1)) < 5e-3
+    assert rel(w.grad, w2.grad) < 1e-4 and rel(b.grad, b2.grad) < 1e-4
