@@ -68,6 +68,12 @@ _SIGNATURES = {
     "ap_adamw_ema_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, POINTER(c_void_p), POINTER(c_float), _I, _P, _P]),
     "ap_batched_transpose_bf16": (_I, [_P, _P, _P, _I, _I, _P]),
 }
+_SIGNATURES["ap_resize_bilinear_s2d16"] = (_I, [_P, _P, _I, _I, _I, _I, _I, _P])
+_SIGNATURES["ap_conv7_pack"] = (_I, [_P, _P, _P])
+_SIGNATURES["ap_conv7_s2d_stat_rows"] = (_I, [_I, _I, _I])
+_SIGNATURES["ap_conv7_s2d"] = (_I, [_P, _P, _P, _I, _I, _I, _P, _P])
+_SIGNATURES["ap_conv7_s2d_wgrad_workspace"] = (ctypes.c_size_t, [_I, _I, _I])
+_SIGNATURES["ap_conv7_s2d_wgrad"] = (_I, [_P, _P, _P, _I, _I, _I, _P, ctypes.c_size_t, _P])
 _SIGNATURES["ap_gemm_nt_patch"] = (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, POINTER(PatchMap), _I, _P])
 _SIGNATURES["ap_bn_relu_fwd_partials"] = (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P])
 _SIGNATURES["ap_conv3x3_c64_stat_rows"] = (_I, [_I, _I, _I])

@@ -229,6 +229,33 @@ k_resize_bilinear_nhwc(const float* __restrict__ x, bf16_t* __restrict__ y, int 
     }
 }
 
+// the same resize, written in the space-to-depth layout the 7x7 / stride 2 stem convolution reads (csrc/conv7.hip):
+// y[b][oy >> 1][ox >> 1][((oy & 1) * 2 + (ox & 1)) * 3 + c], 16 bf16 per 2x2 block (12 used, 4 zero); C = 3, Ho and Wo even
+__global__ void __launch_bounds__(256)
+k_resize_bilinear_s2d16(const float* __restrict__ x, bf16_t* __restrict__ y, int B, int Hi, int Wi, int Ho, int Wo, float sh, float sw) {
+    const int64_t total = (int64_t)B * Ho * Wo;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % Wo);
+        const int64_t t = i / Wo;
+        const int oy = (int)(t % Ho), b = (int)(t / Ho);
+        const float fy = fmaxf(((float)oy + 0.5f) * sh - 0.5f, 0.f), fx = fmaxf(((float)ox + 0.5f) * sw - 0.5f, 0.f);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hi - 1), x1 = x0 + (x0 < Wi - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* p = x + (int64_t)b * 3 * Hi * Wi;
+        const int sub = (oy & 1) * 2 + (ox & 1);
+        bf16_t* o = y + ((((int64_t)b * (Ho >> 1) + (oy >> 1)) * (Wo >> 1) + (ox >> 1)) << 4) + sub * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* pc = p + (int64_t)c * Hi * Wi;
+            const float top = (1.f - lx) * pc[(int64_t)y0 * Wi + x0] + lx * pc[(int64_t)y0 * Wi + x1];
+            const float bot = (1.f - lx) * pc[(int64_t)y1 * Wi + x0] + lx * pc[(int64_t)y1 * Wi + x1];
+            o[c] = f2bf((1.f - ly) * top + ly * bot);
+        }
+        if (sub == 3) { o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; }           // channels 12..15 of the block
+    }
+}
+
 // ---------------------------------------------------------------------------- DropPath masks
 // timm DropPath: mask = floor(keep + U[0,1)), factor = mask / keep.  One launch produces, for every DropPath site of
 // a forward pass: the per-sample factors, the 0/1 masks and the per-token bf16 masks the bias gradients read (16-byte aligned rows).
@@ -289,6 +316,15 @@ int ap_resize_bilinear_nhwc(const float* x, ap_bf16* y, int B, int C, int Hi, in
     if (B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return AP_ERR_SHAPE;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_resize_bilinear_nhwc, dim3(grid_for((int64_t)B * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, y, B, C, Hi, Wi, Ho, Wo,
+                       (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    return ap_check_launch();
+}
+
+int ap_resize_bilinear_s2d16(const float* x, ap_bf16* y, int B, int Hi, int Wi, int Ho, int Wo, ap_stream_t stream) {
+    if (!x || !y) return AP_ERR_NULL;
+    if (B <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || (Ho & 1) || (Wo & 1)) return AP_ERR_SHAPE;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_resize_bilinear_s2d16, dim3(grid_for((int64_t)B * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, y, B, Hi, Wi, Ho, Wo,
                        (float)Hi / (float)Ho, (float)Wi / (float)Wo);
     return ap_check_launch();
 }

@@ -687,6 +687,36 @@ def patch_conv_ok(x, weight, k):
             and weight.shape[2] == k and weight.shape[3] == k)
 
 
+class Conv7BNReLUFn(torch.autograd.Function):
+    """conv7x7 / stride 2 (3 -> 64, no bias) -> BatchNorm2d -> ReLU: the first triple of the VOLO stem (models/volo.py:355-358) on the
+    space-to-depth image xs [B,H,W,16] (ops.resize_bilinear_s2d16) -- csrc/conv7.hip; the image needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, xs, conv_w, weight, bias, running_mean, running_var, training, momentum, eps):
+        wp = ops.conv7_pack(conv_w.detach().float().contiguous())
+        if training:
+            z, partials = ops.conv7_s2d(xs, wp, True)
+            y, mean, rstd = ops.bn_relu_fwd(z, weight, bias, running_mean, running_var, True, momentum, eps, partials=partials)
+        else:
+            z = ops.conv7_s2d(xs, wp)
+            y, mean, rstd = ops.bn_relu_fwd(z, weight, bias, running_mean, running_var, False, momentum, eps)
+        ctx.save_for_backward(xs, z, conv_w, weight, bias, mean, rstd)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, z, conv_w, weight, bias, mean, rstd = ctx.saved_tensors
+        if not ctx.training:
+            raise AutoProgHipError("Conv7BNReLUFn backward is implemented for training mode (batch statistics) only")
+        params = (conv_w, weight, bias)
+        bufs, sunk = _param_grad_buffers(params)
+        dz = ops.bn_relu_bwd(dy.contiguous(), z, weight, bias, mean, rstd, bufs[1], bufs[2])
+        ops.conv7_s2d_wgrad(xs, dz, bufs[0])
+        dw, dg, db = _finish_param_grads(params, bufs, sunk)
+        return None, dw, dg, db, None, None, None, None, None
+
+
 class Conv3x3BNReLUFn(torch.autograd.Function):
     """conv3x3(64 -> 64, stride 1, pad 1, no bias) -> BatchNorm2d -> ReLU on an NHWC bf16 tensor: the second and third triple of the
     VOLO stem (models/volo.py:359-366) on the HIP convolution kernels of csrc/conv.hip.  The convolution's epilogue also produces the

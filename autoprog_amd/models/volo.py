@@ -330,7 +330,16 @@ class PatchEmbed(nn.Module):
             raise RuntimeError("autoprog_amd models run on the GPU only (no CPU fallback)")
         fused = self.compute_dtype == BF16
         size = self.resize_to if self.resize_to else x.shape[-1]
-        if fused and x.dtype == torch.float32 and x.shape[-1] == x.shape[-2] and not x.requires_grad:
+        first = None
+        if (fused and self.stem_conv and self.hip_conv and x.dtype == torch.float32 and x.shape[-1] == x.shape[-2] and not x.requires_grad
+                and size % 2 == 0 and tuple(self.conv[0].weight.shape) == (64, 3, 7, 7) and self.conv[0].stride[0] == 2):
+            # resize + space-to-depth in one kernel, then the 7x7 / stride 2 convolution of csrc/conv7.hip with its BatchNorm + ReLU
+            from .. import ops
+            bn = self.conv[1]
+            first = AF.Conv7BNReLUFn.apply(ops.resize_bilinear_s2d16(x.contiguous(), size), self.conv[0].weight, bn.weight, bn.bias,
+                                           bn.running_mean, bn.running_var, self.training, bn.momentum, bn.eps)
+            x = first.permute(0, 3, 1, 2)
+        elif fused and x.dtype == torch.float32 and x.shape[-1] == x.shape[-2] and not x.requires_grad:
             # one kernel: bilinear resize to the step's resolution (identity when the sizes agree) + NCHW fp32 -> NHWC bf16
             from .. import ops
             x = ops.resize_bilinear_nhwc(x.contiguous(), size).permute(0, 3, 1, 2)      # NCHW view of channels_last memory
@@ -345,6 +354,10 @@ class PatchEmbed(nn.Module):
                     counters = []
                     for i in (0, 3, 6):
                         conv, bn = self.conv[i], self.conv[i + 1]
+                        if i == 0 and first is not None:
+                            if self.training and bn.num_batches_tracked is not None:
+                                counters.append(bn.num_batches_tracked)
+                            continue
                         if i and tuple(conv.weight.shape) == (64, 64, 3, 3) and self.hip_conv:
                             # the two 3x3 convolutions at 64 channels: HIP implicit GEMM with the BatchNorm statistics in its epilogue
                             nhwc = AF.Conv3x3BNReLUFn.apply(x.permute(0, 2, 3, 1), conv.weight, bn.weight, bn.bias, bn.running_mean,

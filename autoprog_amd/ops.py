@@ -450,3 +450,50 @@ def conv3x3_c64_wgrad(x, dy, dw):
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     check(lib.ap_conv3x3_c64_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), ws_bytes, _stream()), "ap_conv3x3_c64_wgrad")
     return dw
+
+
+# ------------------------------------------------------------------------------------- stem 7x7 / stride 2 convolution (3 -> 64)
+def resize_bilinear_s2d16(x, size):
+    """fp32 [B,3,Hi,Wi] -> bf16 [B,size/2,size/2,16]: bilinear resize (F.interpolate align_corners=False) in the space-to-depth
+    layout conv7_s2d reads (size even)"""
+    _req(x, torch.float32, "x")
+    B, C, Hi, Wi = x.shape
+    if C != 3 or size % 2:
+        raise AutoProgHipError("resize_bilinear_s2d16: 3 channels and an even output size (got C=%d, size=%d)" % (C, size))
+    y = torch.empty((B, size // 2, size // 2, 16), dtype=BF16, device=x.device)
+    check(lib.ap_resize_bilinear_s2d16(x.data_ptr(), y.data_ptr(), B, Hi, Wi, size, size, _stream()), "ap_resize_bilinear_s2d16")
+    return y
+
+
+def conv7_pack(weight):
+    _req(weight, torch.float32, "weight")
+    if tuple(weight.shape) != (64, 3, 7, 7):
+        raise AutoProgHipError("conv7_s2d handles 3 -> 64 channels, 7x7 (got %s)" % (tuple(weight.shape),))
+    wp = torch.empty(16 * 64 * 16, dtype=BF16, device=weight.device)
+    check(lib.ap_conv7_pack(weight.contiguous().data_ptr(), wp.data_ptr(), _stream()), "ap_conv7_pack")
+    return wp
+
+
+def conv7_s2d(xs, w_packed, want_stats=False):
+    """xs [B,H,W,16] bf16 (space-to-depth image) -> [B,H,W,64] bf16 = conv7x7 / stride 2 / pad 3 of the image"""
+    _req(xs, BF16, "xs"); _req(w_packed, BF16, "w_packed")
+    B, H, W, C = xs.shape
+    if C != 16:
+        raise AutoProgHipError("conv7_s2d: 16 space-to-depth channels (got %d)" % C)
+    y = torch.empty((B, H, W, 64), dtype=BF16, device=xs.device)
+    stats = torch.empty((lib.ap_conv7_s2d_stat_rows(B, H, W), 2, 64), dtype=torch.float32, device=xs.device) if want_stats else None
+    check(lib.ap_conv7_s2d(xs.data_ptr(), w_packed.data_ptr(), y.data_ptr(), B, H, W, stats.data_ptr() if want_stats else None, _stream()),
+          "ap_conv7_s2d")
+    return (y, stats) if want_stats else y
+
+
+def conv7_s2d_wgrad(xs, dz, dw):
+    """dw (fp32 [64,3,7,7]) += weight gradient of conv7_s2d"""
+    _req(xs, BF16, "xs"); _req(dz, BF16, "dz"); _req(dw, torch.float32, "dw")
+    B, H, W, _ = xs.shape
+    if tuple(dz.shape) != (B, H, W, 64) or tuple(dw.shape) != (64, 3, 7, 7):
+        raise AutoProgHipError("conv7_s2d_wgrad: shapes %s %s %s" % (tuple(xs.shape), tuple(dz.shape), tuple(dw.shape)))
+    ws_bytes = lib.ap_conv7_s2d_wgrad_workspace(B, H, W)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=xs.device)
+    check(lib.ap_conv7_s2d_wgrad(xs.data_ptr(), dz.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), ws_bytes, _stream()), "ap_conv7_s2d_wgrad")
+    return dw

@@ -227,6 +227,20 @@ size_t ap_conv3x3_c64_wgrad_workspace(int B, int H, int W);
 int ap_conv3x3_c64_wgrad(const ap_bf16* x, const ap_bf16* dy, float* dw_oihw, int B, int H, int W, void* workspace, size_t ws_bytes,
                          ap_stream_t stream);
 
+/* ---- first stem convolution in HIP: 7x7 / stride 2 / pad 3, 3 -> 64, no bias (models/volo.py:355-357) on the space-to-depth input
+ * xs[B, H, W, 16] (bf16; H, W = half the image size; channel (sy*2+sx)*3+c = pixel (2Y+sy, 2X+sx) channel c, 12..15 zero) */
+/* fp32 [B,3,Hi,Wi] -> xs [B,Ho/2,Wo/2,16]: the bilinear resize of ap_resize_bilinear_nhwc written in that layout (Ho, Wo even) */
+int ap_resize_bilinear_s2d16(const float* x, ap_bf16* xs, int B, int Hi, int Wi, int Ho, int Wo, ap_stream_t stream);
+/* fp32 OIHW [64][3][7][7] -> packed bf16 operand (16*64*16 elements) */
+int ap_conv7_pack(const float* w_oihw, ap_bf16* w_packed, ap_stream_t stream);
+/* y[B,H,W,64] = conv7x7/s2(image) ; stats as for ap_conv3x3_c64: float[ap_conv7_s2d_stat_rows(B,H,W)][2][64] or NULL */
+int ap_conv7_s2d_stat_rows(int B, int H, int W);
+int ap_conv7_s2d(const ap_bf16* xs, const ap_bf16* w_packed, ap_bf16* y, int B, int H, int W, float* stats, ap_stream_t stream);
+/* dw_oihw[64][3][7][7] (fp32) += weight gradient; dz = output gradient [B,H,W,64]; per-workgroup slabs in `workspace`, ordered reduction */
+size_t ap_conv7_s2d_wgrad_workspace(int B, int H, int W);
+int ap_conv7_s2d_wgrad(const ap_bf16* xs, const ap_bf16* dz, float* dw_oihw, int B, int H, int W, void* workspace, size_t ws_bytes,
+                       ap_stream_t stream);
+
 /* ---- fused optimizer step: AdamW (torch.optim.AdamW semantics, main_prog.py:484)
  * + n_ema <= 4 ModelEmaV2 updates (main_prog.py:1030-1033) over one flat fp32 slab of n parameters
  * (n % 4 == 0).  wd_mask[i] != 0 selects decoupled weight decay for element i; `ema` / `ema_decay`

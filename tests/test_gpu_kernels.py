@@ -596,3 +596,30 @@ def test_patch_conv_fn_vs_torch_fp32(B, H, W, C, N, k):
     assert rel(y, y2.permute(0, 2, 3, 1)) < 5e-3
     assert rel(x.grad, x2.grad.permute(0, 2, 3, 1)) < 5e-3
     assert rel(w.grad, w2.grad) < 1e-4 and rel(b.grad, b2.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,R,src", [(2, 40, 40), (3, 64, 48), (1, 18, 18), (4, 224, 224)])
+def test_conv7_s2d_fwd_wgrad_vs_torch_fp32(B, R, src):
+    """The first stem convolution (7x7 / stride 2 / pad 3, 3 -> 64: models/volo.py:355-357) on the space-to-depth image:
+    ap_resize_bilinear_s2d16 + ap_conv7_s2d / _wgrad against F.interpolate + torch's fp32 convolution on the same bf16-rounded
+    operands.  Outputs 5e-3 rel-L2 (bf16 store), partial BatchNorm sums 1e-5, fp32 weight gradient 1e-5."""
+    import torch.nn.functional as F
+    from autoprog_amd import ops
+    torch.manual_seed(R)
+    img = torch.randn(B, 3, src, src, device="cuda")
+    w = torch.randn(64, 3, 7, 7, device="cuda") * 0.1
+    xs = ops.resize_bilinear_s2d16(img, R)
+    ref_img = (F.interpolate(img, size=(R, R), mode="bilinear", align_corners=False) if R != src else img).to(torch.bfloat16).float()
+    back = xs[..., :12].reshape(B, R // 2, R // 2, 2, 2, 3).permute(0, 5, 1, 3, 2, 4).reshape(B, 3, R, R)        # undo the space-to-depth
+    assert rel(back, ref_img) < 4e-3 and float(xs[..., 12:].abs().max()) == 0.0
+    img16 = back.float()
+    y, st = ops.conv7_s2d(xs, ops.conv7_pack(w), True)
+    ref = F.conv2d(img16, w.to(torch.bfloat16).float(), None, 2, 3).permute(0, 2, 3, 1)
+    assert y.shape == ref.shape and rel(y, ref) < 5e-3
+    sums = st.double().sum(0)
+    assert rel(sums[0], y.double().sum((0, 1, 2))) < 1e-5 and rel(sums[1], y.double().pow(2).sum((0, 1, 2))) < 1e-5
+    dz = torch.randn_like(y)
+    dw = torch.full((64, 3, 7, 7), 0.25, device="cuda")
+    ops.conv7_s2d_wgrad(xs, dz, dw)
+    refdw = torch.nn.grad.conv2d_weight(img16, (64, 3, 7, 7), dz.float().permute(0, 3, 1, 2), stride=2, padding=3)
+    assert rel(dw - 0.25, refdw) < 1e-5
