@@ -8,8 +8,9 @@ kernels (no weight copies): a supernet keeps all layers and a per-step `ActiveLa
 selects the active ones.
 
 Activations are bf16 token-major ([B,H,W,C] / [B,N,C]); parameters stay fp32.  The conv stem
-(reference PatchEmbed) runs through torch.nn.functional convolutions (MIOpen) in channels_last
-bf16 -- SURVEY.md section 8 row A8/N3 schedules a hand-written implicit-GEMM for a later round.
+(reference PatchEmbed) runs on the HIP convolution kernels of csrc/conv7.hip / conv.hip and the
+patch-addressed GEMMs at the 64-wide stem of the BASELINE configs (SURVEY.md section 8 row A8/N3);
+other stem widths and the fp32 debugging path use torch.nn.functional.conv2d.
 """
 import math
 
@@ -302,7 +303,7 @@ def rand_bbox(size, lam, scale=1):
 
 class PatchEmbed(nn.Module):
     """reference PatchEmbed (models/volo.py:342-380): conv7x7/s -> BN -> ReLU -> 2x(conv3x3 -> BN ->
-    ReLU) -> conv(patch/s).  Runs in bf16 channels_last through MIOpen (row N3: HIP later)."""
+    ReLU) -> conv(patch/s).  bf16 NHWC on the HIP stem kernels (64-wide stem); MIOpen otherwise."""
 
     def __init__(self, img_size=224, stem_conv=False, stem_stride=1, patch_size=8, in_chans=3, hidden_dim=64, embed_dim=384):
         super().__init__()
@@ -323,9 +324,10 @@ class PatchEmbed(nn.Module):
         self.resize_to = None              # elastic input size: a fp32 batch of another size is resized on the way in (main_prog.py:973)
 
     def forward(self, x):
-        """[B,3,r,r] -> NCHW feature map (channels_last memory, bf16).  Convolutions go through MIOpen
-        (torch.nn.functional.conv2d, bf16 channels_last); every BatchNorm+ReLU pair runs as the fused HIP
-        kernels of csrc/bnrelu.hip on the NHWC view of the conv output."""
+        """[B,3,r,r] -> NCHW feature map (channels_last memory, bf16).  64-wide stem: resize + space-to-depth kernel, the
+        7x7 / stride 2 convolution of csrc/conv7.hip, the two 3x3 convolutions of csrc/conv.hip (BatchNorm statistics in
+        their epilogues, BN + ReLU by csrc/bnrelu.hip) and the patch projection as a patch-addressed GEMM.  Other widths:
+        torch.nn.functional.conv2d (MIOpen, bf16 channels_last) with the same HIP BatchNorm + ReLU kernels."""
         if not x.is_cuda:
             raise RuntimeError("autoprog_amd models run on the GPU only (no CPU fallback)")
         fused = self.compute_dtype == BF16
