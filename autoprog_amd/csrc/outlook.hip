@@ -230,6 +230,185 @@ k_outlook_dlogits(const bf16_t* __restrict__ v, const bf16_t* __restrict__ dy, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------ MFMA formulation
+// The gather above spends 16 VALU operations per (contribution, source slot, 8 channels) -- it is VALU-bound (2 TB/s).
+// Here the 9 x 9 by 9 x 32 product of every window runs on the matrix pipe and only the fold stays on the VALU:
+//   Z_w[p][ch] = sum_q P_w[p][q] * V[src(w, q)][ch]      two v_mfma_f32_16x16x16_bf16 per window (9 of 16 rows / K slots used)
+//   Y[t][ch]   = sum_{(w, p): src(w, p) = t} Z_w[p][ch]   1, 2, 2 or 4 terms per pixel (parity classes as above)
+// P_w goes to LDS as bf16 rows of 16 (slots 9..15 zero); the V fragment (rows = channels, K = the window's 9 source pixels) is one
+// ds_read_b64_tr_b16 per 16 channels from the pixel-major patch; Z_w (bf16, 9 x 32) overwrites P_w's slot -- the wave that owns the
+// window reads P before it writes Z.  TP = true folds dY with the transposed probabilities (dV).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+#define OPZ 288                  // bf16 elements of a window's P / Z slot (9 x 32)
+template <bool TP>
+__global__ void __launch_bounds__(OGT)
+k_outlook_gather_mfma(const bf16_t* __restrict__ in, const bf16_t* __restrict__ logits, int ldl, bf16_t* __restrict__ out,
+                      int H, int W, int heads, float scale, int SR, int nstrips) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int h = (H + 1) >> 1, w = (W + 1) >> 1;
+    const int C = heads * OHD;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = bid % heads; bid /= heads;
+    const int strip = bid % nstrips;
+    const int b = bid / nstrips;
+    const int I0 = strip * SR;
+    const int nq = min(SR, h - I0);
+    const int pw = 2 * w + 1, ph = 2 * nq + 3;
+    const int y0 = 2 * I0 - 1;
+    const int nwr = min(nq + 1, h - I0);
+    const int nwin = nwr * w;
+    const int npix = (2 * SR + 3) * pw;
+    bf16_t* patch = reinterpret_cast<bf16_t*>(smem_raw);                       // [npix][32], pixel-major
+    bf16_t* PZ = patch + (size_t)npix * OHD;                                   // [nwin][9][32]: P rows (16 used per row) then Z
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // ONE exposed memory latency per workgroup: the logits of the first PU softmax rows of every thread are requested before
+    // the patch, and consumed after it
+    constexpr int PU = 3;
+    const int64_t win_base = ((int64_t)b * h + I0) * w;
+    const int nrows_p = nwin * OKK;
+    unsigned short raw[PU][OKK];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+        const int rc = min((int)threadIdx.x + u * OGT, nrows_p - 1);
+        const int wl = rc / OKK, p = rc - wl * OKK;
+        // the row's 9 bf16 (18 bytes at a 2-byte aligned address) as five aligned dwords instead of nine 2-byte gathers; the dword before
+        // / after the row lies inside the logits matrix (ldl >= heads * 81 + pad, 16-byte aligned rows)
+        const bf16_t* a = logits + (win_base + wl) * ldl + head * OPP + p * OKK;
+        const int odd = (int)((reinterpret_cast<uintptr_t>(a) >> 1) & 1);
+        const unsigned* a4 = reinterpret_cast<const unsigned*>(a - odd);
+        unsigned dw[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dw[k] = a4[k];
+#pragma unroll
+        for (int q = 0; q < OKK; ++q) {
+            const int e = q + odd;                                   // halfword index within the 5 dwords (odd is uniform per row only)
+            const unsigned lo = dw[q >> 1], hi = dw[(q + 1) >> 1];
+            raw[u][q] = odd ? (unsigned short)((q & 1) ? (hi & 0xffffu) : (lo >> 16)) : (unsigned short)((q & 1) ? (lo >> 16) : (lo & 0xffffu));
+            (void)e;
+        }
+    }
+    {   // patch: rows [y0, y0+ph) x cols [-1, pw-1), zero outside the image; all loads of a thread first
+        const bf16_t* src = in + (int64_t)b * H * W * C + head * OHD;
+        const int total = ph * pw * 4;
+        constexpr int SU = 5;
+        for (int idx0 = threadIdx.x; idx0 < total; idx0 += SU * OGT) {
+            u32x4 v[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int idx = idx0 + u * OGT;
+                const int c = idx & 3, pix = idx >> 2;
+                const int pr = pix / pw, pc = pix - pr * pw;
+                const int y = y0 + pr, x = pc - 1;
+                const bool ok = (idx < total) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
+                v[u] = ok ? ld16(src + ((int64_t)y * W + x) * C + c * 8) : zero4;
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int idx = idx0 + u * OGT;
+                if (idx < total) st16(patch + (idx >> 2) * OHD + (idx & 3) * 8, v[u]);
+            }
+        }
+    }
+    // softmax rows -> bf16 P (TP: transposed) in rows of 16 (slots 9..15 zero), first 9 x 16 elements of the window's slot
+    auto softmax_row = [&](int r, const unsigned short* lg) {
+        const int wl = r / OKK, p = r - wl * OKK;
+        float sv[OKK];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int q = 0; q < OKK; ++q) { sv[q] = bf2f(lg[q]) * scale; mx = fmaxf(mx, sv[q]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < OKK; ++q) { sv[q] = __expf(sv[q] - mx); sum += sv[q]; }
+        const float inv = 1.0f / sum;
+        bf16_t* slot = PZ + wl * OPZ;
+        if (TP) {
+#pragma unroll
+            for (int q = 0; q < OKK; ++q) slot[q * 16 + p] = f2bf(sv[q] * inv);          // A[q][p] = P[p][q]
+            if (p < 7) {
+#pragma unroll
+                for (int q = 0; q < OKK; ++q) slot[q * 16 + 9 + p] = 0;                     // K slots 9..15 of every row
+            }
+        } else {
+            float o8[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o8[q] = q < OKK ? sv[q] * inv : 0.f;
+            st16(slot + p * 16, pack8(o8));
+            st16(slot + p * 16 + 8, pack8(o8 + 8));
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+        const int r = threadIdx.x + u * OGT;
+        if (r < nrows_p) softmax_row(r, raw[u]);
+    }
+    for (int r = threadIdx.x + PU * OGT; r < nrows_p; r += OGT) {                           // taller strips than 3 rows per thread
+        const int wl = r / OKK, p = r - wl * OKK;
+        const bf16_t* a = logits + (win_base + wl) * ldl + head * OPP + p * OKK;
+        unsigned short lg[OKK];
+#pragma unroll
+        for (int q = 0; q < OKK; ++q) lg[q] = a[q];
+        softmax_row(r, lg);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4, q4 = fr >> 2, p4 = fr & 3;
+    for (int wl = wave; wl < nwin; wl += OGT / 64) {
+        const int wi = wl / w, wj = wl - wi * w;                      // window row within the strip, column
+        bf16_t* slot = PZ + wl * OPZ;
+        // second operand: rows = p (fr), K = q: 4 bf16 at q = 4 g .. 4 g + 3 (rows 9..15 read the slot's tail: their output columns are dropped)
+        const s16x4_t pfrag = *reinterpret_cast<const s16x4_t*>(slot + min(fr, OKK - 1) * 16 + g * 4);
+        // first operand: rows = channels, K = source pixels: lane (q4, p4) of group g addresses pixel src(w, 4 g + q4), channels 4 p4 .. + 3
+        const int kq = min(4 * g + q4, OKK - 1);                      // K slots 9..15 meet zeros of P: any finite pixel will do
+        const bf16_t* vpix = patch + ((2 * wi + kq / 3) * pw + 2 * wj + kq % 3) * OHD + p4 * 4;
+        f32x4 z[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const s16x4_t vfrag = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(vpix + t * 16));
+            z[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vfrag, pfrag, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+        // lane (fr = p, g) holds channels 16 t + 4 g .. + 3 of Z_w[p]
+        if (fr < OKK) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u32x2 pk;
+                pk[0] = pack_bf2(z[t][0], z[t][1]); pk[1] = pack_bf2(z[t][2], z[t][3]);
+                *reinterpret_cast<u32x2*>(slot + fr * OHD + 16 * t + 4 * g) = pk;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int cls = 0; cls < 4; ++cls) {
+        const int dy = cls >> 1, dx = cls & 1;
+        const int ncols = (W - dx + 1) >> 1;
+        const int nrows = min(nq, (H - dy + 1) / 2 - I0);
+        const int nro = dy ? 2 : 1, nco = dx ? 2 : 1;
+        for (int item = threadIdx.x; item < nrows * ncols * 4; item += OGT) {
+            const int c = item & 3, pq = item >> 2;
+            const int qi = pq / ncols, j = pq - qi * ncols;
+            const int i = I0 + qi;
+            const int y = 2 * i + dy, x = 2 * j + dx;
+            float acc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+            for (int ro = 0; ro < nro; ++ro) {
+                const int wi = dy ? (ro ? i + 1 : i) : i;
+                const int ar = dy ? (ro ? 0 : 2) : 1;
+                if (wi >= h) continue;
+                for (int co = 0; co < nco; ++co) {
+                    const int wj = dx ? (co ? j + 1 : j) : j;
+                    const int ac = dx ? (co ? 0 : 2) : 1;
+                    if (wj >= w) continue;
+                    float f[8];
+                    unpack8(ld16(PZ + ((wi - I0) * w + wj) * OPZ + (ar * 3 + ac) * OHD + c * 8), f);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] += f[k];
+                }
+            }
+            st16(out + (((int64_t)b * H + y) * W + x) * C + head * OHD + c * 8, pack8(acc));
+        }
+    }
+}
+
 static int gather_launch(bool tp, const bf16_t* in, const bf16_t* logits, int ldl, bf16_t* out, int B, int H, int W, int heads,
                          float scale, hipStream_t s) {
     const int h = (H + 1) / 2, w = (W + 1) / 2;
@@ -245,6 +424,26 @@ static int gather_launch(bool tp, const bf16_t* in, const bf16_t* logits, int ld
     const int nstrips = (h + SR - 1) / SR;
     const dim3 grid((unsigned)(B * nstrips * heads));
     (void)hipGetLastError();
+    static int use_mfma = -1;
+    if (use_mfma < 0) { const char* e = getenv("AP_OUTLOOK_MFMA"); use_mfma = e ? atoi(e) : 1; }
+    if (use_mfma) {
+        auto lds_m = [&](int sr) { return (size_t)(2 * sr + 3) * pw * OHD * 2 + (size_t)(sr + 1) * w * OPZ * 2; };
+        int SRm = sr_env > 0 ? sr_env : 3; if (SRm > h) SRm = h;       // 3 window rows: 50.4 us forward at 28 x 28 / B = 128 (4: 58.6, 2: 50.3)
+        while (SRm > 1 && lds_m(SRm) > 78 * 1024) --SRm;
+        if (lds_m(SRm) <= 160 * 1024) {
+            const int ns = (h + SRm - 1) / SRm;
+            const dim3 gm((unsigned)(B * ns * heads));
+            static bool attr_done = false;
+            if (!attr_done) {
+                (void)hipFuncSetAttribute((const void*)k_outlook_gather_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)k_outlook_gather_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_done = true; (void)hipGetLastError();
+            }
+            if (tp) hipLaunchKernelGGL(k_outlook_gather_mfma<true>, gm, dim3(OGT), lds_m(SRm), s, in, logits, ldl, out, H, W, heads, scale, SRm, ns);
+            else hipLaunchKernelGGL(k_outlook_gather_mfma<false>, gm, dim3(OGT), lds_m(SRm), s, in, logits, ldl, out, H, W, heads, scale, SRm, ns);
+            return ap_check_launch();
+        }
+    }
     if (tp) hipLaunchKernelGGL(k_outlook_gather<true>, grid, dim3(OGT), lds_of(SR), s, in, logits, ldl, out, H, W, heads, scale, SR, nstrips);
     else hipLaunchKernelGGL(k_outlook_gather<false>, grid, dim3(OGT), lds_of(SR), s, in, logits, ldl, out, H, W, heads, scale, SR, nstrips);
     return ap_check_launch();
