@@ -24,6 +24,11 @@ class TnProblem(Structure):
                 ("M", c_int), ("N1", c_int), ("N2", c_int), ("alpha", c_float), ("colsum_A", c_void_p), ("colsum_weight", c_void_p), ("colsum_scale", c_float), ("b_patch", c_void_p)]
 
 
+class LnReduce(Structure):
+    """ap_ln_reduce (include/autoprog_hip.h)"""
+    _fields_ = [("partial", c_void_p), ("n_partial", c_int), ("C", c_int), ("dgamma", c_void_p), ("dbeta", c_void_p)]
+
+
 class PatchMap(Structure):
     """ap_patch_map (include/autoprog_hip.h)"""
     _fields_ = [("group", c_int), ("group_stride", c_int), ("row_stride", c_int), ("kseg", c_int), ("kseg_stride", c_int)]
@@ -74,6 +79,8 @@ _SIGNATURES["ap_conv7_s2d_stat_rows"] = (_I, [_I, _I, _I])
 _SIGNATURES["ap_conv7_s2d"] = (_I, [_P, _P, _P, _I, _I, _I, _P, _P])
 _SIGNATURES["ap_conv7_s2d_wgrad_workspace"] = (ctypes.c_size_t, [_I, _I, _I])
 _SIGNATURES["ap_conv7_s2d_wgrad"] = (_I, [_P, _P, _P, _I, _I, _I, _P, ctypes.c_size_t, _P])
+_SIGNATURES["ap_layernorm_bwd_partial"] = (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, POINTER(c_int), _P])
+_SIGNATURES["ap_layernorm_bwd_reduce_batched"] = (_I, [_P, _I, _P])
 _SIGNATURES["ap_gemm_nt_patch"] = (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, POINTER(PatchMap), _I, _P])
 _SIGNATURES["ap_bn_relu_fwd_partials"] = (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P])
 _SIGNATURES["ap_conv3x3_c64_stat_rows"] = (_I, [_I, _I, _I])

@@ -284,6 +284,42 @@ int ap_layernorm_fwd(const ap_bf16* x, const float* gamma, const float* beta, ap
     return ap_check_launch();
 }
 
+// up to AP_LN_MAX_BATCH dgamma/dbeta reductions in one launch (blockIdx.y = reduction): the LayerNorms of one block
+struct LnReduceBatch { const float* partial[AP_LN_MAX_BATCH]; float* dgamma[AP_LN_MAX_BATCH]; float* dbeta[AP_LN_MAX_BATCH];
+                       int nblocks[AP_LN_MAX_BATCH]; int C[AP_LN_MAX_BATCH]; };
+__global__ void __launch_bounds__(1024)
+k_ln_bwd_reduce_batched(LnReduceBatch bt) {
+    __shared__ float red[32][33];
+    const int y = blockIdx.y;
+    const float* __restrict__ partial = bt.partial[y];
+    const int nblocks = bt.nblocks[y], C = bt.C[y], C2 = 2 * C;
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    if (blockIdx.x * 32 >= C2) return;
+    float s = 0.f;
+    if (c < C2) {
+        int b = ry;
+        for (; b + 7 * 32 < nblocks; b += 8 * 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + u * 32) * C2 + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nblocks; b += 32) s += partial[(int64_t)b * C2 + c];
+    }
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < C2) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) t += red[r][cx];
+        if (c < C) bt.dgamma[y][c] += t; else bt.dbeta[y][c - C] += t;
+    }
+}
+
+static thread_local int* g_ln_defer_blocks = nullptr;       // set by ap_layernorm_bwd_partial around its call of ap_layernorm_bwd
+
 size_t ap_layernorm_bwd_workspace(int64_t rows, int C) {
     (void)rows;
     return (size_t)1024 * 2 * (size_t)C * sizeof(float);
@@ -313,7 +349,38 @@ int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, co
     else hipLaunchKernelGGL((k_ln_bwd<4, 1>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);
     int rc = ap_check_launch();
     if (rc != AP_OK) return rc;
+    if (g_ln_defer_blocks) { *g_ln_defer_blocks = (int)grid; return AP_OK; }      // ap_layernorm_bwd_partial: the caller batches the reduction
     hipLaunchKernelGGL(k_ln_bwd_reduce, dim3((2 * C + 31) / 32), dim3(1024), 0, s, partial, (int)grid, 2 * C, dgamma, dbeta, C);
+    return ap_check_launch();
+}
+
+int ap_layernorm_bwd_partial(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* mean, const float* rstd,
+                             const ap_bf16* dres, ap_bf16* dx, int64_t rows, int C, void* workspace, size_t ws_bytes, int* n_partial,
+                             ap_stream_t stream) {
+    if (!n_partial) return AP_ERR_NULL;
+    float dummy = 0.f;                                   // dgamma / dbeta are not touched on this path
+    g_ln_defer_blocks = n_partial;
+    *n_partial = 0;
+    const int rc = ap_layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, &dummy, &dummy, rows, C, workspace, ws_bytes, stream);
+    g_ln_defer_blocks = nullptr;
+    return rc;
+}
+
+int ap_layernorm_bwd_reduce_batched(const ap_ln_reduce* items, int count, ap_stream_t stream) {
+    if (!items) return AP_ERR_NULL;
+    if (count <= 0 || count > AP_LN_MAX_BATCH) return AP_ERR_SHAPE;
+    LnReduceBatch bt;
+    int cmax = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!items[i].partial || !items[i].dgamma || !items[i].dbeta) return AP_ERR_NULL;
+        if (items[i].n_partial <= 0 || items[i].C <= 0) return AP_ERR_SHAPE;
+        bt.partial[i] = items[i].partial; bt.dgamma[i] = items[i].dgamma; bt.dbeta[i] = items[i].dbeta;
+        bt.nblocks[i] = items[i].n_partial; bt.C[i] = items[i].C;
+        if (items[i].C > cmax) cmax = items[i].C;
+    }
+    for (int i = count; i < AP_LN_MAX_BATCH; ++i) { bt.partial[i] = bt.partial[0]; bt.dgamma[i] = bt.dgamma[0]; bt.dbeta[i] = bt.dbeta[0]; bt.nblocks[i] = 0; bt.C[i] = 0; }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_ln_bwd_reduce_batched, dim3((2 * cmax + 31) / 32, count), dim3(1024), 0, (hipStream_t)stream, bt);
     return ap_check_launch();
 }
 

@@ -164,13 +164,17 @@ class wgrad_batch:
         global _wgrad_batch
         self.prev = _wgrad_batch
         _wgrad_batch = []
+        self.ln = []                  # deferred LayerNorm dgamma/dbeta reductions of the block: ops.layernorm_bwd(..., defer=batch.ln)
         return self
 
     def __exit__(self, *exc):
         global _wgrad_batch
         pending, _wgrad_batch = _wgrad_batch, self.prev
-        if pending and exc[0] is None:
-            _launch_wgrads(pending)
+        if exc[0] is None:
+            if self.ln:
+                ops.layernorm_bwd_reduce_batched(self.ln)        # one launch for the block's LayerNorms (was one per LayerNorm)
+            if pending:
+                _launch_wgrads(pending)
         return False
 
 
@@ -261,16 +265,16 @@ class TransformerBlockFn(torch.autograd.Function):
         bufs, sunk = _param_grad_buffers(params)
         (dn1w, dn1b, dqkv_w, dqkv_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = bufs
         dy2 = dy.reshape(x2.shape).contiguous()
-        with wgrad_batch():                  # the four weight gradients launch together on exit
+        with wgrad_batch() as batch:         # the four weight gradients (and the two LayerNorm parameter gradients) launch together on exit
             # MLP branch
             dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, dgelu_of=h, row_scale=rs2, rows_per_scale=N, cs_weight=tm2, inv_keep=inv_keep)
             dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b)
-            dx1 = ops.layernorm_bwd(dxn2, x1, n2w, m2, r2, dy2, dn2w, dn2b)
+            dx1 = ops.layernorm_bwd(dxn2, x1, n2w, m2, r2, dy2, dn2w, dn2b, defer=batch.ln)
             # attention branch
             do = _linear_bwd(dx1, o, proj_w, dproj_w, dproj_b, row_scale=rs1, rows_per_scale=N, cs_weight=tm1, inv_keep=inv_keep)
             dqkv = ops.mhsa_bwd(qkv, o, do, lse, B, N, heads, scale)      # dropped samples: do = 0, so the masked rows of o do not matter
             dxn1 = _linear_bwd(dqkv, xn1, qkv_w, dqkv_w, dqkv_b)
-            dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b)
+            dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b, defer=batch.ln)
         return (dx.view(dy.shape), None, None, *_finish_param_grads(params, bufs, sunk), None, None, None, None, None, None, None, None, None)
 
 
@@ -369,16 +373,16 @@ class OutlookerBlockFn(torch.autograd.Function):
         bufs, sunk = _param_grad_buffers(params)
         (dn1w, dn1b, dv_w, dv_b, dattn_w, dattn_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = bufs
         dy2 = dy.reshape(T, C).contiguous()
-        with wgrad_batch():                  # the five weight gradients launch together (side stream) on exit
+        with wgrad_batch() as batch:         # the five weight gradients launch together on exit
             dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, dgelu_of=h)
             dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b)
-            dx1 = ops.layernorm_bwd(dxn2, x1, n2w, m2, r2, dy2, dn2w, dn2b)
+            dx1 = ops.layernorm_bwd(dxn2, x1, n2w, m2, r2, dy2, dn2w, dn2b, defer=batch.ln)
             dyo = _linear_bwd(dx1, yo.view(T, C), proj_w, dproj_w, dproj_b)
             dv, dlogits = ops.outlook_bwd(v.view(B, H, W, C), logits, dyo.view(B, H, W, C), heads, scale)
             dpooled = _linear_bwd(dlogits, pooled2, attn_w, dattn_w, dattn_b, n=attn_w.shape[0])
             dxn1 = _linear_bwd(dv.view(T, C), xn1, v_w, dv_w, dv_b)
             ops.avgpool2_bwd_acc(dpooled.view(B, (H + 1) // 2, (W + 1) // 2, C), dxn1.view(B, H, W, C))
-            dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b)
+            dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b, defer=batch.ln)
         return (dx.view(dy.shape), *_finish_param_grads(params, bufs, sunk), None, None)
 
 

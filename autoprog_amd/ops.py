@@ -94,18 +94,37 @@ def layernorm_fwd(x, gamma, beta, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta):
-    """dx = dres + dLN/dx ; dgamma/dbeta (fp32) are accumulated in place."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, defer=None):
+    """dx = dres + dLN/dx ; dgamma/dbeta (fp32) are accumulated in place.  defer: a list -- the dgamma/dbeta reduction is not
+    launched but appended to it (layernorm_bwd_reduce_batched reduces the LayerNorms of a block in one launch)."""
     _req(dy, BF16, "dy"); _req(x, BF16, "x")
     C = x.shape[-1]
     rows = x.numel() // C
     dx = torch.empty_like(x)
     ws_bytes = lib.ap_layernorm_bwd_workspace(rows, C)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    if defer is not None and rows > 0:
+        n = ctypes.c_int(0)
+        check(lib.ap_layernorm_bwd_partial(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                           dres.data_ptr() if dres is not None else None, dx.data_ptr(), rows, C, ws.data_ptr(), ws_bytes,
+                                           ctypes.byref(n), _stream()), "ap_layernorm_bwd_partial")
+        defer.append((ws, n.value, C, dgamma, dbeta))
+        return dx
     check(lib.ap_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                dres.data_ptr() if dres is not None else None, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                rows, C, ws.data_ptr(), ws_bytes, _stream()), "ap_layernorm_bwd")
     return dx
+
+
+def layernorm_bwd_reduce_batched(items):
+    """items: the entries layernorm_bwd(..., defer=items) appended; one launch per 4 LayerNorms"""
+    from ._lib import LnReduce
+    for i0 in range(0, len(items), 4):
+        chunk = items[i0:i0 + 4]
+        arr = (LnReduce * len(chunk))()
+        for q, (ws, n, C, dg, db) in zip(arr, chunk):
+            q.partial, q.n_partial, q.C, q.dgamma, q.dbeta = ws.data_ptr(), n, C, dg.data_ptr(), db.data_ptr()
+        check(lib.ap_layernorm_bwd_reduce_batched(ctypes.cast(arr, ctypes.c_void_p), len(chunk), _stream()), "ap_layernorm_bwd_reduce_batched")
 
 
 # ------------------------------------------------------------------------------------- gemm

@@ -67,6 +67,15 @@ int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, co
                      const float* rstd, const ap_bf16* dres /*nullable*/, ap_bf16* dx,
                      float* dgamma, float* dbeta, int64_t rows, int C,
                      void* workspace, size_t ws_bytes, ap_stream_t stream);
+/* the same without the dgamma / dbeta reduction: the per-workgroup partial rows stay in `workspace` (which must live until the
+ * batched reduction ran), *n_partial receives their count; ap_layernorm_bwd_reduce_batched then reduces up to AP_LN_MAX_BATCH
+ * LayerNorms (all of one block) in ONE launch: dgamma / dbeta += column sums of the partial rows */
+#define AP_LN_MAX_BATCH 4
+typedef struct ap_ln_reduce { const float* partial; int n_partial; int C; float* dgamma; float* dbeta; } ap_ln_reduce;
+int ap_layernorm_bwd_partial(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* mean, const float* rstd,
+                             const ap_bf16* dres, ap_bf16* dx, int64_t rows, int C, void* workspace, size_t ws_bytes, int* n_partial,
+                             ap_stream_t stream);
+int ap_layernorm_bwd_reduce_batched(const ap_ln_reduce* items, int count, ap_stream_t stream);
 
 /* ---- Linear layers (nn.Linear: models/volo.py:67,68,71,156,158,180,182,253,256,258,547,553)
  * C[M,N] = epilogue( A[M,K] . B[N,K]^T )   bf16 in, fp32 MFMA accumulate, bf16 out
