@@ -81,6 +81,8 @@ _SIGNATURES["ap_conv7_s2d_wgrad_workspace"] = (ctypes.c_size_t, [_I, _I, _I])
 _SIGNATURES["ap_conv7_s2d_wgrad"] = (_I, [_P, _P, _P, _I, _I, _I, _P, ctypes.c_size_t, _P])
 _SIGNATURES["ap_layernorm_bwd_partial"] = (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, POINTER(c_int), _P])
 _SIGNATURES["ap_layernorm_bwd_reduce_batched"] = (_I, [_P, _I, _P])
+_SIGNATURES["ap_quantize_fp8"] = (_I, [_P, _P, _L, _P, _P, _P])
+_SIGNATURES["ap_gemm_nt_fp8"] = (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, POINTER(GemmEpilogue), _P])
 _SIGNATURES["ap_gemm_nt_patch"] = (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, POINTER(PatchMap), _I, _P])
 _SIGNATURES["ap_bn_relu_fwd_partials"] = (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P])
 _SIGNATURES["ap_conv3x3_c64_stat_rows"] = (_I, [_I, _I, _I])

@@ -256,6 +256,35 @@ k_resize_bilinear_s2d16(const float* __restrict__ x, bf16_t* __restrict__ y, int
     }
 }
 
+// ---------------------------------------------------------------------------- fp8 (OCP e4m3) quantisation
+// y = sat(x * scale[0]) as e4m3 (|.| <= 448), 16 values per thread; amax[0] = max(amax[0], max |x|) (fp32 bits compare as ints)
+__global__ void __launch_bounds__(256)
+k_quantize_fp8(const bf16_t* __restrict__ x, unsigned char* __restrict__ y, int64_t n16, const float* __restrict__ scale, float* __restrict__ amax) {
+    const float sc = scale[0];
+    float mx = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+        float f[16];
+        unpack8(ld16(x + i * 16), f);
+        unpack8(ld16(x + i * 16 + 8), f + 8);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { mx = fmaxf(mx, fabsf(f[4 * k + e])); v[e] = fminf(fmaxf(f[4 * k + e] * sc, -448.f), 448.f); }
+            int w = 0;
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+            o[k] = (unsigned)w;
+        }
+        st16(y + i * 16, o);
+    }
+    if (amax) {
+        mx = group_max<64>(mx);
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(amax), __float_as_int(mx));
+    }
+}
+
 // ---------------------------------------------------------------------------- DropPath masks
 // timm DropPath: mask = floor(keep + U[0,1)), factor = mask / keep.  One launch produces, for every DropPath site of
 // a forward pass: the per-sample factors, the 0/1 masks and the per-token bf16 masks the bias gradients read (16-byte aligned rows).
@@ -326,6 +355,15 @@ int ap_resize_bilinear_s2d16(const float* x, ap_bf16* y, int B, int Hi, int Wi, 
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_resize_bilinear_s2d16, dim3(grid_for((int64_t)B * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, y, B, Hi, Wi, Ho, Wo,
                        (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    return ap_check_launch();
+}
+
+int ap_quantize_fp8(const ap_bf16* x, unsigned char* y, int64_t n, const float* scale, float* amax, ap_stream_t stream) {
+    if (!x || !y || !scale) return AP_ERR_NULL;
+    if (n < 0 || (n & 15)) return AP_ERR_SHAPE;
+    if (n == 0) return AP_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_quantize_fp8, dim3(grid_for(n / 16)), dim3(256), 0, (hipStream_t)stream, x, y, n / 16, scale, amax);
     return ap_check_launch();
 }
 

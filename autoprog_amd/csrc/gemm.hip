@@ -42,7 +42,11 @@
 // without the hint the scheduler spends a wave of occupancy on interleaving the erf evaluations of the epilogue chunks.
 // PATCH = 1: the rows of A are patches of an NHWC feature map (PatchMap, gemm_epi.h); PATCH = 2: the rows of C are (the input gradient
 // of such a patch convolution, written straight into the feature-map layout; plain epilogue only).
-template <int TM, int TN, int WGM, int WGN, bool DEPI = true, int PF = 1, bool PRE = false, int PATCH = 0>
+// FP8 = true: A and B hold OCP e4m3 bytes (configs[4] "mixed MFMA fp8 GEMM / bf16 accum" -> fp32 accumulate here).  The kernel is
+// launched with K, lda, ldb counted in PAIRS of bytes, so staging, swizzle and addressing are the bf16 kernel's; a 16-byte fragment is
+// 16 K positions = two v_mfma_f32_16x16x32_fp8_fp8 on its 8-byte halves (the same K set on both operands), and the accumulators are
+// scaled by the two dequantisation factors in the epilogue.
+template <int TM, int TN, int WGM, int WGN, bool DEPI = true, int PF = 1, bool PRE = false, int PATCH = 0, bool FP8 = false>
 __global__ void __launch_bounds__(WGM * WGN * 64) __attribute__((amdgpu_waves_per_eu((PRE && TM * TN == 128 * 128 && WGM * WGN == 4) ? 3 : 1)))
 k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
           int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
@@ -168,8 +172,14 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) {
+                    if constexpr (FP8) {
+                        typedef __attribute__((ext_vector_type(2))) long l64x2;
+                        const l64x2 wv = __builtin_bit_cast(l64x2, wf[nt]), xv = __builtin_bit_cast(l64x2, xf[mt]);
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wv[0], xv[0], acc[nt][mt], 0, 0, 0);
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wv[1], xv[1], acc[nt][mt], 0, 0, 0);
+                    } else acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                }
         }
         __syncthreads();
     };
@@ -200,6 +210,13 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
     }
 #endif
 
+    if constexpr (FP8) {
+        const float dq = ep.dq_a[0] * ep.dq_b[0];
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) acc[a][b] *= dq;
+    }
     // ---------------------------------------------------------------- epilogue
     // PASSES passes of EROWS rows: accumulators -> fp32 [EROWS][TN] tile in LDS (16-B chunk swizzle) -> every
     // thread finishes 8 consecutive columns of a row with 16-byte coalesced global accesses
@@ -1130,7 +1147,7 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     if (!A || !B || !C) return AP_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0) return AP_ERR_SHAPE;
     if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N) return AP_ERR_SHAPE;
-    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}};
+    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}, nullptr, nullptr};
     { const char* e = getenv("AP_GEMM_DBG"); if (e) ep.dbg = atoi(e); }
     if (epi) {
         ep.bias = epi->bias; ep.gelu = epi->gelu; ep.preact = epi->preact_out; ep.dgelu_of = epi->dgelu_of;
@@ -1316,6 +1333,26 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     return ap_check_launch();
 }
 
+int ap_gemm_nt_fp8(const unsigned char* A, int lda, const unsigned char* B, int ldb, ap_bf16* C, int ldc, int M, int N, int K,
+                   const float* dq_a, const float* dq_b, const ap_gemm_epilogue* epi, ap_stream_t stream) {
+    if (!A || !B || !C || !dq_a || !dq_b) return AP_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0) return AP_ERR_SHAPE;
+    if ((K & 15) || (lda & 15) || (ldb & 15) || lda < K || ldb < K || ldc < N) return AP_ERR_SHAPE;       // 16-byte chunks of e4m3
+    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}, dq_a, dq_b};
+    if (epi) {
+        ep.bias = epi->bias; ep.gelu = epi->gelu; ep.preact = epi->preact_out; ep.dgelu_of = epi->dgelu_of;
+        ep.row_scale = epi->row_scale; ep.rows_per_scale = epi->rows_per_scale > 0 ? epi->rows_per_scale : 1;
+        ep.residual = epi->residual; ep.ldr = epi->ldr;
+        if (ep.residual && ep.ldr < N) return AP_ERR_SHAPE;
+    }
+    (void)hipGetLastError();
+    const int tm = (M + 127) / 128, tn = (N + 127) / 128, nt = tm * tn;
+    // byte pairs: the kernel's element is 2 bytes
+    hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, false, 1, false, 0, true>), dim3(nt), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const bf16_t*>(A), lda / 2, reinterpret_cast<const bf16_t*>(B), ldb / 2, C, ldc, M, N, K / 2, tn, nt, ep);
+    return ap_check_launch();
+}
+
 static bool patch_map_device(const ap_patch_map* map, PatchMap& pm) {
     if (!map || map->group < 1 || map->kseg < 1) return false;
     pm.group = map->group; pm.gstride = map->group_stride; pm.rstride = map->row_stride; pm.kseg = map->kseg; pm.kstride = map->kseg_stride;
@@ -1328,7 +1365,7 @@ int ap_gemm_nt_patch(const ap_bf16* A, const ap_bf16* B, int ldb, ap_bf16* C, in
                      const float* bias, const ap_patch_map* map, int side, ap_stream_t stream) {
     if (!A || !B || !C || !map) return AP_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (ldb & 7) || ldb < K) return AP_ERR_SHAPE;
-    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}};
+    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}, nullptr, nullptr};
     if (!patch_map_device(map, ep.pm)) return AP_ERR_SHAPE;
     if ((int64_t)M >= (int64_t)(0xFFFFFFFFu / (unsigned)map->group)) return AP_ERR_SHAPE;       // exactness bound of the magic division
     (void)hipGetLastError();

@@ -28,6 +28,7 @@ struct EpiArgs {
     const float* bias; int gelu; bf16_t* preact; const bf16_t* dgelu_of; const float* row_scale;
     int rows_per_scale; const bf16_t* residual; int ldr; int dbg; unsigned long long* stamps;
     PatchMap pm;                // used by the PATCH instantiations of k_gemm_nt only
+    const float* dq_a; const float* dq_b;     // fp8 instantiation: device scalars, accumulators are multiplied by dq_a[0] * dq_b[0] first
 };
 
 // epilogue of 8 consecutive output columns [n, n+8) of row m held in v[] (fp32 accumulators):

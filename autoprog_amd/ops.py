@@ -154,6 +154,46 @@ def gemm_nt(a, b, n=None, k=None, bias=None, gelu=False, preact_out=None, dgelu_
     return out
 
 
+FP8_MAX = 448.0          # OCP e4m3
+
+
+def quantize_fp8(x, scale, amax=None):
+    """bf16 tensor (numel % 16 == 0) -> uint8 tensor of e4m3 bytes, y = sat(x * scale[0]); scale / amax: fp32 device scalars
+    (amax[0] = max(amax[0], max|x|): the statistic the NEXT step's scale is derived from -- delayed scaling)"""
+    _req(x, BF16, "x"); _req(scale, torch.float32, "scale")
+    y = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(lib.ap_quantize_fp8(x.data_ptr(), y.data_ptr(), x.numel(), scale.data_ptr(), amax.data_ptr() if amax is not None else None,
+                              _stream()), "ap_quantize_fp8")
+    return y
+
+
+def quantize_fp8_now(x):
+    """current scaling (one extra pass for the amax): -> (bytes, dequantisation factor as a device scalar)"""
+    amax = x.abs().amax().float().clamp_min(1e-12).reshape(1)
+    return quantize_fp8(x, (FP8_MAX / amax).contiguous()), (amax / FP8_MAX).contiguous()
+
+
+def gemm_nt_fp8(a8, b8, dq_a, dq_b, n=None, bias=None, gelu=False, preact_out=None, residual=None, row_scale=None, rows_per_scale=1):
+    """out[M, :n] = epilogue(dq_a * dq_b * a8 @ b8[:n]^T): a8 [M,K], b8 [>=n,K] uint8 e4m3 bytes (K % 16 == 0), bf16 output"""
+    _req(a8, torch.uint8, "a8"); _req(b8, torch.uint8, "b8")
+    M, K = a8.shape
+    n = b8.shape[0] if n is None else n
+    ldc = round_up(n, 8)
+    out = torch.empty((M, ldc), dtype=BF16, device=a8.device)
+    epi = GemmEpilogue()
+    epi.bias = bias.data_ptr() if bias is not None else None
+    epi.gelu = 1 if gelu else 0
+    epi.preact_out = preact_out.data_ptr() if preact_out is not None else None
+    epi.dgelu_of = None
+    epi.row_scale = row_scale.data_ptr() if row_scale is not None else None
+    epi.rows_per_scale = int(rows_per_scale)
+    epi.residual = residual.data_ptr() if residual is not None else None
+    epi.ldr = residual.shape[1] if residual is not None else 0
+    check(lib.ap_gemm_nt_fp8(a8.data_ptr(), K, b8.data_ptr(), b8.shape[1], out.data_ptr(), ldc, M, n, K, dq_a.data_ptr(), dq_b.data_ptr(),
+                             ctypes.byref(epi), _stream()), "ap_gemm_nt_fp8")
+    return out
+
+
 def gemm_tn_acc(a, b, c, n1=None, n2=None, colsum=None):
     """c[:n1, :n2] += a[:, :n1]^T @ b[:, :n2]   (c fp32, accumulated); optionally colsum[:n1] += a.sum(0)."""
     _req(a, BF16, "a"); _req(b, BF16, "b"); _req(c, torch.float32, "c")

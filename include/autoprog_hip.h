@@ -103,6 +103,13 @@ typedef struct ap_gemm_epilogue {
 } ap_gemm_epilogue;
 int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C, int ldc,
                int M, int N, int K, const ap_gemm_epilogue* epi, ap_stream_t stream);
+/* ---- fp8 forward GEMM (BASELINE configs[4] "mixed MFMA fp8 GEMM"): OCP e4m3 operands, fp32 accumulation, bf16 output.
+ * y = sat(x * scale[0]) -> e4m3, n % 16 == 0; amax (nullable): amax[0] = max(amax[0], max |x|) for the next step's scale */
+int ap_quantize_fp8(const ap_bf16* x, unsigned char* y, int64_t n, const float* scale, float* amax, ap_stream_t stream);
+/* C = epi(dq_a[0] * dq_b[0] * A8 . B8^T): A8 [M,K], B8 [N,K] e4m3 bytes (K, lda, ldb multiples of 16), dq_* device scalars (1/scale);
+ * same epilogue as ap_gemm_nt */
+int ap_gemm_nt_fp8(const unsigned char* A, int lda, const unsigned char* B, int ldb, ap_bf16* C, int ldc, int M, int N, int K,
+                   const float* dq_a, const float* dq_b, const struct ap_gemm_epilogue* epi, ap_stream_t stream);
 /* weight gradient: C[N1,N2] += A[M,N1]^T . B[M,N2]   (fp32 accumulate into C, atomics);
  * optional fused bias gradient: colsum_A[n] += sum_m A[m,n] (NULL to skip) */
 int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* C, int ldc,

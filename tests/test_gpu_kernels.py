@@ -623,3 +623,36 @@ def test_conv7_s2d_fwd_wgrad_vs_torch_fp32(B, R, src):
     ops.conv7_s2d_wgrad(xs, dz, dw)
     refdw = torch.nn.grad.conv2d_weight(img16, (64, 3, 7, 7), dz.float().permute(0, 3, 1, 2), stride=2, padding=3)
     assert rel(dw - 0.25, refdw) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 384, 1152), (4096, 1152, 384), (300, 200, 192)])
+def test_gemm_nt_fp8_vs_dequantised_reference(M, N, K):
+    """ap_quantize_fp8 + ap_gemm_nt_fp8 (BASELINE configs[4] 'mixed MFMA fp8 GEMM'): (a) the quantiser against torch's e4m3 cast of the
+    clamped, scaled input (bit exact) and its amax; (b) the GEMM against an fp32 matmul of the SAME dequantised bytes (the only
+    differences left are the fp32 summation order and the bf16 store: 4e-3 rel-L2), with bias + GELU + stored pre-activation and
+    with a residual; (c) against the un-quantised fp32 product: 6e-2 (e4m3 keeps 3 mantissa bits)."""
+    import torch.nn.functional as F
+    from autoprog_amd import ops
+    torch.manual_seed(M + N)
+    a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda") * 0.1
+    res = torch.randn(M, ops.round_up(N, 8), device="cuda").to(torch.bfloat16)
+    amax = torch.zeros(1, device="cuda")
+    sa = (ops.FP8_MAX / a.float().abs().amax()).reshape(1)
+    a8 = ops.quantize_fp8(a, sa, amax)
+    assert float(amax) == float(a.float().abs().amax())
+    ref8 = (a.float() * sa).clamp(-448, 448).to(torch.float8_e4m3fn)
+    assert torch.equal(a8.view(torch.float8_e4m3fn).float(), ref8.float())
+    w8, dq_w = ops.quantize_fp8_now(w)
+    dq_a = (1.0 / sa).contiguous()
+    a_dq = a8.view(torch.float8_e4m3fn).float() * dq_a
+    w_dq = w8.view(torch.float8_e4m3fn).float() * dq_w
+    h = torch.empty(M, ops.round_up(N, 8), dtype=torch.bfloat16, device="cuda")
+    y = ops.gemm_nt_fp8(a8, w8, dq_a, dq_w, bias=bias, gelu=True, preact_out=h)[:, :N]
+    pre = a_dq @ w_dq.t() + bias
+    assert rel(h[:, :N], pre) < 4e-3
+    assert rel(y, F.gelu(pre.to(torch.bfloat16).float())) < 4e-3
+    y2 = ops.gemm_nt_fp8(a8, w8, dq_a, dq_w, residual=res)[:, :N]
+    assert rel(y2, a_dq @ w_dq.t() + res[:, :N].float()) < 4e-3
+    assert rel(ops.gemm_nt_fp8(a8, w8, dq_a, dq_w)[:, :N], a.float() @ w.float().t()) < 6e-2

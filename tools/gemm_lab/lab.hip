@@ -150,7 +150,7 @@ int main(int argc, char** argv) {
         bf16_t* Cref; CK(hipMalloc(&Cref, (size_t)s.M * ldc * 2));
         CK(hipStreamSynchronize(st));
         auto epi_for = [&](const Set& b) {
-            EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}};
+            EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}, nullptr, nullptr};
             if (bias) ep.bias = d_bias;
             if (gelu) { ep.gelu = 1; ep.preact = b.H; }
             if (dgelu) ep.dgelu_of = b.H;
