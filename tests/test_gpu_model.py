@@ -514,3 +514,33 @@ def test_loss_curve_realistic_init_vs_reference():
     assert dev[0] < 1e-3 and dev[:4].max() < 2.5e-3, dev.tolist()
     assert dev.max() < 2.5e-2, (losses, d["losses"].tolist())
     assert dev.max() < 0.1 * np.abs(d["losses_bf16_autocast"] - d["losses"]).max()
+
+
+def test_hip_stem_eval_and_elastic_resolution_vs_oracle():
+    """The 64-wide HIP stem (conv7 on the space-to-depth image, the two 3x3 convolutions, patch-addressed proj; models/volo.py:342-380)
+    in EVAL mode (running statistics) and with the per-step input resize (main_prog.py:973-974: a 96 px batch fed to a model set to
+    64 px) against the oracle on the resized image.  Outputs <= 3e-2 rel-L2 (bf16 network, as the other full-network checks)."""
+    import torch.nn.functional as F
+    from autoprog_amd.models import create_model
+    torch.manual_seed(3)
+    model = create_model("model_variant", variant="volo_h12_l9", num_classes=40, img_size=224).cuda()
+    with torch.no_grad():                                  # non-trivial running statistics
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    model.eval()
+    arch = R.variant_arch("volo_h12_l9")
+    p = {k: v.detach().double().cpu() for k, v in model.state_dict().items()}
+    x = torch.randn(2, 3, 96, 96, device="cuda")
+    model.set_sample_config(dict(layer_num=9, min_layer_num=9, max_layer_num=9, input_size=64, token_label_size=4))
+    assert model.patch_embed.hip_conv
+    with torch.no_grad():
+        y = model(x)
+    xr = F.interpolate(x.double().cpu(), size=(64, 64), mode="bilinear", align_corners=False)
+    ref = R.volo_forward(p, xr, train=False, **arch)
+    assert rel(y, ref) < 3e-2, rel(y, ref)
+    # the same input through the MIOpen stem: the two stems agree to bf16 accuracy
+    model.patch_embed.hip_conv = False
+    with torch.no_grad():
+        y2 = model(x)
+    assert rel(y, y2) < 2e-2, rel(y, y2)
