@@ -62,8 +62,10 @@ def test_volo_train_eval_vs_reference_golden(tag, variant, classes):
         den += float(g.pow(2).sum())
         if float(g.norm()) > 1e-6:
             worst[name] = float(diff.norm() / g.norm())
-    assert (num / den) ** 0.5 < 0.12, (num / den) ** 0.5
-    bad = {k: v for k, v in worst.items() if v > 0.4}
+    print("volo_full %s: global gradient rel-L2 %.4f; worst tensors %s" % (tag, (num / den) ** 0.5, sorted(((round(v, 3), k) for k, v in worst.items()), reverse=True)[:6]))
+    # measured: global 0.058 (h2_l3) / 0.018 (h2_l6), worst tensors 0.19 / 0.085 (first block's norm1 and the 16-wide MIOpen stem)
+    assert (num / den) ** 0.5 < 0.08, (num / den) ** 0.5
+    bad = {k: v for k, v in worst.items() if v > 0.25}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
     load_sd(model, d, tag)                  # the train forward above updated the BN running stats once more
     model.eval()
