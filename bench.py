@@ -16,6 +16,7 @@ Workloads (--workload):
   stages  BASELINE.json configs[2]: the reference schedule's four stages (l, r) = (9,128) (12,160) (15,192) (18,224) with DropPath
           0 / .033 / .067 / .1 on ONE supernet (elastic depth mask + on-device bilinear resize, main_prog.py:973), a quarter
           of the steps each; --search-mix draws (l, r) uniformly per step instead (supernet search, main_prog.py:1824-1828)
+  d5      BASELINE.json configs[4] in bf16: volo_d5 at 448 px (flash MHSA, head_dim 48), default per-GPU batch 16
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     dominant kernel (k_gemm_nt): algorithmic FLOPs and bytes of its launches in one step / their summed duration,
@@ -204,7 +205,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (scripts/train_autoprog.sh: -b 128)")
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--variant", default="volo_h12_l18")
-    ap.add_argument("--workload", default="d1", choices=["d1", "stages"])
+    ap.add_argument("--workload", default="d1", choices=["d1", "stages", "d5"],
+                    help="d5: BASELINE configs[4] in bf16 -- VOLO-D5 at 448 px (use --batch 8..16); not the default line")
     ap.add_argument("--search-mix", action="store_true", help="stages workload: uniform random (l, r) per step (supernet search)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
@@ -248,7 +250,13 @@ def main():
 
     torch.manual_seed(42 + rank)
     np.random.seed(42 + rank)
-    model = create_model("model_variant", variant=args.variant, drop_path_rate=0.1).to(dev).train()
+    if args.workload == "d5":
+        args.variant, args.res = "volo_d5", 448
+        if args.batch == 128:
+            args.batch = 16
+        model = create_model("volo_d5", img_size=448, drop_path_rate=0.1).to(dev).train()
+    else:
+        model = create_model("model_variant", variant=args.variant, drop_path_rate=0.1).to(dev).train()
     if world > 1:                      # identical initial weights on every rank (DDP broadcast)
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0)
@@ -333,7 +341,7 @@ def main():
     # (reported under config, never part of `value`)
     fwd_bwd_ms = None
     allreduce_ms = None
-    if not args.no_optimizer and args.workload == "d1":
+    if not args.no_optimizer and args.workload in ("d1", "d5"):
         def step_nb():
             reducer.zero_grad()
             loss_fn(model(images), target).backward()
@@ -405,8 +413,11 @@ def main():
             wl = ("BASELINE.json configs[2]: %s supernet over the AutoProg stages (l,r) = %s, %s, batch %d, on-device resize from %d px"
                   % (args.variant, [(s[0], s[1]) for s in STAGES], "uniform random (l,r) per step" if args.search_mix else "a quarter of the steps each", B, res))
         else:
-            wl = "BASELINE.json configs[1]: %s (VOLO-D1) %dpx token-label training step" % (args.variant, res)
-        line = {"metric": "images/sec/GPU (fwd+bwd) VOLO-D1 224px AutoProg step", "value": round(value, 2), "unit": "images/sec",
+            wl = ("BASELINE.json configs[4] in bf16 (no fp8): volo_d5 448px token-label training step, batch %d" % B if args.workload == "d5"
+                  else "BASELINE.json configs[1]: %s (VOLO-D1) %dpx token-label training step" % (args.variant, res))
+        metric = ("images/sec/GPU (fwd+bwd) VOLO-D5 448px token-label step" if args.workload == "d5"
+                  else "images/sec/GPU (fwd+bwd) VOLO-D1 224px AutoProg step")
+        line = {"metric": metric, "value": round(value, 2), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "value_semantics": "whole-job aggregate over n_gpus (per-GPU rate in images_per_sec_per_gpu)",
