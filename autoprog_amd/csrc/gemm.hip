@@ -23,7 +23,12 @@
 #include "common.h"
 #include <type_traits>
 #include "gemm_epi.h"
+#ifndef AP_EXPERIMENTS
+#define AP_EXPERIMENTS 0       // 1: also build the measured-and-rejected kernels (LDS-DMA rings, persistent tiles) and their AP_GEMM_* switches
+#endif
+#if AP_EXPERIMENTS
 #include "gemm_dma.h"
+#endif
 #include <cstdlib>
 #include <cstdio>
 
@@ -366,6 +371,7 @@ k_gemm_nt_skinny(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict
     }
 }
 
+#if AP_EXPERIMENTS
 // ------------------------------------------------------------ gemm_nt, persistent LDS-DMA ring
 // Main forward / input-gradient GEMM for K % 64 == 0 (every Linear of the D1..D5 and DeiT models).
 // Ablation of a non-persistent 256x128 ring kernel on the qkv shape (M 25088, N 1152, K 384; rocprof +
@@ -735,6 +741,8 @@ k_gemm_nt_p(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
 #endif
 }
 
+#endif  // AP_EXPERIMENTS
+
 // ------------------------------------------------------------------------------------ wgrad
 #define TM 64          // tokens per step (MFMA reduction)
 __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
@@ -1027,6 +1035,7 @@ k_tn_reduce(TnGroup grp) {
     }
 }
 
+#if AP_EXPERIMENTS
 // --------------------------------------------------------------------- wgrad, LDS-DMA ring
 // Same reduction as k_gemm_tn for the full 64-token steps of [0, M - M%64): 8 waves (2 x 4, wave tile
 // 64 x 32), operand tiles [64 tok][128] filled by global_load_lds into a 4-stage ring (128 KB), three
@@ -1140,6 +1149,8 @@ k_gemm_tn_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
         }
 }
 
+#endif  // AP_EXPERIMENTS
+
 extern "C" {
 
 int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C, int ldc, int M, int N, int K,
@@ -1165,6 +1176,7 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         hipLaunchKernelGGL(k_gemm_nt_skinny, dim3((N + 31) / 32, (M + 63) / 64), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, ep);
         return ap_check_launch();
     }
+#if AP_EXPERIMENTS
     // LDS-DMA ring kernels of gemm_dma.h (round-2 lab, profiles/r02_gemm_lab.txt): AP_GEMM_NT_DMA=1 routes plain / bias-only launches
     // with N % 192 == 0 and K % 64 == 0 to the persistent 256x192 tile (up to 8 % faster than the kernel below on cold operands
     // for N = 192 / 384, slower with epilogue operands: its direct epilogue reads them in 64-byte row segments).  Default off.
@@ -1260,6 +1272,7 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
 #endif
         return ap_check_launch();
     }
+#endif  // AP_EXPERIMENTS
     // tile selection (measured on the VOLO-D1 shape list, tools/bench_gemm.py): AP_GEMM_NT_TILE forces a variant
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("AP_GEMM_NT_TILE"); forced = e ? atoi(e) : 0; }
@@ -1388,9 +1401,11 @@ int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* 
     if (M <= 0 || N1 <= 0 || N2 <= 0) return AP_ERR_SHAPE;
     if ((lda & 7) || (ldb & 7) || lda < N1 || ldb < N2 || ldc < N2) return AP_ERR_SHAPE;
     const int t1 = (N1 + 127) / 128, t2 = (N2 + 127) / 128;
+    int full_steps = 0;
+#if AP_EXPERIMENTS
     static int tn_old = -1;
     if (tn_old < 0) { const char* e = getenv("AP_GEMM_TN_RING"); tn_old = (e && e[0] == '1') ? 0 : 1; }   // ring variant lost to the multi-workgroup kernel
-    const int full_steps = tn_old ? 0 : M / TM;
+    full_steps = tn_old ? 0 : M / TM;
     if (full_steps > 0) {
         // ring kernel over the full 64-token steps: ~1 workgroup per CU, >= 8 steps per workgroup
         int splits = (256 + t1 * t2 - 1) / (t1 * t2);
@@ -1406,6 +1421,7 @@ int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* 
         const int rc = ap_check_launch();
         if (rc != AP_OK) return rc;
     }
+#endif
     const int done = full_steps * TM;
     if (done < M) {                                   // token tail (or everything when the ring is disabled)
         const int Mt = M - done;

@@ -13,7 +13,8 @@
  *   - bf16 tensors are passed as uint16_t*, row-major, leading dimension in ELEMENTS and a
  *     multiple of 8 (16-byte rows); fp32 statistics / parameters / gradients are float*
  *   - return 0 on success, a negative AP_ERR_* otherwise (no exceptions cross the ABI)
- *   - entry points are re-entrant and thread-compatible (no global mutable state)
+ *   - entry points are re-entrant and thread-compatible; the only process-wide state is a handful of tuning switches
+ *     (AP_* environment variables, each read once into a function-local static) and one-time hipFuncSetAttribute calls
  */
 #ifndef AUTOPROG_HIP_H
 #define AUTOPROG_HIP_H

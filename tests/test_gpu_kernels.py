@@ -453,16 +453,24 @@ def test_bn_relu_fused(ops, B, H, W, C):
     assert rel(ye, torch.relu(bn(x.double().permute(0, 3, 1, 2))).permute(0, 2, 3, 1)) < TOL_BF16
 
 
-@pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_GEMM_NT_DMA": "1"}, {"AP_GEMM_NT_DMA": "3"}, {"AP_GEMM_NT_P": "1"}, {"AP_GEMM_NT_P": "4"}, {"AP_GEMM_NT_RING": "1"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"},
-                                 {"AP_GEMM_TN_RING": "1"}, {"AP_ASYNC_WGRAD": "1"}])
+@pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"}, {"AP_OUTLOOK_MFMA": "0"},
+                                 {"AP_STEM_HIP_CONV": "0"}, {"AP_ASYNC_WGRAD": "1"}])
 def test_experimental_kernel_paths_stay_parity_green(env):
     """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:
     re-run the GEMM / block tests in a child process with the switch set (the switches are read once per process)"""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     key = next(iter(env))
-    sel = "test_mhsa" if "MHSA" in key else ("gemm and not experimental" if "WGRAD" not in key else "vs_reference_golden or grad_sink")
-    files = ["tests/test_gpu_kernels.py"] if "WGRAD" not in key else ["tests/test_gpu_blocks.py", "tests/test_gpu_model.py"]
+    if "MHSA" in key:
+        sel, files = "test_mhsa", ["tests/test_gpu_kernels.py"]
+    elif "OUTLOOK" in key:
+        sel, files = "outlook", ["tests/test_gpu_kernels.py", "tests/test_gpu_blocks.py"]
+    elif "STEM" in key:
+        sel, files = "d1_shapes or hip_stem or patch_embed", ["tests/test_gpu_model.py", "tests/test_gpu_blocks.py"]
+    elif "WGRAD" in key:
+        sel, files = "vs_reference_golden or grad_sink", ["tests/test_gpu_blocks.py", "tests/test_gpu_model.py"]
+    else:
+        sel, files = "gemm and not experimental", ["tests/test_gpu_kernels.py"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", sel] + files, cwd=root, env=dict(os.environ, **env),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]

@@ -535,7 +535,7 @@ def test_hip_stem_eval_and_elastic_resolution_vs_oracle():
     p = {k: v.detach().double().cpu() for k, v in model.state_dict().items()}
     x = torch.randn(2, 3, 96, 96, device="cuda")
     model.set_sample_config(dict(layer_num=9, min_layer_num=9, max_layer_num=9, input_size=64, token_label_size=4))
-    assert model.patch_embed.hip_conv
+    model.patch_embed.hip_conv = True          # (AP_STEM_HIP_CONV=0 runs of the suite flip the default)
     with torch.no_grad():
         y = model(x)
     xr = F.interpolate(x.double().cpu(), size=(64, 64), mode="bilinear", align_corners=False)
