@@ -121,3 +121,37 @@ def test_layernorm_shift_invariance_and_samples(ops):
         rows = torch.randint(0, T, (64,), device="cuda")
         ref = torch.nn.functional.layer_norm(x[rows].double(), (C,), g.double(), b.double(), 1e-5)
         assert rel(y[rows], ref) < 1e-2
+
+
+def test_d1_b128_forward_vs_oracle_on_an_image_slice():
+    """End to end at the BASELINE size: volo_h12_l18 (VOLO-D1), 224 px, batch 128, eval mode (running BatchNorm statistics, so the
+    samples are independent) -- the fused logits of 8 of the 128 images against the oracle run on those 8 images alone.  Then one
+    full-size training step on the same batch: finite loss near ln(1000) and finite, non-zero gradients in every parameter."""
+    import numpy as np
+    from oracle import ref_cpu as R
+    from autoprog_amd.models import create_model
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    torch.manual_seed(11)
+    model = create_model("model_variant", variant="volo_h12_l18", num_classes=1000, img_size=224, drop_path_rate=0.1).cuda()
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.8, 1.2)
+    x = torch.randn(128, 3, 224, 224, device="cuda")
+    model.eval()
+    with torch.no_grad():
+        y = model(x)
+    idx = [0, 17, 33, 64, 65, 99, 126, 127]
+    p = {k: v.detach().double().cpu() for k, v in model.state_dict().items()}
+    ref = R.volo_forward(p, x[idx].double().cpu(), train=False, **R.variant_arch("volo_h12_l18"))
+    err = float((y[idx].double().cpu() - ref).norm() / ref.norm())
+    assert err < 3e-2, err
+    model.train()
+    g = torch.Generator().manual_seed(1)
+    target = torch.softmax(torch.randn(128, 1000, 198, generator=g) * 3, dim=1).cuda()
+    np.random.seed(0)
+    loss = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=1000)(model(x), target)
+    loss.backward()
+    assert torch.isfinite(loss) and 6.0 < float(loss) < 14.0, float(loss)
+    for n, q in model.named_parameters():
+        assert q.grad is not None and torch.isfinite(q.grad).all() and float(q.grad.abs().max()) > 0, n
