@@ -19,6 +19,9 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef AP_EXPERIMENTS
+#define AP_EXPERIMENTS 0
+#endif
 #define CV_C 64
 #define CV_TR 32                  // tile rows
 #define CV_TW 16                  // tile columns (one MFMA fragment of 16 pixels per row)
@@ -450,11 +453,13 @@ int ap_conv3x3_c64(const ap_bf16* x, const ap_bf16* w_packed, ap_bf16* y, int B,
         attr_done = 1;
     }
     const int grid = cv_grid(ntiles);
+#if AP_EXPERIMENTS             // ablation instantiations (DESIGN.md "Convolution kernels, by ablation"): make EXTRA=-DAP_EXPERIMENTS=1, AP_CONV_ABL=bits
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("AP_CONV_ABL"); abl = e ? atoi(e) : 0; }
 #define CV_ABL_LAUNCH(A) case A: hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64<false, A>), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES); \
         hipLaunchKernelGGL((k_conv3x3_c64<false, A>), dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats); return ap_check_launch();
     switch (abl) { CV_ABL_LAUNCH(1) CV_ABL_LAUNCH(2) CV_ABL_LAUNCH(3) CV_ABL_LAUNCH(4) CV_ABL_LAUNCH(7) CV_ABL_LAUNCH(8) CV_ABL_LAUNCH(11) default: break; }
+#endif
     if (stats) hipLaunchKernelGGL((k_conv3x3_c64<true>), dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats);
     else hipLaunchKernelGGL((k_conv3x3_c64<false>), dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats);
     return ap_check_launch();
