@@ -22,50 +22,62 @@ k_soft_ce(const bf16_t* __restrict__ logits, int ldx, const float* __restrict__ 
     const int64_t b = blockIdx.x / tiles_per_batch;
     const int n0 = (blockIdx.x % tiles_per_batch) * CE_TN;
     const int ntok = min(CE_TN, rows_per_batch - n0);
+    // the logits of this wave's (up to) four rows are requested FIRST: they do not depend on the target tile, so their latency hides
+    // behind phase A (clamped, unconditional 4-byte loads; columns beyond C are masked where they are used)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned lraw[CE_TN / 4][CE_MAXV];
+#pragma unroll
+    for (int r = 0; r < CE_TN / 4; ++r) {
+        const int64_t rowc = min(b * rows_per_batch + n0 + min(wave + 4 * r, ntok - 1), M - 1);
+        const bf16_t* xr = logits + rowc * ldx;
+#pragma unroll
+        for (int i = 0; i < CE_MAXV; ++i) lraw[r][i] = *reinterpret_cast<const unsigned*>(xr + min(2 * (lane + 64 * i), ldx - 2));
+    }
     // ---- phase A: target tile -> LDS (token-major)
     {
         const int tn = threadIdx.x & (CE_TN - 1), cl = threadIdx.x / CE_TN;     // 16 classes per pass
-        const float* tb = target + b * t_sb + (int64_t)(n0 + tn) * t_sn;
+        const int tnc = min(tn, ntok - 1);                                       // lanes beyond the tile's tokens read a valid token (never stored)
+        const float* tb = target + b * t_sb + (int64_t)(n0 + tnc) * t_sn;
         // mix-token: the image-level label of sample b is lam * t[b] + (1 - lam) * t[B-1-b] (loss/cross_entropy.py:151-152)
-        const float* tb2 = mix_batches > 0 ? target + (int64_t)(mix_batches - 1 - b) * t_sb + (int64_t)(n0 + tn) * t_sn : tb;
+        const float* tb2 = mix_batches > 0 ? target + (int64_t)(mix_batches - 1 - b) * t_sb + (int64_t)(n0 + tnc) * t_sn : tb;
         const float lam2 = mix_batches > 0 ? 1.0f - mix_lam : 0.f, lam1 = mix_batches > 0 ? mix_lam : 1.0f;
-        // 8 independent loads in flight per thread (the one-load-per-iteration loop waited a full memory latency 63 times)
+        // CE_INFLIGHT independent loads in flight per thread: the tile is 63 four-byte loads per thread, and every batch exposes one memory
+        // latency (one load per iteration: 63 latencies; 8 per batch: 8; 32 per batch: 2)
         constexpr int CSTEP = 256 / CE_TN;
-        for (int c0 = cl; c0 < C; c0 += 8 * CSTEP) {
-            float v[8];
+        constexpr int CE_INFLIGHT = 32;
+        const bool mixed = mix_batches > 0;
+        for (int c0 = cl; c0 < C; c0 += CE_INFLIGHT * CSTEP) {
+            float v[CE_INFLIGHT], v2[CE_INFLIGHT];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c = c0 + u * CSTEP;
-                v[u] = (tn < ntok && c < C) ? lam1 * tb[(int64_t)c * t_sc] + lam2 * tb2[(int64_t)c * t_sc] : 0.f;
+            for (int u = 0; u < CE_INFLIGHT; ++u) {
+                const int c = min(c0 + u * CSTEP, C - 1);                       // clamped: unconditional loads (no exec-masked blocks)
+                v[u] = tb[(int64_t)c * t_sc];
+                v2[u] = mixed ? tb2[(int64_t)c * t_sc] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < CE_INFLIGHT; ++u) {
                 const int c = c0 + u * CSTEP;
-                if (tn < ntok && c < C) tt[tn * Cp + c] = v[u];
+                if (tn < ntok && c < C) tt[tn * Cp + c] = lam1 * v[u] + lam2 * v2[u];
             }
         }
     }
     __syncthreads();
     // ---- phase B
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int tn = wave; tn < ntok; tn += 4) {
+#pragma unroll
+    for (int r = 0; r < CE_TN / 4; ++r) {
+        const int tn = wave + 4 * r;
         const int64_t row = b * rows_per_batch + n0 + tn;
-        if (row >= M) break;
-        const bf16_t* xr = logits + row * ldx;
+        if (tn >= ntok || row >= M) break;
         const float* tr = tt + tn * Cp;
         float xv[CE_MAXV][2];
         float mx = -3.0e38f;
 #pragma unroll
         for (int i = 0; i < CE_MAXV; ++i) {
             const int c = 2 * (lane + 64 * i);
-            if (c + 1 < C) {
-                const unsigned u = *reinterpret_cast<const unsigned*>(xr + c);
-                xv[i][0] = bf_lo(u); xv[i][1] = bf_hi(u);
-                mx = fmaxf(mx, fmaxf(xv[i][0], xv[i][1]));
-            } else if (c < C) {
-                xv[i][0] = bf2f(xr[c]); xv[i][1] = -3.0e38f;
-                mx = fmaxf(mx, xv[i][0]);
-            } else { xv[i][0] = -3.0e38f; xv[i][1] = -3.0e38f; }
+            const unsigned u = lraw[r][i];
+            xv[i][0] = c < C ? bf_lo(u) : -3.0e38f;
+            xv[i][1] = c + 1 < C ? bf_hi(u) : -3.0e38f;
+            mx = fmaxf(mx, fmaxf(xv[i][0], xv[i][1]));
         }
         mx = group_max<64>(mx);
         float se = 0.f, st = 0.f, stx = 0.f;
