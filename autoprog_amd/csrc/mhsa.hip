@@ -164,28 +164,29 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
     const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
     const bf16_t* obase = out + (int64_t)b * N * C + h * HD;
     const bf16_t* gbase = dout + (int64_t)b * N * C + h * HD;
+    // delta = rowsum(dO * O) and the scaled lse.  The loads of the first sweep (the only one at head_dim 32) are issued BEFORE the
+    // operand staging, so that the workgroup exposes ONE memory latency instead of two
+    constexpr int DIT = 2;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    u32x4 va0[DIT], vd0[DIT];
+    float ls0[DIT];
+#pragma unroll
+    for (int it = 0; it < DIT; ++it) {
+        const int idx = threadIdx.x + it * 512;
+        const int row = idx / CH, c = idx % CH;
+        const bool ok = idx < Npad * CH && row < N;
+        va0[it] = ok ? ld16(obase + (int64_t)row * C + c * 8) : zero4;
+        vd0[it] = ok ? ld16(gbase + (int64_t)row * C + c * 8) : zero4;
+        ls0[it] = (ok && c == 0) ? lse[((int64_t)b * heads + h) * N + row] : 0.f;
+    }
     {
         bf16_t* tiles[4] = {Qs, Ks, Vs, Gs};
         const bf16_t* srcs[4] = {base, base + C, base + 2 * C, gbase};
         const int64_t strides[4] = {ld, ld, ld, (int64_t)C};
         att_stage_n<HD, 4, 2>(tiles, srcs, strides, N, Npad);
     }
-    // delta = rowsum(dO * O) and the scaled lse: both iterations' loads are issued before anything is reduced
     {
-        constexpr int DIT = 2;
-        const u32x4 zero4 = {0u, 0u, 0u, 0u};
-        for (int idx0 = threadIdx.x; idx0 < Npad * CH; idx0 += DIT * 512) {     // Npad*CH is a multiple of 128: whole waves
-            u32x4 va[DIT], vd[DIT];
-            float ls[DIT];
-#pragma unroll
-            for (int it = 0; it < DIT; ++it) {
-                const int idx = idx0 + it * 512;
-                const int row = idx / CH, c = idx % CH;
-                const bool ok = idx < Npad * CH && row < N;
-                va[it] = ok ? ld16(obase + (int64_t)row * C + c * 8) : zero4;
-                vd[it] = ok ? ld16(gbase + (int64_t)row * C + c * 8) : zero4;
-                ls[it] = (ok && c == 0) ? lse[((int64_t)b * heads + h) * N + row] : 0.f;
-            }
+        auto reduce_rows = [&](int idx0, const u32x4* va, const u32x4* vd, const float* ls) {
 #pragma unroll
             for (int it = 0; it < DIT; ++it) {
                 const int idx = idx0 + it * 512;
@@ -204,6 +205,21 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
                     fl[row] = (row < N) ? ls[it] * 1.4426950408889634f : 1.0e30f;
                 }
             }
+        };
+        reduce_rows(threadIdx.x, va0, vd0, ls0);
+        for (int idx0 = threadIdx.x + DIT * 512; idx0 < Npad * CH; idx0 += DIT * 512) {     // head_dim 64: a second sweep (Npad*CH is a multiple of 128: whole waves)
+            u32x4 va[DIT], vd[DIT];
+            float ls[DIT];
+#pragma unroll
+            for (int it = 0; it < DIT; ++it) {
+                const int idx = idx0 + it * 512;
+                const int row = idx / CH, c = idx % CH;
+                const bool ok = idx < Npad * CH && row < N;
+                va[it] = ok ? ld16(obase + (int64_t)row * C + c * 8) : zero4;
+                vd[it] = ok ? ld16(gbase + (int64_t)row * C + c * 8) : zero4;
+                ls[it] = (ok && c == 0) ? lse[((int64_t)b * heads + h) * N + row] : 0.f;
+            }
+            reduce_rows(idx0, va, vd, ls);
         }
     }
     __syncthreads();
