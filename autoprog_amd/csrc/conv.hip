@@ -272,6 +272,9 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
 //   output    : every workgroup STORES its partial 9 x 64 x 64 sums to its own slab; k_conv3x3_wgrad_reduce adds the slabs in
 //               order into dW (fp32 OIHW, +=): no atomics, bit-reproducible
 #define CW_T 16
+#ifndef CW_PTR
+#define CW_PTR 16
+#endif
 #define CW_PW (CW_T + 2)
 #define CW_DPIX (CW_T * CW_T)
 #define CW_APIX (CW_PW * CW_PW)
@@ -373,6 +376,125 @@ k_conv3x3_c64_wgrad(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
         __syncthreads();
     }
     // partial sums: slab[wg][tap][co][ci]; lane holds co = 16 tq + 4 g + r, ci = 16 wave + fr
+    float* mine = slab + (int64_t)blockIdx.x * CV_WELEMS;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                mine[(tap * CV_C + 16 * tq + 4 * g + r) * CV_C + 16 * wave + fr] = acc[tap][tq][r];
+}
+
+// The same reduction with ONE workgroup per CU and the whole register file behind it (the default; AP_CONV_WGRAD_P=0 selects the kernel
+// above): the next tile's dy tile and input patch are loaded into registers (19 x 16 B per thread) while the current one is computed,
+// and the fragments of K step k+1 are read from LDS while the MFMAs of step k issue.  The two-workgroup kernel cannot afford either
+// next to its 144 accumulators and spends 74 % of its wave time waiting.  208 -> 151 us at B = 128, 112 x 112 (16-row tiles; 32-row
+// tiles spill and take 177); half the slabs, too.
+template <int TR>
+__global__ void __launch_bounds__(256)
+k_conv3x3_c64_wgrad_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ slab, int H, int W,
+                      int tiles_x, int tiles_y, int ntiles) {
+    constexpr int DPIX = TR * CW_T, APIX = (TR + 2) * CW_PW;
+    constexpr int ND = DPIX * 8 / 256, NA = (APIX * 8 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) bf16_t cw_smem[];
+    bf16_t* D = cw_smem;                        // [TR*16 px][64 co]
+    bf16_t* A = cw_smem + DPIX * CV_C;          // [(TR+2)*18 px][64 ci]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4, q = fr >> 2, p = fr & 3;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const int c8 = (tid & 7) * 8, cidx = tid & 7;
+    int dbase[4][2], abase[3][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int col = 8 * (g & 1) + q + 4 * hf;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            dbase[t][hf] = ((g >> 1) * CW_T + col) * CV_C + (((2 * t + (p >> 1)) ^ cw_key(col)) << 3) + (p & 1) * 4;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int pc = col + dx;
+            abase[dx][hf] = ((g >> 1) * CW_PW + pc) * CV_C + (((2 * wave + (p >> 1)) ^ cw_key(pc)) << 3) + (p & 1) * 4;
+        }
+    }
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    auto trfrag = [&](const bf16_t* base0, const bf16_t* base1) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base1));
+        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    u32x4 rd[ND], ra[NA];
+    auto origin = [&](int t, int& b, int& ty0, int& tx0) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
+        b = t / (tiles_x * tiles_y); ty0 = ty * TR; tx0 = tx * CW_T;
+    };
+    int tl = tid >> 3;                               // laundered per tile (see k_conv3x3_c64): keeps per-chunk offsets out of long-lived registers
+    auto gload = [&](int t) {
+        int b, ty0, tx0;
+        origin(t, b, ty0, tx0);
+        const bf16_t* ximg = x + (int64_t)b * H * W * CV_C;
+        const bf16_t* dimg = dy + (int64_t)b * H * W * CV_C;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int px = tl + 32 * i, r = px >> 4, c = px & 15;
+            const int gy = min(ty0 + r, H - 1), gx = min(tx0 + c, W - 1);
+            rd[i] = ld16(dimg + (unsigned)((gy * W + gx) * CV_C + c8));
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int px = min(tl + 32 * i, APIX - 1), r = (px * 3641) >> 16, c = px - r * CW_PW;     // px / 18 (exact below 1170)
+            const int gy = min(max(ty0 - 1 + r, 0), H - 1), gx = min(max(tx0 - 1 + c, 0), W - 1);
+            ra[i] = ld16(ximg + (unsigned)((gy * W + gx) * CV_C + c8));
+        }
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) gload(t);
+    for (; t < ntiles; t += gridDim.x) {
+        int b, ty0, tx0;
+        origin(t, b, ty0, tx0);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int px = (tid >> 3) + 32 * i, r = px >> 4, c = px & 15;
+            st16(D + px * CV_C + ((cidx ^ cw_key(c)) << 3), ((ty0 + r < H) && (tx0 + c < W)) ? rd[i] : zero4);
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int px = (tid >> 3) + 32 * i, r = (px * 3641) >> 16, c = px - r * CW_PW;
+            const unsigned gy = (unsigned)(ty0 - 1 + r), gx = (unsigned)(tx0 - 1 + c);
+            if (px < APIX) st16(A + px * CV_C + ((cidx ^ cw_key(c)) << 3), (gy < (unsigned)H && gx < (unsigned)W) ? ra[i] : zero4);
+        }
+        __syncthreads();
+        asm volatile("" : "+v"(tl));
+        if (t + (int)gridDim.x < ntiles) gload(t + gridDim.x);          // in flight during the MFMA steps below
+        // K steps (tile rows 2k, 2k+1 = 32 pixels), fully unrolled with the fragments of step k+1 read from LDS while the 36 MFMAs of
+        // step k issue (one wave per SIMD: nothing else hides the LDS latency); fences keep the two-stage pipeline as written
+        bf16x8 df[2][4], af[2][9];
+        auto fload = [&](int k, bf16x8* dfr, bf16x8* afr) {
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) dfr[tq] = trfrag(D + dbase[tq][0] + 2 * k * CW_T * CV_C, D + dbase[tq][1] + 2 * k * CW_T * CV_C);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dyy = tap / 3, dxx = tap - 3 * dyy;
+                afr[tap] = trfrag(A + abase[dxx][0] + (2 * k + dyy) * CW_PW * CV_C, A + abase[dxx][1] + (2 * k + dyy) * CW_PW * CV_C);
+            }
+        };
+        fload(0, df[0], af[0]);
+#pragma unroll
+        for (int k = 0; k < TR / 2; ++k) {
+            if (k + 1 < TR / 2) fload(k + 1, df[(k + 1) & 1], af[(k + 1) & 1]);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int tq = 0; tq < 4; ++tq) acc[tap][tq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[k & 1][tq], af[k & 1][tap], acc[tap][tq], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
     float* mine = slab + (int64_t)blockIdx.x * CV_WELEMS;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -485,13 +607,27 @@ int ap_conv3x3_c64_wgrad(const ap_bf16* x, const ap_bf16* dy, float* dw_oihw, in
     const int64_t nt64 = (int64_t)B * tiles_x * tiles_y;
     if (nt64 > 0x7fffffff) return AP_ERR_SHAPE;
     if (ws_bytes < ap_conv3x3_c64_wgrad_workspace(B, H, W)) return AP_ERR_SHAPE;
-    const int ntiles = (int)nt64, grid = cw_grid(ntiles);
+    int ntiles = (int)nt64, grid = cw_grid(ntiles);
     static int attr_done = 0;
     (void)hipGetLastError();
+    constexpr int PTR = CW_PTR;
+    constexpr int P_LDS = (PTR * CW_T + (PTR + 2) * CW_PW) * CV_C * 2;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES) != hipSuccess) return AP_ERR_LAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64_wgrad_p<PTR>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS) != hipSuccess) return AP_ERR_LAUNCH;
         attr_done = 1;
     }
+    static int use_p = -1;
+    if (use_p < 0) { const char* e = getenv("AP_CONV_WGRAD_P"); use_p = e ? atoi(e) : 1; }
+    if (use_p) {                // one prefetching workgroup per CU, 32 x 16 tiles
+        const int tyy = (H + PTR - 1) / PTR;
+        const int64_t np = (int64_t)B * tiles_x * tyy;
+        ntiles = (int)np;
+        const int gp = ntiles < 256 ? ntiles : 256;
+        if ((size_t)gp * CV_WELEMS * sizeof(float) > ws_bytes) return AP_ERR_SHAPE;
+        grid = gp;
+        hipLaunchKernelGGL((k_conv3x3_c64_wgrad_p<PTR>), dim3(grid), dim3(256), P_LDS, (hipStream_t)stream, x, dy, static_cast<float*>(workspace), H, W, tiles_x, tyy, ntiles);
+    } else
     hipLaunchKernelGGL(k_conv3x3_c64_wgrad, dim3(grid), dim3(256), CW_LDS_BYTES, (hipStream_t)stream, x, dy, static_cast<float*>(workspace), H, W, tiles_x, tiles_y, ntiles);
     int rc = ap_check_launch();
     if (rc != AP_OK) return rc;
