@@ -196,12 +196,18 @@ k_conv7_s2d_wgrad(const bf16_t* __restrict__ xs, const bf16_t* __restrict__ dz, 
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int c8 = (tid & 7) * 8, cidx = tid & 7;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
-        const int ty0 = ty * SW_T, tx0 = tx * SW_T;
+    // the next tile's loads are in flight during the MFMA steps of the current one, and the fragments of K step k+1 are read while
+    // the MFMAs of step k issue (as k_conv3x3_c64_wgrad_p)
+    u32x4 rd[8], ra[3];
+    auto origin = [&](int t, int& b, int& ty0, int& tx0) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
+        b = t / (tiles_x * tiles_y); ty0 = ty * SW_T; tx0 = tx * SW_T;
+    };
+    auto gload = [&](int t) {
+        int b, ty0, tx0;
+        origin(t, b, ty0, tx0);
         const bf16_t* ximg = xs + (int64_t)b * H * W * S_CI;
         const bf16_t* dimg = dz + (int64_t)b * H * W * S_CO;
-        u32x4 rd[8], ra[3];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int px = (tid >> 3) + 32 * i, r = px >> 4, c = px & 15;
@@ -214,7 +220,13 @@ k_conv7_s2d_wgrad(const bf16_t* __restrict__ xs, const bf16_t* __restrict__ dz, 
             const int gy = min(max(ty0 - 2 + r, 0), H - 1), gx = min(max(tx0 - 2 + c, 0), W - 1);
             ra[i] = ld16(ximg + (unsigned)((gy * W + gx) * S_CI + (ch & 1) * 8));
         }
-        __syncthreads();
+    };
+    int t = blockIdx.x;
+    if (t < ntiles) gload(t);
+    for (; t < ntiles; t += gridDim.x) {
+        int b, ty0, tx0;
+        origin(t, b, ty0, tx0);
+        __syncthreads();                         // the previous tile's fragment reads are done
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int px = (tid >> 3) + 32 * i, r = px >> 4, c = px & 15;
@@ -227,17 +239,23 @@ k_conv7_s2d_wgrad(const bf16_t* __restrict__ xs, const bf16_t* __restrict__ dz, 
             if (px < SW_APIX) st16(A + px * S_CI + (ch & 1) * 8, (gy < (unsigned)H && gx < (unsigned)W) ? ra[i] : zero4);
         }
         __syncthreads();
+        if (t + (int)gridDim.x < ntiles) gload(t + gridDim.x);
+        bf16x8 df[2][4], af[2][4];
+        auto fload = [&](int k, bf16x8* dfr, bf16x8* afr) {
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) dfr[tq] = trfrag(D + dbase[tq][0] + 2 * k * SW_T * S_CO, D + dbase[tq][1] + 2 * k * SW_T * S_CO);
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) afr[dx] = trfrag(A + abase[dx][0] + 2 * k * SW_PW * S_CI, A + abase[dx][1] + 2 * k * SW_PW * S_CI);
+        };
+        fload(0, df[0], af[0]);
 #pragma unroll
         for (int k = 0; k < SW_T / 2; ++k) {
-            bf16x8 df[4];
+            if (k + 1 < SW_T / 2) fload(k + 1, df[(k + 1) & 1], af[(k + 1) & 1]);
 #pragma unroll
-            for (int tq = 0; tq < 4; ++tq) df[tq] = trfrag(D + dbase[tq][0] + 2 * k * SW_T * S_CO, D + dbase[tq][1] + 2 * k * SW_T * S_CO);
+            for (int dx = 0; dx < 4; ++dx)
 #pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-                const bf16x8 af = trfrag(A + abase[dx][0] + 2 * k * SW_PW * S_CI, A + abase[dx][1] + 2 * k * SW_PW * S_CI);
-#pragma unroll
-                for (int tq = 0; tq < 4; ++tq) acc[dx][tq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[tq], af, acc[dx][tq], 0, 0, 0);
-            }
+                for (int tq = 0; tq < 4; ++tq) acc[dx][tq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[k & 1][tq], af[k & 1][dx], acc[dx][tq], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // slab[wg][tap = 4 dy + dx][co][c16]; lane holds co = 16 tq + 4 g + r, c16 = fr
