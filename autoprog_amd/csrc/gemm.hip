@@ -794,6 +794,13 @@ struct TnArgs {
 struct TnDet { float* slab; float* cs_slab; };
 #define TN_MAX_GROUP 8
 struct TnGroup { TnArgs p[TN_MAX_GROUP]; int count; };
+// Placement of a grouped launch: entry b = (problem << 12 | split * tiles + tile) of workgroup b, TN_MAP_IDLE = none.  Workgroup
+// b runs on XCD b % 8, so the host puts ALL output tiles of one (problem, token split) on one XCD: that split's operand slab is
+// then fetched through ONE L2 instead of the 1.5-2 that a contiguous id range per XCD gives when 5 splits meet 8 XCDs
+// (transformer block: 486 MB of beyond-L2 traffic per launch for 270 MB of operands before).
+#define TN_MAP_MAX 1024
+#define TN_MAP_IDLE 0xFFFFu
+struct TnMap { unsigned short e[TN_MAP_MAX]; };
 
 template <bool BPATCH = false>
 __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
@@ -804,7 +811,7 @@ __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, c
     // XCD-aware decode: workgroups that share an XCD (and its L2) get consecutive ids, i.e. all output
     // tiles of the SAME token split, so each token range is fetched from HBM by one L2 only
     // (before: 347 MB of beyond-L2 traffic for 77 MB of operands on the qkv shape)
-    const int id = xcd_remap(block, nblocks);
+    const int id = nblocks > 0 ? xcd_remap(block, nblocks) : block;        // nblocks <= 0: `block` is already split * tiles + tile (TnMap)
     const int bz = id / (t1 * t2), tl = id - bz * (t1 * t2);
     const int by = tl / t1, bx = tl - by * t1;
     const int n0 = bx * 128, k0 = by * 128;
@@ -1002,6 +1009,17 @@ k_gemm_tn_grouped(TnGroup grp) {
     const TnArgs& a = grp.p[pi];
     tn_tile(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N1, a.N2, a.steps_per_split, a.colsum, a.t1, a.t2, a.nblocks,
             (int)blockIdx.x - a.start, sA, sB, a.cs_weight, a.cs_scale, a.slab, a.splits, a.alpha);
+}
+// the same with the host-made placement table (one (problem, split) per XCD)
+__global__ void __launch_bounds__(256)
+k_gemm_tn_grouped_map(TnGroup grp, TnMap map) {
+    __shared__ __attribute__((aligned(16))) bf16_t sA[TM * 128];
+    __shared__ __attribute__((aligned(16))) bf16_t sB[TM * 128];
+    const unsigned e = map.e[blockIdx.x];
+    if (e == TN_MAP_IDLE) return;
+    const TnArgs& a = grp.p[e >> 12];
+    tn_tile(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N1, a.N2, a.steps_per_split, a.colsum, a.t1, a.t2, 0,
+            (int)(e & 0xFFFu), sA, sB, a.cs_weight, a.cs_scale, a.slab, a.splits, a.alpha);
 }
 
 // one weight gradient whose B rows are patches of an NHWC feature map (PatchMap): a k x k / stride k convolution's dW
@@ -1510,6 +1528,37 @@ static int tn_plan(const ap_tn_problem* problems, int count, TnGroup& grp, int& 
     return AP_OK;
 }
 
+// One (problem, token split) = one XCD: greedy packing of the groups, largest first, onto the least loaded of the 8 XCDs; the
+// launch is 8 * (largest load) workgroups, the unused ids return at once.  false = does not fit the table or the resident capacity
+// (more than `cap` slots per XCD would start a second round of workgroups): the caller keeps the contiguous-range placement.
+static bool tn_place(const TnGroup& grp, int cap, TnMap& map, int& blocks) {
+    struct G { int p, s, n; };
+    G g[TN_MAP_MAX]; int ng = 0;
+    for (int i = 0; i < grp.count; ++i) {
+        const int tiles = grp.p[i].t1 * grp.p[i].t2;
+        if (tiles * grp.p[i].splits > 0x1000) return false;
+        for (int s = 0; s < grp.p[i].splits; ++s) { if (ng == TN_MAP_MAX) return false; g[ng++] = G{i, s, tiles}; }
+    }
+    for (int i = 1; i < ng; ++i) {                       // insertion sort by size, descending, stable
+        const G v = g[i]; int j = i - 1;
+        while (j >= 0 && g[j].n < v.n) { g[j + 1] = g[j]; --j; }
+        g[j + 1] = v;
+    }
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < TN_MAP_MAX; ++i) map.e[i] = TN_MAP_IDLE;
+    for (int i = 0; i < ng; ++i) {
+        int x = 0;
+        for (int k = 1; k < 8; ++k) if (load[k] < load[x]) x = k;
+        if (load[x] + g[i].n > cap || (load[x] + g[i].n) * 8 > TN_MAP_MAX) return false;
+        for (int t = 0; t < g[i].n; ++t) map.e[(load[x] + t) * 8 + x] = (unsigned short)((g[i].p << 12) | (g[i].s * g[i].n + t));
+        load[x] += g[i].n;
+    }
+    int mx = 0;
+    for (int k = 0; k < 8; ++k) if (load[k] > mx) mx = load[k];
+    blocks = mx * 8;
+    return true;
+}
+
 size_t ap_gemm_tn_grouped_workspace(const ap_tn_problem* problems, int count) {
     TnGroup grp; int blocks = 0; size_t fl = 0;
     if (tn_plan(problems, count, grp, blocks, fl) != AP_OK) return 0;
@@ -1534,7 +1583,18 @@ int ap_gemm_tn_acc_grouped(const ap_tn_problem* problems, int count, void* works
     if (any_patch) {
         if (count != 1) return AP_ERR_UNSUPPORTED;                  // a patch-addressed problem is launched on its own
         hipLaunchKernelGGL(k_gemm_tn_patch, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp.p[0]);
-    } else hipLaunchKernelGGL(k_gemm_tn_grouped, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
+    } else {
+        static int place = -1, cap = 0;
+        if (place < 0) {
+            const char* e = getenv("AP_GEMM_TN_PLACE"); place = e ? atoi(e) : 1;
+            int dev = 0; hipGetDevice(&dev); hipDeviceProp_t pr;
+            cap = 2 * ((hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256) / 8;     // resident workgroups per XCD
+        }
+        TnMap map; int mblocks = 0;
+        if (place && tn_place(grp, cap, map, mblocks))
+            hipLaunchKernelGGL(k_gemm_tn_grouped_map, dim3(mblocks), dim3(256), 0, (hipStream_t)stream, grp, map);
+        else hipLaunchKernelGGL(k_gemm_tn_grouped, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
+    }
     if (workspace) hipLaunchKernelGGL(k_tn_reduce, dim3(1024), dim3(256), 0, (hipStream_t)stream, grp);
     return ap_check_launch();
 }
