@@ -327,190 +327,230 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
     }
 }
 
-// ---- backward in ONE pass (head_dim 32, N <= 256) ---------------------------------------------------------------------------------
-// k_mhsa_bwd recomputes S and dP (and the exponentials) twice: once key-owned for dK/dV, once query-owned for dQ.  Here a wave owns a
-// PAIR of key tiles (32 keys) and walks the query-tile pairs once: S, dP, P, dS for the 32 x 32 block, dV += P^T dO and dK += dS^T Q as
-// before -- and dQ, which needs dS with the QUERY as the fragment row: the wave writes its dS block to a private LDS scratch as
-// [key][q] (8-byte stores) and reads it back transposed (ds_read_b64_tr_b16) in the key order of the K^T fragment.  Every wave keeps
-// dQ partial sums of ALL query tiles in registers (16 x 2 accumulator tiles); after the loop the waves' partials are added through LDS
-// in a fixed order (bit-reproducible) and stored.  Half the exponentials / VALU work and 30 % fewer MFMAs than the two-pass kernel; one
-// workgroup per CU (registers), persistent over the (image, head) items.
-// STATUS (round 2): parity-green, selected with AP_MHSA_ONEPASS=1, NOT the default: 117 us against 64 us at B = 128, N = 196.  By
-// phase (AP_MHSA_DBG bits): operand staging alone 33 us, + main loop 49, + dQ reduction 35 -- with one workgroup per CU the three run
-// one after the other, and the main loop is a dependent MFMA -> exp -> pack -> MFMA -> LDS -> MFMA chain per wave at two waves per SIMD.
-// What it needs to win: the next item's tiles staged during the main loop, a tree reduction through 16-byte LDS accesses, and two
-// query-pair chains interleaved by hand.
-#define OP_SSTR 40               // scratch row stride (bf16): 32 q + padding
-template <int NP, bool EXACT>    // key / query tile PAIRS the registers are sized for (7: N <= 224, i.e. the 196 tokens of a 224 px image);
-                                 // EXACT: NT == 2 NP, so the unrolled loops carry no guards and stay one basic block the scheduler can interleave
-__global__ void __launch_bounds__(512)
-k_mhsa_bwd_onepass(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
-                   const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int heads, float scale, int NT, int nitems, int dbg = 0) {
-    constexpr int HD = 32, CH = 4;
+// ---- backward with dS handed over through LDS (head_dim 32, 7 .. 13 token tiles): the default for the 196 tokens of a 224 px image -----
+// k_mhsa_bwd computes S, dP and the exponentials twice (key-owned for dK / dV, query-owned for dQ) and stages its operands once per
+// workgroup with nothing of its own to overlap.  Here: 16 waves, one workgroup per CU, persistent over the (image, head) items.
+//   waves 0 .. ntile-1 : phase 1 -- the key-owned pass of k_mhsa_bwd (wave = one key tile, all query pairs, fully unrolled: dK, dV),
+//                        with -delta as the initial accumulator of dP, plus its dS block written to LDS as [key][query] (8-byte
+//                        stores); barrier; phase 2 -- wave = one QUERY tile: dQ = dS K with dS read back transposed
+//                        (ds_read_b64_tr_b16) in the key order of the K^T fragment.  No second softmax, no partial dQ sums across waves
+//                        (a first one-pass version kept dQ partials of all query tiles in every wave: 112 registers and a
+//                        cross-wave reduction, 117 us).
+//   waves 13 .. 15     : loaders -- fetch the NEXT item's O, dO, lse (-> delta, into the other lse / delta buffer) and Q, K, V rows into
+//                        registers while the others compute; Q, V, dO go to their LDS tiles behind the phase-1 barrier, K behind the
+//                        item's last one: the operand latency of an item hides behind the previous item's arithmetic.
+// LDS: four operand tiles (57 KB at N = 196) + 2 x (lse, delta) + dS^T [keys][232] (94 KB) = 155 KB.  The barriers are LDS-only
+// (s_waitcnt lgkmcnt(0); s_barrier): nothing waits for the prefetch or for the result stores.
+// B = 128, N = 196, 12 heads: 52 us against 66 us (k_mhsa_bwd); by phase: barriers + launch 10, arithmetic 31 (VALU-bound: 56 exp, fma,
+// mul, cvt each per wave and item, on the SIMD that holds 4 of the 13 compute waves), exposed loader work + result stores 11.
+#define DS_STR 232               // dS^T row stride (bf16): 224 queries + 8 of padding (464 B: conflict-free transposed reads)
+#define DS_LOADERS 3
+template <int NP>                // query-tile pairs (NT == 2 NP): the phase-1 loop is unrolled, every LDS address is a base + constant
+__global__ void __launch_bounds__(1024)
+k_mhsa_bwd_ds(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+              const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int heads, float scale, int NT, int nitems) {
+    constexpr int HD = 32, LT = 64 * DS_LOADERS, NPRE = 5;        // NPRE: 16-byte chunks per loader thread and tile (Npad * 4 <= 5 * 192)
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     const int Npad = NT * 16;
     bf16_t* Qs = smem;
     bf16_t* Ks = Qs + Npad * HD;
     bf16_t* Vs = Ks + Npad * HD;
     bf16_t* Gs = Vs + Npad * HD;
-    float* fl = reinterpret_cast<float*>(Gs + Npad * HD);
-    float* fd = fl + Npad;
-    bf16_t* scratch = reinterpret_cast<bf16_t*>(fd + Npad);                   // [8 waves][4 slots][32 keys][OP_SSTR]
-    float* red = reinterpret_cast<float*>(smem);                              // after the main loop: [8 waves][32 q][32 d] fp32 over Q/K/V
+    float* flb = reinterpret_cast<float*>(Gs + Npad * HD);                    // [2 buffers][lse * log2 e | delta][Npad]
+    bf16_t* dSt = reinterpret_cast<bf16_t*>(flb + 4 * Npad);                  // [ntile * 16 keys][DS_STR]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4, q4 = fr >> 2, p4 = fr & 3;
     const int C = heads * HD;
     const int64_t ld = 3 * C;
     const float c2 = scale * 1.4426950408889634f;
+    const int ntile = (N + 15) >> 4;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const bool loader = wave >= 16 - DS_LOADERS;
+    const int ltid = threadIdx.x - 64 * (16 - DS_LOADERS);
+
+    // loader state: chunk i of tile t is (row, c) = ((i * LT + ltid) >> 2, ltid & 3); rows beyond N read row N-1 and become zeros in LDS
+    // loader state: chunk i of a tile is (row, c) = ((i * LT + ltid) >> 2, ltid & 3); rows beyond N read row N-1 and become zeros in LDS.
+    // Registers decide the shape: every spilled load destination makes the loader wait for that load before it can issue the next
+    // batch (one memory latency per batch: 8 - 11 us per item with 150 - 220 B of scratch).  So: O, dO and lse first, delta and lse
+    // go straight to the OTHER lse / delta buffer (the current one is being read), O is dropped, then Q, K, V follow: 80 registers.
+    u32x4 pre[4][NPRE];
+    auto issue = [&](int item, float* fl_n, float* fd_n) {
+        const int b = item / heads, h = item % heads;
+        const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
+        const bf16_t* obase = out + (int64_t)b * N * C + h * HD;
+        const bf16_t* gbase = dout + (int64_t)b * N * C + h * HD;
+        const float* lbase = lse + ((int64_t)b * heads + h) * N;
+        int lt = ltid;
+        asm volatile("" : "+v"(lt));        // as in deposit(): keeps the per-chunk offsets out of long-lived registers
+        {
+            u32x4 po[NPRE];
+            float pl[NPRE];
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                const int id = i * LT + lt, row = min(id >> 2, N - 1), c = id & 3;
+                const unsigned ro = (unsigned)(row * C + c * 8);               // uniform base + 32-bit lane offset
+                po[i] = ld16(obase + ro);
+                pre[3][i] = ld16(gbase + ro);
+                pl[i] = lbase[(unsigned)row];
+            }
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                const int id = i * LT + lt, row = id >> 2, c = id & 3;
+                float a8[8], d8[8];
+                unpack8(po[i], a8);
+                unpack8(pre[3][i], d8);
+                float pt = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pt += a8[k] * d8[k];
+                pt += __shfl_xor(pt, 1, 64);                                   // the 4 chunks of a row sit in 4 consecutive lanes
+                pt += __shfl_xor(pt, 2, 64);
+                if (c == 0 && id < Npad * 4) {
+                    const bool ok = row < N;
+                    fd_n[row] = ok ? -pt : 0.f;                                // negated: the initial accumulator of dP
+                    fl_n[row] = ok ? pl[i] * 1.4426950408889634f : 1.0e30f;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int id = i * LT + lt, row = min(id >> 2, N - 1), c = id & 3;
+            const unsigned rq = (unsigned)(row * 3 * C + c * 8);
+            pre[0][i] = ld16(base + rq);
+            pre[1][i] = ld16(base + C + rq);
+            pre[2][i] = ld16(base + 2 * C + rq);
+        }
+    };
+    auto deposit = [&](bool keys) {         // keys = false: Q, V, dO (free once phase 1 is over); true: K (read by phase 2 as well)
+        int lt = ltid;
+        asm volatile("" : "+v"(lt));        // laundered: otherwise the 20 LDS addresses are hoisted out of the item loop, held for the whole kernel and spilled
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int id = i * LT + lt, row = id >> 2, c = id & 3;
+            if (id < Npad * 4) {
+                const bool ok = row < N;
+                const int off = att_off<HD>(row, c);
+                if (keys) *reinterpret_cast<u32x4*>(Ks + off) = ok ? pre[1][i] : zero4;
+                else {
+                    *reinterpret_cast<u32x4*>(Qs + off) = ok ? pre[0][i] : zero4;
+                    *reinterpret_cast<u32x4*>(Vs + off) = ok ? pre[2][i] : zero4;
+                    *reinterpret_cast<u32x4*>(Gs + off) = ok ? pre[3][i] : zero4;
+                }
+            }
+        }
+    };
+
     const int rb0 = att_row_base<HD>(lane, 0);
     int tb[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) tb[dt] = att_tr_base<HD>(lane, dt);
-    bf16_t* Sw = scratch + wave * 4 * 32 * OP_SSTR;
-    const int sw_base = fr * OP_SSTR + 4 * g;                                  // write: row = key (fr) (+16 jt), columns 4 g .. (+16 hf)
-    const int sr_base = (4 * g + q4) * OP_SSTR + 4 * p4;                        // transposed read: rows 4 g + q4 (+16), columns 4 p4 .. (+16 hf)
-    const int npair = NT >> 1;
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int sw_base = fr * DS_STR + 4 * g;                                   // write: row = key fr of the tile, columns 4 g .. (+16: second query tile)
+    const int sr_base = (4 * g + q4) * DS_STR + 4 * p4;                         // transposed read: rows 4 g + q4 (+16), columns 4 p4 ..
 
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const int wg = item;
-        const int b = wg / heads, h = wg % heads;
-        const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
-        const bf16_t* obase = out + (int64_t)b * N * C + h * HD;
-        const bf16_t* gbase = dout + (int64_t)b * N * C + h * HD;
-        bf16_t* dbase = dqkv + (int64_t)b * N * ld + h * HD;
-        __syncthreads();                                     // the previous item's reduction reads are done
-        {   // delta loads, then the operand tiles: one exposed latency
-            u32x4 va0[2], vd0[2];
-            float ls0[2];
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int idx = threadIdx.x + it * 512;
-                const int row = idx / CH, c = idx % CH;
-                const bool ok = idx < Npad * CH && row < N;
-                va0[it] = ok ? ld16(obase + (int64_t)row * C + c * 8) : zero4;
-                vd0[it] = ok ? ld16(gbase + (int64_t)row * C + c * 8) : zero4;
-                ls0[it] = (ok && c == 0) ? lse[((int64_t)b * heads + h) * N + row] : 0.f;
-            }
-            bf16_t* tiles[4] = {Qs, Ks, Vs, Gs};
-            const bf16_t* srcs[4] = {base, base + C, base + 2 * C, gbase};
-            const int64_t strides[4] = {ld, ld, ld, (int64_t)C};
-            att_stage_n<HD, 4, 2>(tiles, srcs, strides, N, Npad);
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int idx = threadIdx.x + it * 512;
-                if (idx >= Npad * CH) continue;
-                const int row = idx / CH, c = idx % CH;
-                float a[8], d[8];
-                unpack8(va0[it], a);
-                unpack8(vd0[it], d);
-                float part = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) part += a[k] * d[k];
-                part += __shfl_xor(part, 1, 64);
-                part += __shfl_xor(part, 2, 64);
-                if (c == 0) { fd[row] = part; fl[row] = (row < N) ? ls0[it] * 1.4426950408889634f : 1.0e30f; }
-            }
+    // LDS-only barrier: the waves wait for their LDS traffic, not for global stores / prefetches in flight (a __syncthreads would also
+    // drain vmcnt -- the loaders' prefetch and the dK / dV stores)
+#define DS_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    if (loader) {
+        // the two roles are separate loops with the same three barriers per item: in one loop the loader's 90 registers of prefetched rows
+        // would be live across the other waves' arithmetic (the allocator does not know the branch is per wave) and spill
+        int item = blockIdx.x, par = 0;
+        if (item < nitems) { issue(item, flb, flb + Npad); deposit(false); deposit(true); }
+        for (; item < nitems; item += gridDim.x) {
+            DS_BAR();                                                          // A: tiles, lse, delta of `item` are in LDS
+            const int nxt = item + gridDim.x;
+            par ^= 1;
+            if (nxt < nitems) issue(nxt, flb + 2 * par * Npad, flb + (2 * par + 1) * Npad);
+            DS_BAR();                                                          // B: phase 1 is over, Q / V / dO are free
+            if (nxt < nitems) deposit(false);
+            DS_BAR();                                                          // C: K and dS^T are free
+            if (nxt < nitems) deposit(true);
         }
-        __syncthreads();
-        f32x4 dq[2 * NP][2];
+        return;
+    }
+    int par = 0;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x, par ^= 1) {
+        DS_BAR();                                                              // A
+        const float* fl = flb + 2 * par * Npad;
+        const float* fd = fl + Npad;
+        const int b = item / heads, h = item % heads;
+        bf16_t* dbase = dqkv + (int64_t)b * N * ld + h * HD;
+        f32x4 dk[2] = {z, z}, dv[2] = {z, z};
+        if (wave < ntile) {
+            // ---- phase 1: this wave owns key tile `wave` -> dK, dV, and its dS block to LDS
+            const int jt = wave;
+            const bf16x8 kf = att_row_at<HD>(Ks, rb0, jt * 16), vf = att_row_at<HD>(Vs, rb0, jt * 16);
 #pragma unroll
-        for (int t = 0; t < 2 * NP; ++t) { dq[t][0] = z; dq[t][1] = z; }
-        if (wave < npair && !(dbg & 1)) {
-            const int k0 = 32 * wave;
-            bf16x8 kf[2], vf[2];
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt) { kf[jt] = att_row_at<HD>(Ks, rb0, k0 + 16 * jt); vf[jt] = att_row_at<HD>(Vs, rb0, k0 + 16 * jt); }
-            f32x4 dk[2][2], dv[2][2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) { dk[a][0] = z; dk[a][1] = z; dv[a][0] = z; dv[a][1] = z; }
+            for (int dt = 0; dt < 2; ++dt) { dk[dt] = z; dv[dt] = z; }
+            bf16_t* Sj = dSt + 16 * jt * DS_STR + sw_base;
 #pragma unroll
             for (int qs = 0; qs < NP; ++qs) {
-                if (EXACT || qs < npair) {
-                    bf16_t* S = Sw + (qs & 3) * 32 * OP_SSTR;          // four scratch slots per wave: consecutive query pairs do not wait for each other
+                f32x4 p[2], ds[2];
 #pragma unroll
-                    for (int jt = 0; jt < 2; ++jt) {         // one key tile at a time: P / dS of 16 keys x 32 queries live
-                        f32x4 p[2], ds[2];                   // [hf]
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int q0 = (2 * qs + hf) * 16;
+                    // the accumulator of dP starts at -delta (stored negated): dP - delta costs no VALU.  (A v_mul_f32 in inline asm, to keep
+                    // hipcc from pairing the multiplies into v_pk_mul_f32, is not an option: the hazard recognizer does not see it and the
+                    // multiply read dP before the MFMA had written it.)
+                    const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_at<HD>(Qs, rb0, q0), kf, z, 0, 0, 0);
+                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_at<HD>(Gs, rb0, q0), vf, *reinterpret_cast<const f32x4*>(fd + q0 + 4 * g), 0, 0, 0);
+                    const f32x4 fl4 = *reinterpret_cast<const f32x4*>(fl + q0 + 4 * g);
 #pragma unroll
-                        for (int hf = 0; hf < 2; ++hf) {
-                            const int q0 = (2 * qs + hf) * 16;
-                            const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_at<HD>(Qs, rb0, q0), kf[jt], z, 0, 0, 0);
-                            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_at<HD>(Gs, rb0, q0), vf[jt], z, 0, 0, 0);
-                            const f32x4 fl4 = *reinterpret_cast<const f32x4*>(fl + q0 + 4 * g);
-                            const f32x4 fd4 = *reinterpret_cast<const f32x4*>(fd + q0 + 4 * g);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -fl4[r]));
-                                p[hf][r] = pv;
-                                ds[hf][r] = pv * (dp[r] - fd4[r]);
-                            }
-                        }
-                        const bf16x8 pf = pack_frag(p[0], p[1]);
-                        const u32x4 dsu = __builtin_bit_cast(u32x4, pack_frag(ds[0], ds[1]));
-                        const bf16x8 dsf = __builtin_bit_cast(bf16x8, dsu);
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            dv[jt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, att_tr_at<HD>(Gs, tb[dt], 32 * qs), dv[jt][dt], 0, 0, 0);
-                            dk[jt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, att_tr_at<HD>(Qs, tb[dt], 32 * qs), dk[jt][dt], 0, 0, 0);
-                        }
-                        // dS block -> scratch [key][q]: this lane's 4 queries (4 g ..) of key fr, both query tiles
-                        u32x2 w0, w1;
-                        w0[0] = dsu[0]; w0[1] = dsu[1]; w1[0] = dsu[2]; w1[1] = dsu[3];
-                        *reinterpret_cast<u32x2*>(S + (16 * jt) * OP_SSTR + sw_base) = w0;            // hf = 0
-                        *reinterpret_cast<u32x2*>(S + (16 * jt) * OP_SSTR + sw_base + 16) = w1;       // hf = 1
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -fl4[r]));
+                        p[hf][r] = pv;
+                        ds[hf][r] = pv * dp[r];                                   // the softmax scale is applied once to dK / dQ
                     }
+                }
+                const bf16x8 pf = pack_frag(p[0], p[1]);
+                const u32x4 dsu = __builtin_bit_cast(u32x4, pack_frag(ds[0], ds[1]));
+                const bf16x8 dsf = __builtin_bit_cast(bf16x8, dsu);
+                u32x2 w0, w1;
+                w0[0] = dsu[0]; w0[1] = dsu[1]; w1[0] = dsu[2]; w1[1] = dsu[3];
+                *reinterpret_cast<u32x2*>(Sj + 32 * qs) = w0;             // queries 32 qs + 4 g .. +3 of key fr
+                *reinterpret_cast<u32x2*>(Sj + 32 * qs + 16) = w1;        // second query tile of the pair
 #pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
-                        const bf16_t* a1 = S + sr_base + 16 * hf;
-                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
-                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1 + 16 * OP_SSTR));
-                        const bf16x8 dsq = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, att_tr_at<HD>(Gs, tb[dt], 32 * qs), dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, att_tr_at<HD>(Qs, tb[dt], 32 * qs), dk[dt], 0, 0, 0);
+                }
+            }
+        }
+        DS_BAR();                                                              // B: dS^T is complete
+        if (wave < ntile) {
+            // ---- phase 2: this wave owns query tile `wave` -> dQ = dS K (padded keys: zero K rows)
+            const int qt = wave;
+            f32x4 dq[2] = {z, z};
+            const bf16_t* a0 = dSt + sr_base + 16 * qt;
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x4 z4 = {0, 0, 0, 0};
+            for (int kp = 0; 2 * kp < ntile; ++kp) {
+                const bf16_t* a1 = a0 + 32 * kp * DS_STR;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
+                s16x4 hi = z4;
+                if (2 * kp + 1 < ntile) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1 + 16 * DS_STR));
+                const bf16x8 dsq = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                        for (int dt = 0; dt < 2; ++dt)
-                            dq[2 * qs + hf][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsq, att_tr_at<HD>(Ks, tb[dt], k0), dq[2 * qs + hf][dt], 0, 0, 0);
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsq, att_tr_at<HD>(Ks, tb[dt], 32 * kp), dq[dt], 0, 0, 0);
+            }
+            // results leave after the arithmetic: nothing waits for these stores (the barriers do not count them)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = qt * 16 + 4 * g + r;
+                if (q < N) {
+                    bf16_t* qp = dbase + (int64_t)q * ld + fr;
+                    bf16_t* kp = qp + C;                                 // key index == query index: tile `wave` on both sides
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        qp[dt * 16] = f2bf(dq[dt][r] * scale);
+                        kp[dt * 16] = f2bf(dk[dt][r] * scale);
+                        kp[C + dt * 16] = f2bf(dv[dt][r]);
                     }
                 }
             }
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = k0 + 16 * jt + 4 * g + r;
-                    if (key < N) {
-                        bf16_t* kp = dbase + (int64_t)key * ld + C + fr;
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) { kp[dt * 16] = f2bf(dk[jt][dt][r] * scale); kp[C + dt * 16] = f2bf(dv[jt][dt][r]); }
-                    }
-                }
         }
-        __syncthreads();                                     // every wave is done with the operand tiles: their LDS becomes the reduction buffer
-        // dQ = sum over the key-pair waves, two query tiles per round, fixed order
-#pragma unroll
-        for (int rr = 0; rr < NP; ++rr) {
-            if ((EXACT || rr < npair) && !(dbg & 2)) {
-                if (wave < npair) {
-#pragma unroll
-                    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                red[(wave * 32 + 16 * hf + 4 * g + r) * 32 + 16 * dt + fr] = dq[2 * rr + hf][dt][r];
-                }
-                __syncthreads();
-#pragma unroll
-                for (int e2 = 0; e2 < 2; ++e2) {
-                    const int e = threadIdx.x + 512 * e2, ql = e >> 5, d = e & 31;
-                    const int q = 32 * rr + ql;
-                    float acc = 0.f;
-                    for (int w = 0; w < npair; ++w) acc += red[(w * 32 + ql) * 32 + d];
-                    if (q < N) dbase[(int64_t)q * ld + d] = f2bf(acc * scale);
-                }
-                __syncthreads();
-            }
-        }
+        DS_BAR();                                                              // C: tiles and dS^T are free
     }
+#undef DS_BAR
 }
 
 // ------------------------------------------------------------------------- class attention
@@ -721,28 +761,27 @@ int ap_mhsa_bwd(const ap_bf16* qkv, const ap_bf16* out, const ap_bf16* dout, con
         attr_done = true;
     }
     (void)hipGetLastError();
-    static int onepass = -1;
-    if (onepass < 0) { const char* e = getenv("AP_MHSA_ONEPASS"); onepass = e ? atoi(e) : 0; }      // default off: 117 us against 64 (phases below)
-    if (hd == 32 && onepass && nt <= 14) {            // up to 7 tile pairs (N <= 224): beyond that the dQ accumulators spill
-        const size_t lds1 = lds + (size_t)8 * 4 * 32 * OP_SSTR * sizeof(bf16_t);
-        static bool a1 = false;
-        if (!a1) {
-            (void)hipFuncSetAttribute((const void*)k_mhsa_bwd_onepass<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_mhsa_bwd_onepass<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_mhsa_bwd_onepass<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            a1 = true; (void)hipGetLastError();
-        }
-        static int n_cu = 0;
-        if (n_cu == 0) { int dev = 0; hipGetDevice(&dev); hipDeviceProp_t pr; n_cu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
-        const int items = B * heads;
-        int g1 = onepass > 1 ? onepass : n_cu;               // AP_MHSA_ONEPASS=<n> > 1: that many persistent workgroups
-        if (g1 > items) g1 = items;
-        if ((size_t)8 * 32 * 32 * sizeof(float) <= (size_t)3 * nt * 16 * hd * sizeof(bf16_t)) {      // the reduction buffer fits the Q/K/V tiles
-            const int np = nt / 2;
-            if (np <= 4) hipLaunchKernelGGL((k_mhsa_bwd_onepass<4, false>), dim3(g1), dim3(512), lds1, s, qkv, out, dout, lse, dqkv, N, heads, scale, nt, items);
-            else if (np == 7) { static int dbg = -1; if (dbg < 0) { const char* e = getenv("AP_MHSA_DBG"); dbg = e ? atoi(e) : 0; }
-                hipLaunchKernelGGL((k_mhsa_bwd_onepass<7, true>), dim3(g1), dim3(512), lds1, s, qkv, out, dout, lse, dqkv, N, heads, scale, nt, items, dbg); }
-            else hipLaunchKernelGGL((k_mhsa_bwd_onepass<7, false>), dim3(g1), dim3(512), lds1, s, qkv, out, dout, lse, dqkv, N, heads, scale, nt, items);
+    // default for head_dim 32 and 8 .. 13 token tiles (N = 113 .. 208): dS through LDS, loader waves (AP_MHSA_BWD_DS=0: the two-pass kernel)
+    static int use_ds = -1, ds_cu = 0;
+    if (use_ds < 0) {
+        const char* e = getenv("AP_MHSA_BWD_DS"); use_ds = e ? atoi(e) : 1;
+        int dev = 0; hipGetDevice(&dev); hipDeviceProp_t pr; ds_cu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+        (void)hipFuncSetAttribute((const void*)k_mhsa_bwd_ds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_mhsa_bwd_ds<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_mhsa_bwd_ds<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_mhsa_bwd_ds<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+    }
+    {
+        const int ntile = (N + 15) / 16;
+        const size_t lds_ds = lds + (size_t)2 * nt * 16 * sizeof(float) + (size_t)ntile * 16 * DS_STR * sizeof(bf16_t);
+        if (hd == 32 && use_ds && ntile <= 16 - DS_LOADERS && ntile >= 7 && nt * 16 * 4 <= 5 * 64 * DS_LOADERS && nt * 16 <= DS_STR - 8 &&
+            lds_ds <= (size_t)160 * 1024) {
+            const int items = B * heads;
+            const dim3 gds(items < ds_cu ? items : ds_cu);
+#define DS_LAUNCH(NP) hipLaunchKernelGGL(k_mhsa_bwd_ds<NP>, gds, dim3(1024), lds_ds, s, qkv, out, dout, lse, dqkv, N, heads, scale, nt, items)
+            switch (nt / 2) { case 4: DS_LAUNCH(4); break; case 5: DS_LAUNCH(5); break; case 6: DS_LAUNCH(6); break; default: DS_LAUNCH(7); break; }
+#undef DS_LAUNCH
             return ap_check_launch();
         }
     }
