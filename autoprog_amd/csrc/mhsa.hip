@@ -144,6 +144,132 @@ k_mhsa_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __re
     }
 }
 
+// The same forward as a PERSISTENT kernel (head_dim 32, 7 .. 13 query tiles): 16 waves, one workgroup per CU walking the (image, head)
+// items.  Wave w < nq owns query tile w of every item (one tile per wave: no 13-tiles-on-4-waves rounding); waves 13 .. 15 are
+// loaders: they fetch the NEXT item's K and V rows and write them to the other K/V buffer in LDS while the others compute, so an item
+// starts on operands that are already there (k_mhsa_fwd stages K/V per workgroup and relies on co-resident workgroups for overlap).
+// One LDS-only barrier per item (s_waitcnt lgkmcnt(0); s_barrier): nothing waits for the Q prefetch or the output stores.
+#define FP_LOADERS 3
+template <int NT>
+__global__ void __launch_bounds__(1024)
+k_mhsa_fwd_p(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int heads, float scale,
+             const float* __restrict__ out_row_scale, int nitems) {
+    constexpr int HD = 32, Npad = NT * 16, LT = 64 * FP_LOADERS, NPRE = (Npad * 4 + LT - 1) / LT;
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];             // [2 buffers][K | V][Npad][32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, g = lane >> 4;
+    const int C = heads * HD;
+    const int64_t ld = 3 * C;
+    const int nq = (N + 15) >> 4;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#define FP_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // heads of one image share 128-B lines of qkv (64 B per token and head): the items an XCD works on at a time are consecutive
+    auto item_of = [&](int v) { return xcd_remap(v, nitems); };
+    const int nround = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // items of this workgroup
+    if (wave >= 16 - FP_LOADERS) {
+        const int ltid = threadIdx.x - 64 * (16 - FP_LOADERS);
+        auto fetch = [&](int item, bf16_t* Kd, bf16_t* Vd) {
+            const int b = item / heads, h = item % heads;
+            const bf16_t* base = qkv + (int64_t)b * N * ld + h * HD;
+            int lt = ltid;
+            asm volatile("" : "+v"(lt));                                      // keeps the per-chunk offsets out of long-lived registers
+            u32x4 pk[NPRE], pv[NPRE];
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                const int id = i * LT + lt, row = min(id >> 2, N - 1), c = id & 3;
+                const unsigned rq = (unsigned)(row * 3 * C + c * 8);           // uniform base + 32-bit lane offset
+                pk[i] = ld16(base + C + rq);
+                pv[i] = ld16(base + 2 * C + rq);
+            }
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                const int id = i * LT + lt, row = id >> 2, c = id & 3;
+                if (id < Npad * 4) {
+                    const bool ok = row < N;
+                    const int off = att_off<HD>(row, c);
+                    *reinterpret_cast<u32x4*>(Kd + off) = ok ? pk[i] : zero4;
+                    *reinterpret_cast<u32x4*>(Vd + off) = ok ? pv[i] : zero4;
+                }
+            }
+        };
+        if (nround > 0) fetch(item_of(blockIdx.x), smem, smem + Npad * HD);
+        for (int k = 0; k < nround; ++k) {
+            FP_BAR();                                                          // buffer k & 1 is complete; everyone is done with the other one
+            if (k + 1 < nround) {
+                bf16_t* nb = smem + ((k + 1) & 1) * 2 * Npad * HD;
+                fetch(item_of(blockIdx.x + (k + 1) * gridDim.x), nb, nb + Npad * HD);
+            }
+        }
+        return;
+    }
+    const float c2 = scale * 1.4426950408889634f;
+    const int kb = att_row_base<HD>(lane, 0);
+    int vb[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) vb[dt] = att_tr_base<HD>(lane, dt);
+    const int qt = wave;
+    const unsigned qoff = (unsigned)(min(qt * 16 + fr, N - 1) * 3 * C + g * 8);
+    bf16x8 qnext = __builtin_bit_cast(bf16x8, zero4);
+    if (qt < nq && nround > 0) {
+        const int item = item_of(blockIdx.x);
+        qnext = __builtin_bit_cast(bf16x8, ld16(qkv + (int64_t)(item / heads) * N * ld + (item % heads) * HD + qoff));
+    }
+    for (int k = 0; k < nround; ++k) {
+        FP_BAR();
+        if (qt >= nq) continue;
+        const int item = item_of(blockIdx.x + k * gridDim.x);
+        const int b = item / heads, h = item % heads;
+        const bf16_t* Ks = smem + (k & 1) * 2 * Npad * HD;
+        const bf16_t* Vs = Ks + Npad * HD;
+        const bf16x8 qf = qnext;
+        if (k + 1 < nround) {                                                  // the Q fragment of the next item: in flight during this one
+            const int nx = item_of(blockIdx.x + (k + 1) * gridDim.x);
+            qnext = __builtin_bit_cast(bf16x8, ld16(qkv + (int64_t)(nx / heads) * N * ld + (nx % heads) * HD + qoff));
+        }
+        f32x4 s[NT];
+        float mx = -1.0e30f;                         // max of the RAW scores (scale > 0)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(att_row_at<HD>(Ks, kb, t * 16), qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            if (t >= NT - 2) {                       // N > 16*(NT-2): only the last two key tiles can hold padding
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (t * 16 + 4 * g + r >= N) s[t][r] = -1.0e30f;
+            }
+            mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nmx = -mx * c2;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[t][r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, nmx)); sum += s[t][r]; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s2 = 0; s2 < NT / 2; ++s2) {
+            const bf16x8 pf = pack_frag(s[2 * s2], s[2 * s2 + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, att_tr_at<HD>(Vs, vb[dt], 32 * s2), o[dt], 0, 0, 0);
+        }
+        const float inv = (out_row_scale ? out_row_scale[b] : 1.0f) / sum;      // 0/1 DropPath keep mask of the projection that follows
+        if (g == 0 && qt * 16 + fr < N) lse[((int64_t)b * heads + h) * N + qt * 16 + fr] = (mx * c2 + log2f(sum)) * 0.6931471805599453f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ir = __shfl(inv, 4 * g + r, 64);
+            const int q = qt * 16 + 4 * g + r;
+            if (q < N) {
+                bf16_t* op = out + ((int64_t)b * N + q) * C + h * HD + fr;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) op[dt * 16] = f2bf(o[dt][r] * ir);
+            }
+        }
+    }
+#undef FP_BAR
+}
+
 template <int HD>
 __global__ void __launch_bounds__(512)
 k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
@@ -452,13 +578,14 @@ k_mhsa_bwd_ds(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, co
     if (loader) {
         // the two roles are separate loops with the same three barriers per item: in one loop the loader's 90 registers of prefetched rows
         // would be live across the other waves' arithmetic (the allocator does not know the branch is per wave) and spill
+        // item v of the launch is xcd_remap(v): the items an XCD works on at a time are consecutive (heads of one image share 128-B lines)
         int item = blockIdx.x, par = 0;
-        if (item < nitems) { issue(item, flb, flb + Npad); deposit(false); deposit(true); }
+        if (item < nitems) { issue(xcd_remap(item, nitems), flb, flb + Npad); deposit(false); deposit(true); }
         for (; item < nitems; item += gridDim.x) {
             DS_BAR();                                                          // A: tiles, lse, delta of `item` are in LDS
             const int nxt = item + gridDim.x;
             par ^= 1;
-            if (nxt < nitems) issue(nxt, flb + 2 * par * Npad, flb + (2 * par + 1) * Npad);
+            if (nxt < nitems) issue(xcd_remap(nxt, nitems), flb + 2 * par * Npad, flb + (2 * par + 1) * Npad);
             DS_BAR();                                                          // B: phase 1 is over, Q / V / dO are free
             if (nxt < nitems) deposit(false);
             DS_BAR();                                                          // C: K and dS^T are free
@@ -467,10 +594,11 @@ k_mhsa_bwd_ds(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, co
         return;
     }
     int par = 0;
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x, par ^= 1) {
+    for (int v = blockIdx.x; v < nitems; v += gridDim.x, par ^= 1) {
         DS_BAR();                                                              // A
         const float* fl = flb + 2 * par * Npad;
         const float* fd = fl + Npad;
+        const int item = xcd_remap(v, nitems);
         const int b = item / heads, h = item % heads;
         bf16_t* dbase = dqkv + (int64_t)b * N * ld + h * HD;
         f32x4 dk[2] = {z, z}, dv[2] = {z, z};
@@ -731,6 +859,25 @@ int ap_mhsa_fwd(const ap_bf16* qkv, ap_bf16* out, float* lse, int B, int N, int 
         attr_done = true;
     }
     (void)hipGetLastError();
+    // head_dim 32 and 7 .. 13 query tiles: the persistent kernel with loader waves (AP_MHSA_FWD_P=0: one workgroup per (image, head))
+    static int use_p = -1, p_cu = 0;
+    if (use_p < 0) {
+        const char* e = getenv("AP_MHSA_FWD_P"); use_p = e ? atoi(e) : 1;
+        int dev = 0; hipDeviceProp_t pr;
+        p_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+        p_cu &= ~7;                                                            // whole XCD groups (xcd_remap)
+        (void)hipGetLastError();
+    }
+    const int nq = (N + 15) / 16;
+    if (hd == 32 && use_p && nq >= 7 && nq <= 16 - FP_LOADERS && p_cu >= 8) {
+        const int items = B * heads;
+        const dim3 gp(items < p_cu ? items : p_cu);
+        const size_t lds_p = 2 * lds;
+#define FP_LAUNCH(NTV) hipLaunchKernelGGL((k_mhsa_fwd_p<NTV>), gp, dim3(1024), lds_p, s, qkv, out, lse, N, heads, scale, out_row_scale, items)
+        switch (nt) { case 8: FP_LAUNCH(8); break; case 10: FP_LAUNCH(10); break; case 12: FP_LAUNCH(12); break; default: FP_LAUNCH(14); break; }
+#undef FP_LAUNCH
+        return ap_check_launch();
+    }
     if (hd == 32) { MHSA_FWD_SWITCH(32) } else { MHSA_FWD_SWITCH(64) }
     return ap_check_launch();
 }
@@ -765,7 +912,9 @@ int ap_mhsa_bwd(const ap_bf16* qkv, const ap_bf16* out, const ap_bf16* dout, con
     static int use_ds = -1, ds_cu = 0;
     if (use_ds < 0) {
         const char* e = getenv("AP_MHSA_BWD_DS"); use_ds = e ? atoi(e) : 1;
-        int dev = 0; hipGetDevice(&dev); hipDeviceProp_t pr; ds_cu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+        int dev = 0; hipDeviceProp_t pr;
+        ds_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+        if (ds_cu >= 8) ds_cu &= ~7;                                           // whole XCD groups (xcd_remap)
         (void)hipFuncSetAttribute((const void*)k_mhsa_bwd_ds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)k_mhsa_bwd_ds<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)k_mhsa_bwd_ds<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

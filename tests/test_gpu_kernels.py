@@ -453,7 +453,7 @@ def test_bn_relu_fused(ops, B, H, W, C):
     assert rel(ye, torch.relu(bn(x.double().permute(0, 3, 1, 2))).permute(0, 2, 3, 1)) < TOL_BF16
 
 
-@pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_MHSA_BWD_DS": "0"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"}, {"AP_OUTLOOK_MFMA": "0"},
+@pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_MHSA_BWD_DS": "0", "AP_MHSA_FWD_P": "0"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"}, {"AP_OUTLOOK_MFMA": "0"},
                                  {"AP_STEM_HIP_CONV": "0"}, {"AP_ASYNC_WGRAD": "1"}, {"AP_GEMM_TN_PLACE": "0"}])
 def test_experimental_kernel_paths_stay_parity_green(env):
     """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:
