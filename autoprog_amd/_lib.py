@@ -51,6 +51,7 @@ _SIGNATURES = {
     "ap_gemm_tn_acc": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "ap_gemm_tn_grouped_workspace": (ctypes.c_size_t, [_P, _I]),
     "ap_gemm_tn_acc_grouped": (_I, [_P, _I, _P, ctypes.c_size_t, _P]),
+    "ap_gemm_tn_acc_grouped_ln": (_I, [_P, _I, _P, _I, _P, ctypes.c_size_t, _P]),
     "ap_colsum_acc": (_I, [_P, _I, _P, _I, _I, _P]),
     "ap_outlook_fwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "ap_outlook_bwd": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

@@ -1010,11 +1010,50 @@ k_gemm_tn_grouped(TnGroup grp) {
     tn_tile(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N1, a.N2, a.steps_per_split, a.colsum, a.t1, a.t2, a.nblocks,
             (int)blockIdx.x - a.start, sA, sB, a.cs_weight, a.cs_scale, a.slab, a.splits, a.alpha);
 }
+// LayerNorm dgamma / dbeta reductions riding in the grouped launch (ap_gemm_tn_acc_grouped_ln): the workgroups behind the placement
+// table add the partial rows k_ln_bwd left (column sums of [nblocks][2 C]) -- the block's own reduction launch (5.8 us, 19 per step,
+// nothing but latency) disappears into a launch that has idle workgroup slots anyway.
+struct TnLnItem { const float* partial; float* dgamma; float* dbeta; int nblocks; int C; };
+struct TnLn { TnLnItem it[AP_LN_MAX_BATCH]; int count; int first; };            // first: blockIdx.x of the first reduction workgroup
+__device__ __forceinline__ void tn_ln_role(const TnLn& ln, int blk, float* red) {          // red: >= 8 * 33 floats of LDS
+    int y = 0, b0 = 0;
+    for (int i = 0; i + 1 < ln.count; ++i) {                                     // which reduction this workgroup belongs to
+        const int nb = (2 * ln.it[i].C + 31) / 32;
+        if (y == i && blk >= b0 + nb) { b0 += nb; y = i + 1; }
+    }
+    const float* __restrict__ partial = ln.it[y].partial;
+    const int nblocks = ln.it[y].nblocks, C = ln.it[y].C, C2 = 2 * C;
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;                      // 32 columns x 8 row groups
+    const int c = (blk - b0) * 32 + cx;
+    if ((blk - b0) * 32 >= C2) return;
+    float s = 0.f;
+    if (c < C2) {
+        int b = ry;
+        for (; b + 15 * 8 < nblocks; b += 16 * 8) {                              // 16 loads in flight per thread
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = partial[(int64_t)(b + u * 8) * C2 + c];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; b < nblocks; b += 8) s += partial[(int64_t)b * C2 + c];
+    }
+    red[ry * 33 + cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < C2) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r * 33 + cx];
+        if (c < C) ln.it[y].dgamma[c] += t; else ln.it[y].dbeta[c - C] += t;
+    }
+}
+
 // the same with the host-made placement table (one (problem, split) per XCD)
 __global__ void __launch_bounds__(256)
-k_gemm_tn_grouped_map(TnGroup grp, TnMap map) {
+k_gemm_tn_grouped_map(TnGroup grp, TnMap map, TnLn ln) {
     __shared__ __attribute__((aligned(16))) bf16_t sA[TM * 128];
     __shared__ __attribute__((aligned(16))) bf16_t sB[TM * 128];
+    if ((int)blockIdx.x >= ln.first) { tn_ln_role(ln, (int)blockIdx.x - ln.first, reinterpret_cast<float*>(sA)); return; }
     const unsigned e = map.e[blockIdx.x];
     if (e == TN_MAP_IDLE) return;
     const TnArgs& a = grp.p[e >> 12];
@@ -1566,6 +1605,17 @@ size_t ap_gemm_tn_grouped_workspace(const ap_tn_problem* problems, int count) {
 }
 
 int ap_gemm_tn_acc_grouped(const ap_tn_problem* problems, int count, void* workspace, size_t ws_bytes, ap_stream_t stream) {
+    return ap_gemm_tn_acc_grouped_ln(problems, count, nullptr, 0, workspace, ws_bytes, stream);
+}
+
+int ap_gemm_tn_acc_grouped_ln(const ap_tn_problem* problems, int count, const ap_ln_reduce* ln_items, int ln_count,
+                              void* workspace, size_t ws_bytes, ap_stream_t stream) {
+    if (ln_count < 0 || ln_count > AP_LN_MAX_BATCH || (ln_count > 0 && !ln_items)) return AP_ERR_SHAPE;
+    for (int i = 0; i < ln_count; ++i) {
+        if (!ln_items[i].partial || !ln_items[i].dgamma || !ln_items[i].dbeta) return AP_ERR_NULL;
+        if (ln_items[i].n_partial <= 0 || ln_items[i].C <= 0) return AP_ERR_SHAPE;
+    }
+    bool ln_done = ln_count == 0;
     TnGroup grp; int blocks = 0; size_t fl = 0;
     const int rc = tn_plan(problems, count, grp, blocks, fl);
     if (rc != AP_OK) return rc;
@@ -1591,9 +1641,23 @@ int ap_gemm_tn_acc_grouped(const ap_tn_problem* problems, int count, void* works
             cap = 2 * ((hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256) / 8;     // resident workgroups per XCD
         }
         TnMap map; int mblocks = 0;
-        if (place && tn_place(grp, cap, map, mblocks))
-            hipLaunchKernelGGL(k_gemm_tn_grouped_map, dim3(mblocks), dim3(256), 0, (hipStream_t)stream, grp, map);
-        else hipLaunchKernelGGL(k_gemm_tn_grouped, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
+        if (place && tn_place(grp, cap, map, mblocks)) {
+            TnLn ln;
+            int lblocks = 0;
+            for (int i = 0; i < AP_LN_MAX_BATCH; ++i) {
+                if (i < ln_count) {
+                    const ap_ln_reduce& q = ln_items[i];
+                    ln.it[i] = TnLnItem{q.partial, q.dgamma, q.dbeta, q.n_partial, q.C}; lblocks += (2 * q.C + 31) / 32;
+                } else ln.it[i] = TnLnItem{nullptr, nullptr, nullptr, 0, 0};
+            }
+            ln.count = ln_count; ln.first = mblocks;
+            hipLaunchKernelGGL(k_gemm_tn_grouped_map, dim3(mblocks + lblocks), dim3(256), 0, (hipStream_t)stream, grp, map, ln);
+            ln_done = true;
+        } else hipLaunchKernelGGL(k_gemm_tn_grouped, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
+    }
+    if (!ln_done) {                                    // no placement table (or a patch-addressed problem): the reductions get their own launch
+        const int rc2 = ap_layernorm_bwd_reduce_batched(ln_items, ln_count, stream);
+        if (rc2 != AP_OK) return rc2;
     }
     if (workspace) hipLaunchKernelGGL(k_tn_reduce, dim3(1024), dim3(256), 0, (hipStream_t)stream, grp);
     return ap_check_launch();

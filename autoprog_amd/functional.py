@@ -171,14 +171,20 @@ class wgrad_batch:
         global _wgrad_batch
         pending, _wgrad_batch = _wgrad_batch, self.prev
         if exc[0] is None:
-            if self.ln:
-                ops.layernorm_bwd_reduce_batched(self.ln)        # one launch for the block's LayerNorms (was one per LayerNorm)
-            if pending:
-                _launch_wgrads(pending)
+            if pending and not async_wgrad and fuse_ln_reduce:
+                _launch_wgrads(pending, self.ln)                 # the block's LayerNorm dgamma / dbeta reductions ride in the weight-gradient launch
+            else:
+                if self.ln:
+                    ops.layernorm_bwd_reduce_batched(self.ln)    # one launch for the block's LayerNorms (was one per LayerNorm)
+                if pending:
+                    _launch_wgrads(pending)
         return False
 
 
-def _launch_wgrads(problems):
+fuse_ln_reduce = os.environ.get("AP_FUSE_LN_REDUCE", "1") != "0"
+
+
+def _launch_wgrads(problems, ln=None):
     if async_wgrad:
         side = wgrad_stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -188,7 +194,7 @@ def _launch_wgrads(problems):
             prob[0].record_stream(side)
             prob[1].record_stream(side)
     else:
-        ops.gemm_tn_acc_grouped(problems)
+        ops.gemm_tn_acc_grouped(problems, ln=ln)
 
 
 def _linear_bwd(g, x_in, w, dw, db, n=None, dgelu_of=None, need_dx=True, row_scale=None, rows_per_scale=1, cs_weight=None, inv_keep=1.0):

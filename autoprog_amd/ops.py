@@ -243,11 +243,16 @@ def gemm_nt_patch_dgrad(dy, wmat_t, shape, k):
     return dx
 
 
-def gemm_tn_acc_grouped(problems):
+def gemm_tn_acc_grouped(problems, ln=None):
     """problems: list of (a, b, c, n1, n2, colsum[, colsum_weight, colsum_scale[, alpha[, b_patch]]]) as for gemm_tn_acc; ONE launch for
     the whole list (chunks of 8).  colsum_weight: bf16 per-token weights of the column sum (DropPath keep mask), colsum_scale its factor;
-    alpha: factor of the product (c += alpha * a^T b); b_patch: PatchMap -- b is then an NHWC feature map whose patches are the rows."""
-    from ._lib import TnProblem, TN_MAX_GROUP
+    alpha: factor of the product (c += alpha * a^T b); b_patch: PatchMap -- b is then an NHWC feature map whose patches are the rows.
+    ln: deferred LayerNorm reductions (the entries layernorm_bwd(..., defer=...) appended, at most 4): they ride in the first launch."""
+    from ._lib import TnProblem, TN_MAX_GROUP, LnReduce
+    ln = list(ln) if ln else []
+    if len(ln) > 4:
+        layernorm_bwd_reduce_batched(ln[4:])
+        ln = ln[:4]
     for i0 in range(0, len(problems), TN_MAX_GROUP):
         chunk = problems[i0:i0 + TN_MAX_GROUP]
         arr = (TnProblem * len(chunk))()
@@ -282,7 +287,15 @@ def gemm_tn_acc_grouped(problems):
         if deterministic:
             ws_bytes = lib.ap_gemm_tn_grouped_workspace(ptr, len(chunk))
             ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=chunk[0][0].device)
-        check(lib.ap_gemm_tn_acc_grouped(ptr, len(chunk), ws.data_ptr() if ws is not None else None, ws_bytes, _stream()), "ap_gemm_tn_acc_grouped")
+        if ln:
+            larr = (LnReduce * len(ln))()
+            for q, (lws, n, C, dg, db) in zip(larr, ln):
+                q.partial, q.n_partial, q.C, q.dgamma, q.dbeta = lws.data_ptr(), n, C, dg.data_ptr(), db.data_ptr()
+            check(lib.ap_gemm_tn_acc_grouped_ln(ptr, len(chunk), ctypes.cast(larr, ctypes.c_void_p), len(ln), ws.data_ptr() if ws is not None else None,
+                                                ws_bytes, _stream()), "ap_gemm_tn_acc_grouped_ln")
+            ln = []
+        else:
+            check(lib.ap_gemm_tn_acc_grouped(ptr, len(chunk), ws.data_ptr() if ws is not None else None, ws_bytes, _stream()), "ap_gemm_tn_acc_grouped")
 
 
 def colsum_acc(a, out, n=None):

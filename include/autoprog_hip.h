@@ -137,6 +137,10 @@ typedef struct ap_tn_problem {
  * them in split order (bitwise reproducible; the mode behind AP_DETERMINISTIC=1 of the Python layer). */
 size_t ap_gemm_tn_grouped_workspace(const ap_tn_problem* problems, int count);
 int ap_gemm_tn_acc_grouped(const ap_tn_problem* problems, int count, void* workspace, size_t ws_bytes, ap_stream_t stream);
+/* the same launch also performs up to AP_LN_MAX_BATCH deferred LayerNorm dgamma / dbeta reductions (ap_layernorm_bwd_partial) on
+ * workgroups of its own: the weight gradients and the LayerNorm parameter gradients of one block in ONE launch */
+int ap_gemm_tn_acc_grouped_ln(const ap_tn_problem* problems, int count, const ap_ln_reduce* ln_items, int ln_count,
+                              void* workspace, size_t ws_bytes, ap_stream_t stream);
 /* bias gradient: out[n] += sum_m A[m,n] */
 int ap_colsum_acc(const ap_bf16* A, int lda, float* out, int M, int N, ap_stream_t stream);
 

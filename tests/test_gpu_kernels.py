@@ -453,8 +453,43 @@ def test_bn_relu_fused(ops, B, H, W, C):
     assert rel(ye, torch.relu(bn(x.double().permute(0, 3, 1, 2))).permute(0, 2, 3, 1)) < TOL_BF16
 
 
+def test_grouped_wgrad_launch_carries_the_layernorm_reductions(ops):
+    """ap_gemm_tn_acc_grouped_ln: the deferred dgamma / dbeta reductions of a block done by extra workgroups of the weight-gradient
+    launch equal the stand-alone batched reduction (same partial rows; only the order of the fp32 additions differs) and the weight
+    gradients themselves are untouched"""
+    torch.manual_seed(5)
+    rows = 3000
+    lns, refs = [], []
+    for C in (192, 384, 96):
+        x, dy, g = rnd(rows, C, seed=C), rnd(rows, C, seed=C + 1), torch.randn(C)
+        mean = x.float().mean(-1); rstd = (x.float().var(-1, unbiased=False) + 1e-5).rsqrt()
+        lns.append((dev(dy), dev(x), dev(g.float()), dev(mean), dev(rstd)))
+    def partials():
+        items, outs = [], []
+        for dy, x, g, mean, rstd in lns:
+            dg, db = torch.zeros_like(g), torch.zeros_like(g)
+            ops.layernorm_bwd(dy, x, g, mean, rstd, None, dg, db, defer=items)
+            outs.append((dg, db))
+        return items, outs
+    M = 4096
+    a, b = dev(rnd(M, 384, seed=11)), dev(rnd(M, 192, seed=12))
+    def problems():
+        return [(a, b, torch.zeros(384, 192, device="cuda"), 384, 192, torch.zeros(384, device="cuda")),
+                (b, a, torch.zeros(192, 384, device="cuda"), 192, 384, None)]
+    it0, out0 = partials(); p0 = problems()
+    ops.layernorm_bwd_reduce_batched(it0); ops.gemm_tn_acc_grouped(p0)
+    it1, out1 = partials(); p1 = problems()
+    ops.gemm_tn_acc_grouped(p1, ln=it1)
+    for (g0, b0), (g1, b1) in zip(out0, out1):
+        assert rel(g1, g0.cpu()) < 1e-5 and rel(b1, b0.cpu()) < 1e-5
+        assert float(g0.abs().max()) > 0
+    for q0, q1 in zip(p0, p1):
+        assert rel(q1[2], q0[2].cpu()) < 1e-5
+    assert rel(p1[0][5], p0[0][5].cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_MHSA_BWD_DS": "0", "AP_MHSA_FWD_P": "0"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"}, {"AP_OUTLOOK_MFMA": "0"},
-                                 {"AP_STEM_HIP_CONV": "0"}, {"AP_ASYNC_WGRAD": "1"}, {"AP_GEMM_TN_PLACE": "0"}])
+                                 {"AP_STEM_HIP_CONV": "0"}, {"AP_ASYNC_WGRAD": "1"}, {"AP_GEMM_TN_PLACE": "0"}, {"AP_FUSE_LN_REDUCE": "0"}])
 def test_experimental_kernel_paths_stay_parity_green(env):
     """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:
     re-run the GEMM / block tests in a child process with the switch set (the switches are read once per process)"""
@@ -467,7 +502,7 @@ def test_experimental_kernel_paths_stay_parity_green(env):
         sel, files = "outlook", ["tests/test_gpu_kernels.py", "tests/test_gpu_blocks.py"]
     elif "STEM" in key:
         sel, files = "d1_shapes or hip_stem or patch_embed", ["tests/test_gpu_model.py", "tests/test_gpu_blocks.py"]
-    elif "WGRAD" in key:
+    elif "WGRAD" in key or "FUSE_LN" in key:
         sel, files = "vs_reference_golden or grad_sink", ["tests/test_gpu_blocks.py", "tests/test_gpu_model.py"]
     else:
         sel, files = "gemm and not experimental", ["tests/test_gpu_kernels.py"]
