@@ -269,26 +269,42 @@ k_conv7_s2d_wgrad(const bf16_t* __restrict__ xs, const bf16_t* __restrict__ dz, 
                 mine[((wave * 4 + dx) * S_CO + 16 * tq + 4 * g + r) * S_CI + fr] = acc[dx][tq][r];
 }
 
-// w.grad[co][c][ky][kx] (fp32 [64][3][7][7]) += sum over the slabs in order; one thread per real weight, 8 loads in flight
-__global__ void __launch_bounds__(256)
+// w.grad[co][c][ky][kx] (fp32 [64][3][7][7]) += sum over the slabs, in a fixed order.  Block = 256 consecutive slab elements x 16 waves;
+// wave v adds slabs v, v + 16, ... with 16-byte coalesced loads, eight in flight; the 16 partial sums meet in LDS and are added in wave
+// order, then each slab element (tap, co, c16) that is a real weight goes to its OIHW place.  (First version: one thread per real
+// weight walking all slabs with scattered 4-byte loads, 60 us; the same scheme as k_conv3x3_wgrad_reduce.)
+__global__ void __launch_bounds__(1024)
 k_conv7_wgrad_reduce(const float* __restrict__ slab, int nslab, float* __restrict__ dw) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;           // (co, c, ky, kx)
-    if (idx >= 64 * 3 * 49) return;
-    const int kx = idx % 7, ky = (idx / 7) % 7, c = (idx / 49) % 3, co = idx / 147;
-    const int ky8 = ky + 1, kx8 = kx + 1;
-    const int tap = (ky8 >> 1) * 4 + (kx8 >> 1), c16 = ((ky8 & 1) * 2 + (kx8 & 1)) * 3 + c;
-    const float* src = slab + (tap * S_CO + co) * S_CI + c16;
-    float s0 = 0.f, s1 = 0.f;
-    int w = 0;
-    for (; w + 7 < nslab; w += 8) {
-        float v[8];
+    __shared__ float4 part[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e0 = blockIdx.x * 256 + lane * 4;              // SW_SLAB = 64 * 256
+    float4 s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    int w = wave;
+    for (; w + 7 * 16 < nslab; w += 8 * 16) {
+        float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(w + u) * SW_SLAB];
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(slab + (int64_t)(w + 16 * u) * SW_SLAB + e0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { if (u & 1) s1 += v[u]; else s0 += v[u]; }
+        for (int u = 0; u < 8; ++u) { s[u & 1].x += v[u].x; s[u & 1].y += v[u].y; s[u & 1].z += v[u].z; s[u & 1].w += v[u].w; }
     }
-    for (; w < nslab; ++w) s0 += src[(int64_t)w * SW_SLAB];
-    dw[idx] += s0 + s1;
+    for (; w < nslab; w += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)w * SW_SLAB + e0);
+        s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+    }
+    part[wave][lane] = make_float4(s[0].x + s[1].x, s[0].y + s[1].y, s[0].z + s[1].z, s[0].w + s[1].w);
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int e = blockIdx.x * 256 + threadIdx.x;        // slab element (tap, co, c16)
+        const float* pf = reinterpret_cast<const float*>(&part[0][0]);
+        float t = 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) t += pf[v * 256 + threadIdx.x];
+        const int c16 = e % S_CI, co = (e / S_CI) % S_CO, tap = e / (S_CI * S_CO);
+        // tap = (ky8 >> 1) * 4 + (kx8 >> 1), c16 = ((ky8 & 1) * 2 + (kx8 & 1)) * 3 + c with (ky8, kx8) = (ky + 1, kx + 1)
+        const int par = c16 / 3, c = c16 - 3 * par;
+        const int ky = 2 * (tap >> 2) + (par >> 1) - 1, kx = 2 * (tap & 3) + (par & 1) - 1;
+        if (c16 < 12 && ky >= 0 && ky < 7 && kx >= 0 && kx < 7) dw[((co * 3 + c) * 7 + ky) * 7 + kx] += t;
+    }
 }
 
 extern "C" {
@@ -355,7 +371,8 @@ int ap_conv7_s2d_wgrad(const ap_bf16* xs, const ap_bf16* dz, float* dw_oihw, int
     hipLaunchKernelGGL(k_conv7_s2d_wgrad, dim3(grid), dim3(256), SW_LDS_BYTES, (hipStream_t)stream, xs, dz, static_cast<float*>(workspace), H, W, tx, ty, nt);
     int rc = ap_check_launch();
     if (rc != AP_OK) return rc;
-    hipLaunchKernelGGL(k_conv7_wgrad_reduce, dim3((64 * 147 + 255) / 256), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(workspace), grid, dw_oihw);
+    static_assert(SW_SLAB % 256 == 0, "whole reduction blocks");
+    hipLaunchKernelGGL(k_conv7_wgrad_reduce, dim3(SW_SLAB / 256), dim3(1024), 0, (hipStream_t)stream, static_cast<const float*>(workspace), grid, dw_oihw);
     return ap_check_launch();
 }
 
