@@ -325,10 +325,10 @@ class ClassBlockFn(torch.autograd.Function):
         bufs, sunk = _param_grad_buffers(params)
         (dn1w, dn1b, dkv_w, dkv_b, dq_w, dq_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = bufs
         g = dc2.contiguous()
-        with wgrad_batch():
+        with wgrad_batch() as batch:
             dh = _linear_bwd(g, a, fc2_w, dfc2_w, dfc2_b, dgelu_of=h)
             dn2 = _linear_bwd(dh, n2, fc1_w, dfc1_w, dfc1_b)
-            dc1 = ops.layernorm_bwd(dn2, c1, n2w, m2, r2, g, dn2w, dn2b)
+            dc1 = ops.layernorm_bwd(dn2, c1, n2w, m2, r2, g, dn2w, dn2b, defer=batch.ln)
             do = _linear_bwd(dc1, o, proj_w, dproj_w, dproj_b)
             dq, dkv_t, dkv_c = ops.class_attn_bwd(q, kv_t, probs, do, B, N + 1, heads, scale, kv_cls=kv_c)
             dnt = _linear_bwd(dkv_t, nt, kv_w, dkv_w, dkv_b)
@@ -336,8 +336,8 @@ class ClassBlockFn(torch.autograd.Function):
             _linear_bwd(dq, nc, q_w, dq_w, dq_b, need_dx=False)
             wq_t = bank.get_t(q_w)
             dnc = ops.gemm_nt(dq, wq_t, n=wq_t.shape[0], k=wq_t.shape[1], residual=dnc_kv)      # dq Wq + dkv_c Wkv in one epilogue
-            dcls = ops.layernorm_bwd(dnc, c0, n1w, mc, rc, dc1, dn1w, dn1b)
-            dtok = ops.layernorm_bwd(dnt, t0, n1w, mt, rt, None, dn1w, dn1b)
+            dcls = ops.layernorm_bwd(dnc, c0, n1w, mc, rc, dc1, dn1w, dn1b)       # reduced at once: it shares dn1w / dn1b with the deferred
+            dtok = ops.layernorm_bwd(dnt, t0, n1w, mt, rt, None, dn1w, dn1b, defer=batch.ln)      # token piece (two deferred sums into one vector would race)
         return (dcls.view(ctx.shapes[0]), dtok.view(ctx.shapes[1]), *_finish_param_grads(params, bufs, sunk), None, None, None, None)
 
 
