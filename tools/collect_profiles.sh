@@ -3,7 +3,7 @@
 #   gpurun_out/r02_bench_n1.json      the default bench line (roofline + cpu_baseline)
 #   gpurun_out/r02_kernel_stats.txt   rocprofv3 --kernel-trace --stats summary of the same command (timed steps only)
 #   gpurun_out/r02_pmc_counters.txt   rocprofv3 --pmc passes (one counter group per pass, no tracing) per kernel
-#   gpurun_out/r02_kernel_table.txt   one line per kernel: HBM bytes, TB/s, MFMA busy %, LDS conflict share (tools/pmc_table.py)
+#   gpurun_out/r02_kernel_table.txt   one line per kernel: HBM bytes, TB/s, MFMA busy %, VALU busy %, LDS conflict share (tools/pmc_table.py)
 #   gpurun_out/gemm_nt_traffic.json   HBM bytes per k_gemm_nt launch from FETCH_SIZE/WRITE_SIZE (gfx950 correction applied)
 # Copy them into profiles/ afterwards.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -17,7 +17,7 @@ fi
 i=0
 # FETCH_SIZE and WRITE_SIZE are derived metrics that do not fit one pass together ("exceeds the capabilities of the hardware",
 # after which rocprofv3 aborts and hangs): one pass each, every pass under a hard timeout
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_TRANS"; do
   i=$((i+1))
   timeout 240 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/_pmc/p$i -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/_pmc$i.log 2>&1
 done
