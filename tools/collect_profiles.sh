@@ -17,7 +17,7 @@ fi
 i=0
 # FETCH_SIZE and WRITE_SIZE are derived metrics that do not fit one pass together ("exceeds the capabilities of the hardware",
 # after which rocprofv3 aborts and hangs): one pass each, every pass under a hard timeout
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_TRANS"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"; do
   i=$((i+1))
   timeout 240 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/_pmc/p$i -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/_pmc$i.log 2>&1
 done
