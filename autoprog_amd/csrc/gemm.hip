@@ -23,6 +23,7 @@
 #include "common.h"
 #include <type_traits>
 #include "gemm_epi.h"
+#include "gemm8p.h"
 #ifndef AP_EXPERIMENTS
 #define AP_EXPERIMENTS 0       // 1: also build the measured-and-rejected kernels (LDS-DMA rings, persistent tiles) and their AP_GEMM_* switches
 #endif
@@ -1208,6 +1209,60 @@ k_gemm_tn_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__
 
 #endif  // AP_EXPERIMENTS
 
+// launch of the persistent 8-phase kernel (gemm8p.h): one instantiation per epilogue flavour of the training step, a generic one
+// for anything else
+template <int NT1, int EF>
+static void g8_go(const G8Args& ga, const EpiArgs& ep, int grid, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_gemm_nt_8p<NT1, EF>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS_BYTES); attr = true; (void)hipGetLastError(); }
+    hipLaunchKernelGGL((k_gemm_nt_8p<NT1, EF>), dim3(grid), dim3(512), G8_LDS_BYTES, st, ga, ep);
+}
+template <int NT1>
+static void g8_pick(const G8Args& ga, const EpiArgs& ep, int grid, hipStream_t st) {
+    switch (g8_flavour(ep)) {
+        case 0: g8_go<NT1, 0>(ga, ep, grid, st); break;
+        case G8_BIAS: g8_go<NT1, G8_BIAS>(ga, ep, grid, st); break;
+        case G8_RS: g8_go<NT1, G8_RS>(ga, ep, grid, st); break;
+        case G8_BIAS | G8_GELU: g8_go<NT1, G8_BIAS | G8_GELU>(ga, ep, grid, st); break;
+        case G8_BIAS | G8_GELU | G8_RS: g8_go<NT1, G8_BIAS | G8_GELU | G8_RS>(ga, ep, grid, st); break;
+        case G8_DGELU: g8_go<NT1, G8_DGELU>(ga, ep, grid, st); break;
+        case G8_DGELU | G8_RS: g8_go<NT1, G8_DGELU | G8_RS>(ga, ep, grid, st); break;
+        case G8_BIAS | G8_RES: g8_go<NT1, G8_BIAS | G8_RES>(ga, ep, grid, st); break;
+        case G8_BIAS | G8_RS | G8_RES: g8_go<NT1, G8_BIAS | G8_RS | G8_RES>(ga, ep, grid, st); break;
+        default: g8_go<NT1, -1>(ga, ep, grid, st); break;
+    }
+}
+static int g8_launch(int bn, const bf16_t* A, int lda, const bf16_t* B, int ldb, bf16_t* C, int ldc, int M, int N, int K, const EpiArgs& ep, hipStream_t st) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr;
+        n_cu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+    }
+    G8Args ga;
+    ga.A = A; ga.lda = lda; ga.B = B; ga.ldb = ldb; ga.C = C; ga.ldc = ldc; ga.M = M; ga.N = N; ga.K = K;
+    ga.tiles_n = (N + bn - 1) / bn; ga.ntiles = ((M + 255) / 256) * ga.tiles_n;
+    const int cap = n_cu & ~7, want = (ga.ntiles + 7) & ~7;        // a multiple of 8: the kernel deals tiles per XCD label
+    const int grid = want < cap ? want : cap;
+    if (bn == 192) g8_pick<1>(ga, ep, grid, st); else g8_pick<2>(ga, ep, grid, st);
+    return ap_check_launch();
+}
+
+// Where the persistent 8-phase kernel is picked.  It is the faster kernel on long reductions (1.50 PFLOP/s at 8192^3 against
+// 0.85 for k_gemm_nt) and it pays a serial tile epilogue plus a whole-CU launch boundary (128 KB of LDS: no overlap with the
+// neighbouring kernels' tails), so inside the training step it wins from K >= 768 on; AP_GEMM_8P = 0 never, 1 (default) plain /
+// bias / row-scale epilogues, 2 also the epilogues that read a second tile (faster stand-alone, slower in the D1 step).
+static int use_8p(int M, int N, int K, int ldc, const EpiArgs& ep) {          // -> 0 (no), 192 or 256 (block tile width)
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("AP_GEMM_8P"); mode = e ? atoi(e) : 1; }
+    if (mode == 0 || (K & 63) || K < 128 || M < 4096 || (N & 7) || (ldc & 7) || (ep.residual && (ep.ldr & 7))) return 0;
+    const int bn = N >= 1024 ? 256 : (N % 192 == 0 ? 192 : (N % 256 == 0 ? 256 : 0));
+    if (bn == 0 || N < 192) return 0;
+    if (mode >= 3) return bn;
+    if (K < 768 || N < 384) return 0;
+    if (ep.gelu || ep.dgelu_of || ep.residual) return mode >= 2 ? bn : 0;
+    return bn;
+}
+
 extern "C" {
 
 int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C, int ldc, int M, int N, int K,
@@ -1343,6 +1398,7 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         // cache-warm operands (33.9 vs 37.2 us on the dfc1 shape when the same buffers are reused back to back) but the training
         // step, whose operands come from HBM, is 0.3 ms SLOWER with them -> off by default
         if (allow192 && N % 192 == 0 && N >= 384 && M >= 4096 && !ep.gelu && !ep.dgelu_of && !ep.residual && K >= 384) variant = 10;
+        else if (const int bn8 = use_8p(M, N, K, ldc, ep)) variant = bn8 == 192 ? 20 : 21;   // persistent 8-phase kernel (gemm8p.h)
         else if (N <= 512 && K <= 256) variant = 4;                              // 64x64
         else if (N <= 256 || ((N % 128 != 0) && (N % 64 == 0))) variant = 2;     // 128x64
         else variant = 1;                                                        // 128x128
@@ -1374,6 +1430,9 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         for (int i = 0; i < nrules; ++i)
             if (rules[i][0] == N && rules[i][1] == K && forced == 0) { variant = rules[i][2]; rule_epi = rules[i][3]; }
     }
+    // variants 20 / 21: the persistent 8-phase kernel of gemm8p.h with 256 x 192 / 256 x 256 tiles (whole 8-column chunks only)
+    if ((variant == 20 || variant == 21) && ((K & 63) || (N & 7) || (ldc & 7) || (ep.residual && (ep.ldr & 7)))) variant = 1;
+    if (variant == 20 || variant == 21) return g8_launch(variant == 20 ? 192 : 256, A, lda, B, ldb, C, ldc, M, N, K, ep, (hipStream_t)stream);
     const int lds_epi = rule_epi >= 0 ? rule_epi : (lds_epi_env >= 0 ? lds_epi_env : (variant != 2 && variant != 10));
 #define NT_LAUNCH(TMv, TNv, WMv, WNv)                                                                        \
     {                                                                                                          \

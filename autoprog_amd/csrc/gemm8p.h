@@ -8,13 +8,15 @@
 //   C[M,N] = epi(A[M,K] . B[N,K]^T)       (the Linear layers of models/volo.py:67,68,71,156,158,180,182 and
 //                                          their input gradients; same contract as k_gemm_nt in gemm.hip)
 //
-// Geometry.  Wave (wr, wc) = (wave >> 2, wave & 3).  The block tile is cut into half-tiles that a PHASE
-// consumes whole, so that a half-tile is dead (restageable) one or two phases after it was read:
+// Geometry.  Block tile 256 x BN, BN = 4 * WN, WN = 32 + 16 * NT1 (NT1 = 2: 256 x 256; NT1 = 1: 256 x 192 -- every Linear
+// width of VOLO-D1 except the heads is a multiple of 192).  Wave (wr, wc) = (wave >> 2, wave & 3).  The block tile is cut
+// into parts that a PHASE consumes whole, so that a part is dead (restageable) one or two phases after it was read:
 //   A half h  = block rows h*128 .. h*128+127; wave (wr, .) reads rows wr*64 .. wr*64+63 of it
-//   B half h  = for every wc the 32 columns wc*64 + h*32 .. +31 (image rows wc*32 .. wc*32+31)
-// A wave therefore owns output rows {h*128 + wr*64 + [0,64)} x columns {wc*64 + [0,64)}: four 64 x 32
-// quadrants (mh, nh), one per phase: (0,0) (0,1) (1,1) (1,0).  B fragments of both halves stay in
-// registers for the whole K-tile, A fragments of one half at a time.
+//   B part 0  = for every wc the 32 columns wc*WN .. +31          (image rows wc*32 .. wc*32+31)
+//   B part 1  = for every wc the 16*NT1 columns wc*WN + 32 .. (image rows wc*16*NT1 ..)
+// A wave therefore owns output rows {h*128 + wr*64 + [0,64)} x columns {wc*WN + [0,WN)}: four quadrants (mh, part), one per
+// phase: (0,0) (0,1) (1,1) (1,0) with 16 / 8*NT1 / 8*NT1 / 16 MFMAs.  B fragments of both parts stay in registers for the
+// whole K-tile, A fragments of one half at a time.
 //
 // LDS image of a half-tile: 16 subtiles [16 rows][32 k] of 1024 B (= one wave-instruction of the DMA),
 // subtile (rb, kb) at ((rb * 2 + kb) * 1024); inside a subtile byte (r * 64 + c * 2) ^ (((r >> 3) & 1) << 5)
@@ -24,7 +26,16 @@
 // The MFMA is issued as D = Bfrag (A operand) x Afrag (B operand): a lane ends with 4 consecutive output
 // columns of one row; the B image rows are permuted (row wc*32 + nt*16 + i  <->  column wc*64 + h*32 + (i>>2)*8
 // + nt*4 + (i&3)) so that the two 16-column tiles of a quadrant give a lane 8 CONSECUTIVE columns: 16-byte
-// stores / epilogue-operand loads, 64 contiguous bytes per row and instruction.
+// stores / epilogue-operand loads, 64 contiguous bytes per row and instruction (the single 16-column tile of part 1 at
+// NT1 = 1 keeps its natural order: 4 consecutive columns, 8-byte accesses).
+//
+// Tile end.  The first wave group waits one barrier for the second (both then hold their results), the epilogues of all eight
+// waves run together, straight from the accumulators, and the second group falls one barrier behind again.  The load stream is
+// not interrupted: the next tile's first K-tiles land under the epilogue.  (Measured and dropped: the epilogue cut into quadrants
+// and run inside the load sections of the following four phases -- bias / row scale by LDS-DMA, second operand by hand-counted asm
+// loads; tools/gemm_lab/gemm8p_distributed_epilogue.h.txt.  A CU stores ~10 B/clk, so a quadrant's stores hold its wave group's
+// load section for ~1600 cycles against the ~256 of the other group's MFMA cluster, and the two groups' epilogues, which run side
+// by side here, then run one after the other: qkv shape 38.9 -> 43.1 us, fc1 + GELU 68 -> 84 us.)
 //
 // Stream.  A workgroup walks its output tiles (tile = first + j * gridDim.x) and their K-tiles as ONE stream
 // of half-tile loads, 7 half-tiles ahead of the reads at the prologue and 3 in flight behind every counted
@@ -32,15 +43,25 @@
 #pragma once
 #include "common.h"
 #include "gemm_epi.h"
+#include <type_traits>
 
-#define G8_LDS_BYTES (2 * 4 * 16384)
+#define G8_LDS_BYTES 163840                    // all of the CU's LDS: two K-tile buffers + the epilogue staging region
 
 #define G8_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
 #define G8_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
 #ifndef G8_ABL
-#define G8_ABL 0          // timing-only ablations (lab builds): 1 no MFMA, 2 no LDS reads, 4 no DMA, 8 no epilogue stores
+#define G8_ABL 0          // timing-only ablations (lab builds): 1 no MFMA, 2 no LDS reads, 4 no DMA, 8 no epilogue (accumulators kept alive)
 #endif
+
+// LDS accesses of the epilogue in inline asm: behind a pending LDS-DMA (the stream's prefetch of the next tile) hipcc guards every
+// ds_read / ds_write it can see with s_waitcnt vmcnt(0), which also waits for the epilogue's own stores, one by one.  These are
+// counted by hand (lgkmcnt) and never alias the K-tile buffers the DMA writes.
+__device__ __forceinline__ unsigned g8_lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
+__device__ __forceinline__ void g8_lds_st16(unsigned a, const u32x4& v) { asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void g8_lds_st8(unsigned a, const u32x2& v) { asm volatile("ds_write_b64 %0, %1" :: "v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ u32x4 g8_lds_ld16(unsigned a) { u32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory"); return v; }
+__device__ __forceinline__ u32x2 g8_lds_ld8(unsigned a) { u32x2 v; asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(a) : "memory"); return v; }
 
 struct G8Args {
     const bf16_t* A; int lda;
@@ -50,79 +71,194 @@ struct G8Args {
     int tiles_n, ntiles;
 };
 
-template <int EPI_MODE>
+// epilogue of W (8 or 4) consecutive output columns [n, n+W) of row m, all inside the matrix; every leading dimension a multiple
+// of 8 elements.  Same operations, same order and same rounding points as epi_chunk (gemm_epi.h).
+template <int W>
+__device__ __forceinline__ void g8_epi(float* v, int m, int n, int ldc, const EpiArgs& ep, bf16_t* __restrict__ C) {
+    typedef typename std::conditional<W == 8, u32x4, u32x2>::type pk_t;
+    auto unpack = [](const pk_t& x, float* f) {
+#pragma unroll
+        for (int i = 0; i < W / 2; ++i) { f[2 * i] = bf_lo(x[i]); f[2 * i + 1] = bf_hi(x[i]); }
+    };
+    auto pack = [](const float* f) {
+        pk_t x;
+#pragma unroll
+        for (int i = 0; i < W / 2; ++i) x[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+        return x;
+    };
+    if (ep.bias) {
+#pragma unroll
+        for (int q = 0; q < W; q += 4) {
+            const float4 b = *reinterpret_cast<const float4*>(ep.bias + n + q);
+            v[q] += b.x; v[q + 1] += b.y; v[q + 2] += b.z; v[q + 3] += b.w;
+        }
+    }
+    if (ep.gelu) {
+        if (ep.preact) {
+            const pk_t h = pack(v);
+            *reinterpret_cast<pk_t*>(ep.preact + (int64_t)m * ldc + n) = h;
+            unpack(h, v);
+        }
+#pragma unroll
+        for (int q = 0; q < W; ++q) v[q] = gelu_erf(v[q]);
+    }
+    if (ep.dgelu_of) {
+        float h[W];
+        unpack(*reinterpret_cast<const pk_t*>(ep.dgelu_of + (int64_t)m * ldc + n), h);
+#pragma unroll
+        for (int q = 0; q < W; ++q) v[q] *= gelu_erf_grad(h[q]);
+    }
+    if (ep.row_scale) {
+        const float rs = ep.row_scale[m / ep.rows_per_scale];
+#pragma unroll
+        for (int q = 0; q < W; ++q) v[q] *= rs;
+    }
+    if (ep.residual) {
+        float h[W];
+        unpack(*reinterpret_cast<const pk_t*>(ep.residual + (int64_t)m * ep.ldr + n), h);
+#pragma unroll
+        for (int q = 0; q < W; ++q) v[q] += h[q];
+    }
+    *reinterpret_cast<pk_t*>(C + (int64_t)m * ldc + n) = pack(v);
+}
+
+// epilogue flavour of an instantiation (EF >= 0: bits known at compile time; EF < 0: read from the arguments at run time).  The
+// generic epilogue is ~25 KB of code that a CU runs once or twice per launch, cold: an instantiation per flavour of the training
+// step keeps what is fetched to what is used (2.8 us -> see DESIGN.md on the 25088 x 384 x 1152 launch).
+enum { G8_BIAS = 1, G8_GELU = 2, G8_DGELU = 4, G8_RS = 8, G8_RES = 16 };
+__host__ __device__ inline int g8_flavour(const EpiArgs& ep) {
+    return (ep.bias ? G8_BIAS : 0) | (ep.gelu ? G8_GELU : 0) | (ep.dgelu_of ? G8_DGELU : 0) | (ep.row_scale ? G8_RS : 0) | (ep.residual ? G8_RES : 0);
+}
+
+// NT1: B part 1 holds NT1 16-column tiles per wave (1: 256 x 192 block tile, 2: 256 x 256).
+template <int NT1, int EF>
 __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
+    const bool has_bias = EF < 0 ? ep.bias != nullptr : (EF & G8_BIAS) != 0;
+    const bool has_gelu = EF < 0 ? ep.gelu != 0 : (EF & G8_GELU) != 0;
+    const bool has_dgelu = EF < 0 ? ep.dgelu_of != nullptr : (EF & G8_DGELU) != 0;
+    const bool has_rs = EF < 0 ? ep.row_scale != nullptr : (EF & G8_RS) != 0;
+    const bool has_res = EF < 0 ? ep.residual != nullptr : (EF & G8_RES) != 0;
+    constexpr int WN = 32 + 16 * NT1, BN = 4 * WN;
+    constexpr int VMN = 4 + NT1;                 // DMA instructions of the three parts in flight behind a counted wait
+    constexpr int KS = 49152 + 8192 * NT1;       // bytes of a K-tile buffer (A h0 | A h1 | B part 0 | B part 1); the two buffers are adjacent
+    constexpr int STG = 2 * KS;                  // epilogue staging region: the rest of the LDS (48 KB at BN = 192, 32 KB at BN = 256)
+    constexpr int PASS_MT = NT1 == 1 ? 4 : 2;    // 16-row tiles per wave group and staging pass
+    constexpr int NPASS = 8 / PASS_MT;
+    constexpr int RS = BN * 2;                   // bytes of a staged row
+    constexpr int GRP = 16 * PASS_MT * RS;       // bytes of a wave group's staging area (24 KB / 16 KB)
+    static_assert(STG + 2 * GRP <= G8_LDS_BYTES, "staging region");
     extern __shared__ __attribute__((aligned(16))) unsigned char g8_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, g = lane >> 4;
     const int nk = ga.K >> 6;
 
-    // ---- DMA source geometry (per lane): image row srow of a half-tile, 16-byte chunk scol of a 32-wide k block
-    const int lp = lane ^ ((lane >> 5) << 1);
-    const int srow = wave * 16 + (lp >> 2);
-    const int scol = (lp & 3) * 8;
-    const int bi = srow & 15;
-    const int bcol = (srow >> 5) * 64 + (bi >> 2) * 8 + ((srow >> 4) & 1) * 4 + (bi & 3);      // + h * 32
-    unsigned char* const dma_dst = g8_smem + wave * 2048;                                       // + slot + kb * 1024
+    // ---- DMA source geometry (per lane).  A wave-instruction fills one 1 KB piece: 8 image rows x 64 k, i.e. it fetches eight
+    // whole 128-byte lines (16 rows x 32 k, half lines, measured slower: twice the L2 requests).  Lane l writes LDS bytes
+    // [16 l, 16 l + 16) of the piece, which hold 16-byte chunk (l & 7) ^ (row & 7) of row l >> 3: the swizzle is applied to the
+    // SOURCE address and again to the read address.
+    // K-tile buffer (KS bytes, the second one right behind the first): A h0 at 0, A h1 at 16384, B part 0 at 32768, B part 1 at
+    // 49152; image row r of a part at (r >> 3) * 1024 + (r & 7) * 128.
+    const int sr8 = lane >> 3;                                   // row inside the piece
+    const int scol = ((lane & 7) ^ sr8) * 8;                     // element column inside the 64-wide k tile
+    // 128-row parts: wave w fills pieces 2w, 2w + 1 = image rows 16 w .. 16 w + 15
+    const int srow = wave * 16 + sr8;                            // (+ 8 for the second piece)
+    // B part 0: image row wc*32 + nt*16 + i  <->  column wc*WN + (i >> 2)*8 + nt*4 + (i & 3)
+    auto bcol0_of = [&](int r) { const int i = r & 15; return (r >> 5) * WN + (i >> 2) * 8 + ((r >> 4) & 1) * 4 + (i & 3); };
+    // part 1: NT1 = 2 -> 128 image rows, same pairing; NT1 = 1 -> 64 image rows in natural order, ONE piece per wave (rows 8 w ..)
+    const int srow1 = NT1 == 2 ? srow : wave * 8 + sr8;
+    auto bcol1_of = [&](int r) { return NT1 == 2 ? bcol0_of(r) + 32 : (r >> 4) * WN + 32 + (r & 15); };
+    unsigned char* const dma_dst = g8_smem + wave * 2048;
+    unsigned char* const dma_dst1 = g8_smem + 49152 + (NT1 == 2 ? wave * 2048 : wave * 1024);
 
-    // ---- fragment read addresses
-    const int lane_off = fr * 64 + ((g ^ ((fr >> 3) << 1)) << 4);
-    const unsigned char* const rdA = g8_smem + wr * 8192 + lane_off;          // + buf*65536 + h*16384 + (mt*2+kb)*1024
-    const unsigned char* const rdB = g8_smem + 32768 + wc * 4096 + lane_off;  // + buf*65536 + h*16384 + (nt*2+kb)*1024
+    // ---- fragment read addresses: row fr of a 16-row tile, chunk kb * 4 + g
+    const int lane_row = (fr >> 3) * 1024 + (fr & 7) * 128;
+    const int lane_off0 = lane_row + ((g ^ (fr & 7)) << 4);              // kb = 0
+    const int lane_off1 = lane_row + (((4 + g) ^ (fr & 7)) << 4);        // kb = 1
+    const unsigned char* const rdA = g8_smem + wr * 8192;                          // + bo + h*16384 + mt*2048 + lane_off{kb}
+    const unsigned char* const rdB0 = g8_smem + 32768 + wc * 4096;                 // + bo + nt*2048 + lane_off{kb}
+    const unsigned char* const rdB1 = g8_smem + 49152 + wc * (2048 * NT1);         // + bo + nt*2048 + lane_off{kb}
+
+    // ---- tile walk: the workgroups that share an XCD (blockIdx % 8, dealt round-robin) take a CONTIGUOUS range of tile ids
+    // (n fastest), so the tiles in flight on one XCD share their A row panels and the weight panel in that XCD's L2
+    const int nxw = (gridDim.x + 7) >> 3;                          // workgroups per XCD label (the grid is a multiple of 8)
+    const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+    const int xq = ga.ntiles >> 3, xr = ga.ntiles & 7;
+    const int t_begin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
+    const int t_end = (xcd < xr ? (xcd + 1) * (xq + 1) : xr * (xq + 1) + (xcd + 1 - xr) * xq);
+    if (t_begin >= t_end) return;                                  // (whole workgroup; before any barrier)
 
     // ---- issue side of the stream
-    int q_tile = blockIdx.x, q_kt = 0;
-    const bf16_t *qa0, *qa1, *qb0, *qb1;
+    int q_tile = t_begin, q_kt = 0;
+    // per-lane source pointers of the two pieces of each part (row pointers: rows 8 apart are NOT a constant apart at the matrix edge)
+    const bf16_t *qa0[2], *qa1[2], *qb0[2], *qb1[NT1];
     auto set_q = [&]() {
-        const int t = q_tile < ga.ntiles ? q_tile : ga.ntiles - 1;
-        const int m0 = (t / ga.tiles_n) * 256, n0 = (t % ga.tiles_n) * 256;
-        qa0 = ga.A + (int64_t)min(m0 + srow, ga.M - 1) * ga.lda + scol;
-        qa1 = ga.A + (int64_t)min(m0 + 128 + srow, ga.M - 1) * ga.lda + scol;
-        qb0 = ga.B + (int64_t)min(n0 + bcol, ga.N - 1) * ga.ldb + scol;
-        qb1 = ga.B + (int64_t)min(n0 + bcol + 32, ga.N - 1) * ga.ldb + scol;
+        const int t = q_tile < t_end ? q_tile : t_end - 1;
+        const int m0 = (t / ga.tiles_n) * 256, n0 = (t % ga.tiles_n) * BN;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            qa0[j] = ga.A + (int64_t)min(m0 + srow + 8 * j, ga.M - 1) * ga.lda + scol;
+            qa1[j] = ga.A + (int64_t)min(m0 + 128 + srow + 8 * j, ga.M - 1) * ga.lda + scol;
+            qb0[j] = ga.B + (int64_t)min(n0 + bcol0_of(srow + 8 * j), ga.N - 1) * ga.ldb + scol;
+        }
+#pragma unroll
+        for (int j = 0; j < NT1; ++j) qb1[j] = ga.B + (int64_t)min(n0 + bcol1_of(srow1 + 8 * j), ga.N - 1) * ga.ldb + scol;
     };
     set_q();
-    // half-tile slots inside a K-tile buffer: 0 = A h0, 1 = A h1, 2 = B h0, 3 = B h1
-    auto dma = [&](const bf16_t* src, int bufoff, int slot) {           // bufoff = 0 / 65536: the K-tile buffer
+    auto dma = [&](const bf16_t* const* src, int bufoff, int part) {   // parts 0 / 1 / 2: A h0, A h1, B part 0 (two pieces per wave)
         if (!(G8_ABL & 4)) {
-            __builtin_amdgcn_global_load_lds(G8_GLB(src + q_kt * 64), G8_LDS(dma_dst + bufoff + slot * 16384), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(G8_GLB(src + q_kt * 64 + 32), G8_LDS(dma_dst + bufoff + slot * 16384 + 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(G8_GLB(src[0] + q_kt * 64), G8_LDS(dma_dst + bufoff + part * 16384), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(G8_GLB(src[1] + q_kt * 64), G8_LDS(dma_dst + bufoff + part * 16384 + 1024), 16, 0, 0);
+        }
+    };
+    auto dma1 = [&](int bufoff) {                                        // B part 1
+        if (!(G8_ABL & 4)) {
+            __builtin_amdgcn_global_load_lds(G8_GLB(qb1[0] + q_kt * 64), G8_LDS(dma_dst1 + bufoff), 16, 0, 0);
+            if constexpr (NT1 == 2) __builtin_amdgcn_global_load_lds(G8_GLB(qb1[NT1 - 1] + q_kt * 64), G8_LDS(dma_dst1 + bufoff + 1024), 16, 0, 0);
         }
     };
     auto q_advance = [&]() {
-        if (++q_kt == nk) { q_kt = 0; q_tile += gridDim.x; set_q(); }
+        if (++q_kt == nk) { q_kt = 0; q_tile += nxw; set_q(); }
     };
 
-    f32x4 acc[2][2][4][2];
-    u32x4 af[4][2], bf[2][2][2];
+    f32x4 acc0[2][4][2], acc1[2][4][NT1];        // [mh][mt][nt] of part 0 / part 1
+    u32x4 af[4][2], bf0[2][2], bf1[NT1][2];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int d = 0; d < 2; ++d) acc0[a][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int d = 0; d < NT1; ++d) acc1[a][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
     };
     auto readA = [&](const unsigned char* base, int h) {
         if (!(G8_ABL & 2)) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) af[mt][kb] = ld16(base + h * 16384 + (mt * 2 + kb) * 1024);
+                for (int kb = 0; kb < 2; ++kb) af[mt][kb] = ld16(base + h * 16384 + mt * 2048 + (kb ? lane_off1 : lane_off0));
         }
     };
-    auto readB = [&](const unsigned char* base, int h) {
+    auto readB0 = [&](const unsigned char* base) {
         if (!(G8_ABL & 2)) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) bf[h][nt][kb] = ld16(base + h * 16384 + (nt * 2 + kb) * 1024);
+                for (int kb = 0; kb < 2; ++kb) bf0[nt][kb] = ld16(base + nt * 2048 + (kb ? lane_off1 : lane_off0));
         }
     };
-    auto mma = [&](int mh, int nh) {
+    auto readB1 = [&](const unsigned char* base) {
+        if (!(G8_ABL & 2)) {
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) bf1[nt][kb] = ld16(base + nt * 2048 + (kb ? lane_off1 : lane_off0));
+        }
+    };
+    auto mma0 = [&](int mh) {
         if (!(G8_ABL & 1)) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -131,86 +267,245 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        acc[mh][nh][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(bf[nh][nt][kb]), as_bf16x8(af[mt][kb]),
-                                                                                     acc[mh][nh][mt][nt], 0, 0, 0);
+                        acc0[mh][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(bf0[nt][kb]), as_bf16x8(af[mt][kb]), acc0[mh][mt][nt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    };
+    auto mma1 = [&](int mh) {
+        if (!(G8_ABL & 1)) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT1; ++nt)
+                        acc1[mh][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(bf1[nt][kb]), as_bf16x8(af[mt][kb]), acc1[mh][mt][nt], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
     };
 #define G8_BAR() __builtin_amdgcn_s_barrier()
 #define G8_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
-#define G8_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define G8_VM(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
 #define G8_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-    // One K-tile = four phases on buffer BUF.  q_live: the half-tiles issued here are real (more stream left).
-    auto ktile = [&](int bo) {               // bo = 0 / 65536: byte offset of this K-tile's buffer
-        const unsigned char* const ra = rdA + bo;
-        const unsigned char* const rb = rdB + bo;
-        // phase 1: quadrant (0,0); completes K-tile T+1 (A h1 into the other buffer)
-        readB(rb, 0); G8_FENCE(); readA(ra, 0); G8_FENCE();
-        const bool live1 = q_tile < ga.ntiles;
-        if (live1) dma(qa1, bo ^ 65536, 1);
+    // One K-tile T = four phases on the buffer at byte offset bo.  A part is restaged (with K-tile T+2) two phases after the phase
+    // that read it -- one phase after for B part 0, whose reads are retired by the lgkmcnt(8) in front of phase 1's first barrier --
+    // and read one phase after the counted wait that retires it (phase 4's, for the whole other buffer).
+    auto ktile = [&](int bo) {
+        // phase 1: quadrant (0, part 0); completes K-tile T+1 (A h1 into the other buffer)
+        readB0(rdB0 + bo); G8_FENCE(); readA(rdA + bo, 0); G8_FENCE();
+        if (q_tile < t_end) dma(qa1, KS - bo, 1);
         q_advance();
         G8_LGKM(8); G8_FENCE();
         G8_BAR(); G8_LGKM(0); G8_FENCE();
-        mma(0, 0); G8_FENCE();
+        mma0(0); G8_FENCE();
         G8_BAR();
-        // phase 2: quadrant (0,1); B h0 of K-tile T+2 into this buffer (its reads were retired by the lgkmcnt(8) above)
-        const bool live = q_tile < ga.ntiles;
-        readB(rb, 1); G8_FENCE();
+        // phase 2: quadrant (0, part 1); B part 0 of K-tile T+2
+        const bool live = q_tile < t_end;
+        readB1(rdB1 + bo); G8_FENCE();
         if (live) dma(qb0, bo, 2);
         G8_BAR(); G8_LGKM(0); G8_FENCE();
-        mma(0, 1); G8_FENCE();
+        mma1(0); G8_FENCE();
         G8_BAR();
-        // phase 3: quadrant (1,1); A h0 of K-tile T+2
-        readA(ra, 1); G8_FENCE();
+        // phase 3: quadrant (1, part 1); A h0 of K-tile T+2
+        readA(rdA + bo, 1); G8_FENCE();
         if (live) dma(qa0, bo, 0);
         G8_BAR(); G8_LGKM(0); G8_FENCE();
-        mma(1, 1); G8_FENCE();
+        mma1(1); G8_FENCE();
         G8_BAR();
-        // phase 4: quadrant (1,0); B h1 of K-tile T+2; the counted wait retires the OTHER buffer (K-tile T+1)
-        if (live) { dma(qb1, bo, 3); G8_VM(6); } else { G8_VM(0); }
+        // phase 4: quadrant (1, part 0); B part 1 of K-tile T+2; the counted wait retires the OTHER buffer (K-tile T+1)
+        if (live) { dma1(bo); G8_VM(VMN); } else { G8_VM(0); }
         G8_FENCE();
         G8_BAR();
-        mma(1, 0); G8_FENCE();
+        mma0(1); G8_FENCE();
         G8_BAR();
     };
 
     // ---- prologue: K-tile 0 whole, K-tile 1 without its A h1
     {
-        dma(qb0, 0, 2); dma(qa0, 0, 0); dma(qb1, 0, 3); dma(qa1, 0, 1);
+        dma(qb0, 0, 2); dma(qa0, 0, 0); dma1(0); dma(qa1, 0, 1);
         q_advance();
-        if (q_tile < ga.ntiles) { dma(qb0, 65536, 2); dma(qa0, 65536, 0); dma(qb1, 65536, 3); G8_VM(6); } else { G8_VM(0); }
+        if (q_tile < t_end) { dma(qb0, KS, 2); dma(qa0, KS, 0); dma1(KS); G8_VM(VMN); } else { G8_VM(0); }
         G8_FENCE();
         G8_BAR();
     }
-    if (wr == 1) G8_BAR();            // the second wave group runs one barrier behind the first
 
     int bo = 0;
-    for (int tile = blockIdx.x; tile < ga.ntiles; tile += gridDim.x) {
+    for (int tile = t_begin; tile < t_end; tile += nxw) {
+        if (wr == 1) G8_BAR();            // the second wave group runs one barrier behind the first
         zero_acc();
-        for (int kt = 0; kt < nk; ++kt) { ktile(bo); bo ^= 65536; }
-        // ---- epilogue, straight from the accumulators: lane (fr, g) holds row fr of each 16-row tile, 8 consecutive columns per quadrant
-        const int m0 = (tile / ga.tiles_n) * 256, n0 = (tile % ga.tiles_n) * 256;
-        const bool vec_ok = (ga.ldc & 7) == 0;
-        if (!(G8_ABL & 8)) {
+        for (int kt = 0; kt < nk; ++kt) { ktile(bo); bo = KS - bo; }
+        if (wr == 0) G8_BAR();            // ... and is waited for here: the eight epilogues run together
+        // ---- epilogue, straight from the accumulators: lane (fr, g) holds row fr of each 16-row tile
+        const int m0 = (tile / ga.tiles_n) * 256, n0 = (tile % ga.tiles_n) * BN;
+        if (G8_ABL & 8) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) asm volatile("" :: "v"(acc0[a][c][d]));
+#pragma unroll
+                    for (int d = 0; d < NT1; ++d) asm volatile("" :: "v"(acc1[a][c][d]));
+                }
+        } else if (G8_ABL & 16) {
+            // timing probe (results WRONG): the same bytes stored as whole 1 KB pieces (full 128-byte lines)
+            bf16_t* base = ga.C + (int64_t)m0 * ga.ldc + (int64_t)n0 * 256 + wave * (16 * (2 + NT1) * 512) + lane * 8;
+            int k = 0;
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const int m = m0 + mh * 128 + wr * 64 + mt * 16 + fr;
+                    float v[8];
 #pragma unroll
-                    for (int nh = 0; nh < 2; ++nh) {
-                        const int n = n0 + wc * 64 + nh * 32 + g * 8;
-                        if (m < ga.M && n < ga.N) {
-                            float v[8];
+                    for (int r = 0; r < 4; ++r) { v[r] = acc0[mh][mt][0][r]; v[4 + r] = acc0[mh][mt][1][r]; }
+                    st16(base + (k++) * 512, pack8(v));
+                    if constexpr (NT1 == 2) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { v[r] = acc[mh][nh][mt][0][r]; v[4 + r] = acc[mh][nh][mt][1][r]; }
-                            epi_chunk(v, m, n, ga.N, ga.ldc, vec_ok, ep, ga.C);
-                        }
+                        for (int r = 0; r < 4; ++r) { v[r] = acc1[mh][mt][0][r]; v[4 + r] = acc1[mh][mt][1][r]; }
+                        st16(base + (k++) * 512, pack8(v));
+                    } else if ((mt & 1) == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[r] = acc1[mh][mt][0][r]; v[4 + r] = acc1[mh][mt + 1][0][r]; }
+                        st16(base + (k++) * 512, pack8(v));
                     }
                 }
+        } else {
+            // ---- epilogue through the staging region: whole 128-byte lines leave the CU (straight from the accumulators a lane
+            // owns 8 consecutive columns of a row, i.e. 64-byte row segments of lines that three waves share: measured 1.3 - 1.5x
+            // the time of line-sized stores on the store phase).  Per pass (16 * PASS_MT rows per wave group):
+            //   [second operand of the pass -> staging by LDS-DMA, whole lines]  barrier
+            //   accumulators (+ bias, gelu' / row scale / residual in fp32) -> bf16 -> staging, in place      barrier
+            //   staging -> global, 16 bytes per lane along rows (GELU runs here, on the stored pre-activation)   barrier
+            // A staged row keeps its 16-byte chunks XORed with (row & 7) inside each group of eight: the 8-lane groups of a
+            // ds_write_b128 then hit 8 different bank quads, and a DMA / row read still covers whole 128-byte lines.
+            unsigned char* const stg = g8_smem + STG + wr * GRP;
+            const unsigned stg_a = g8_lds_addr(stg);
+            const bf16_t* const in_src = has_dgelu ? ep.dgelu_of : (has_res ? ep.residual : nullptr);
+            const int in_ld = has_dgelu ? ga.ldc : ep.ldr;
+            const bool rowgelu = has_gelu;                        // GELU (and what follows it) is applied in the row phase
+            constexpr int CPR = BN / 8;                               // 16-byte chunks per staged row
+            constexpr int NIT = 16 * PASS_MT * CPR / 256;             // chunks per lane and pass (6 / 4)
+            const int nb = n0 + wc * WN;
+            float bias0[8], bias1[4 * NT1];
+            if (has_bias) {
+                *reinterpret_cast<float4*>(bias0) = *reinterpret_cast<const float4*>(ep.bias + min(nb + g * 8, ga.N - 8));
+                *reinterpret_cast<float4*>(bias0 + 4) = *reinterpret_cast<const float4*>(ep.bias + min(nb + g * 8, ga.N - 8) + 4);
+#pragma unroll
+                for (int q = 0; q < NT1; ++q)
+                    *reinterpret_cast<float4*>(bias1 + 4 * q) = *reinterpret_cast<const float4*>(ep.bias + min(nb + 32 + g * 4 * NT1, ga.N - 4 * NT1) + 4 * q);
+            }
+            // MFMA-layout addresses inside a staged row: part 0 = 16 bytes at chunk wc*WN/8 + g, part 1 = 8 * NT1 bytes behind it
+            const int c0 = (wc * WN) / 8 + g;
+            const int c1 = NT1 == 2 ? (wc * WN + 32) / 8 + g : (wc * WN + 32) / 8 + (g >> 1);
+            const int off0 = ((c0 ^ (fr & 7)) << 4);
+            const int off1 = ((c1 ^ (fr & 7)) << 4) + (NT1 == 2 ? 0 : (g & 1) * 8);
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int mh = pass / (NPASS / 2), mtb = (pass % (NPASS / 2)) * PASS_MT;    // this pass: tiles mt = mtb .. mtb + PASS_MT - 1 of half mh
+                const int rbase = m0 + mh * 128 + wr * 64 + mtb * 16;                        // first matrix row of the wave group's pass
+                if (has_dgelu || has_res) {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int id = it * 256 + wc * 64 + lane, row = id / CPR, p = id % CPR;
+                        const bf16_t* src = in_src + (int64_t)min(rbase + row, ga.M - 1) * in_ld + min(n0 + ((p ^ (row & 7)) << 3), ga.N - 8);
+                        __builtin_amdgcn_global_load_lds(G8_GLB(src), G8_LDS(stg + (it * 256 + wc * 64) * 16), 16, 0, 0);
+                    }
+                    G8_VM(0);
+                    G8_BAR();
+                }
+#pragma unroll
+                for (int t = 0; t < PASS_MT; ++t) {
+                    const int mt = mtb + t;
+                    const int m = min(rbase + t * 16 + fr, ga.M - 1);
+                    const unsigned rowp = stg_a + (t * 16 + fr) * RS;
+                    const float rs = has_rs ? ep.row_scale[m / ep.rows_per_scale] : 1.f;
+                    float v[8], w[4 * NT1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = acc0[mh][mt][0][r]; v[4 + r] = acc0[mh][mt][1][r]; }
+#pragma unroll
+                    for (int d = 0; d < NT1; ++d)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) w[4 * d + r] = acc1[mh][mt][d][r];
+                    if (has_bias) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += bias0[q];
+#pragma unroll
+                        for (int q = 0; q < 4 * NT1; ++q) w[q] += bias1[q];
+                    }
+                    if (!rowgelu) {
+                        u32x4 i0 = {0u, 0u, 0u, 0u}, i1 = {0u, 0u, 0u, 0u};
+                        if (has_dgelu || has_res) {
+                            i0 = g8_lds_ld16(rowp + off0);
+                            if constexpr (NT1 == 2) i1 = g8_lds_ld16(rowp + off1);
+                            else { const u32x2 t2 = g8_lds_ld8(rowp + off1); i1[0] = t2[0]; i1[1] = t2[1]; }
+                            G8_LGKM(0);
+                            asm volatile("" : "+v"(i0), "+v"(i1));
+                        }
+                        if (has_dgelu) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { v[2 * q] *= gelu_erf_grad(bf_lo(i0[q])); v[2 * q + 1] *= gelu_erf_grad(bf_hi(i0[q])); }
+#pragma unroll
+                            for (int q = 0; q < 2 * NT1; ++q) { w[2 * q] *= gelu_erf_grad(bf_lo(i1[q])); w[2 * q + 1] *= gelu_erf_grad(bf_hi(i1[q])); }
+                        }
+                        if (has_rs) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] *= rs;
+#pragma unroll
+                            for (int q = 0; q < 4 * NT1; ++q) w[q] *= rs;
+                        }
+                        if (has_res && !has_dgelu) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { v[2 * q] += bf_lo(i0[q]); v[2 * q + 1] += bf_hi(i0[q]); }
+#pragma unroll
+                            for (int q = 0; q < 2 * NT1; ++q) { w[2 * q] += bf_lo(i1[q]); w[2 * q + 1] += bf_hi(i1[q]); }
+                        }
+                    }
+                    if (G8_ABL & 128) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) asm volatile("" :: "v"(v[q]));
+#pragma unroll
+                        for (int q = 0; q < 4 * NT1; ++q) asm volatile("" :: "v"(w[q]));
+                    } else {
+                    g8_lds_st16(rowp + off0, pack8(v));
+                    if constexpr (NT1 == 2) g8_lds_st16(rowp + off1, pack8(w));
+                    else { u32x2 t2; t2[0] = pack_bf2(w[0], w[1]); t2[1] = pack_bf2(w[2], w[3]); g8_lds_st8(rowp + off1, t2); }
+                    }
+                }
+                G8_LGKM(0);
+                G8_BAR();
+                // rows out: chunk id -> (row, position p); position p of a row holds the row's 16-byte chunk p ^ (row & 7)
+                u32x4 xs[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) xs[it] = (G8_ABL & 64) ? u32x4{0u, 0u, 0u, 0u} : g8_lds_ld16(stg_a + (it * 256 + wc * 64 + lane) * 16);
+                G8_LGKM(0);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(xs[it]));
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int id = it * 256 + wc * 64 + lane, row = id / CPR, p = id % CPR;
+                    const int m = rbase + row, n = n0 + ((p ^ (row & 7)) << 3);
+                    u32x4 x = xs[it];
+                    if (m < ga.M && n < ga.N) {
+                        if (rowgelu) {
+                            // x = the bf16-rounded pre-activation (bias included): stored as it is, the activation applied to the rounded value
+                            if (ep.preact) st16(ep.preact + (int64_t)m * ga.ldc + n, x);
+                            float f[8];
+                            unpack8(x, f);
+                            const float rs = has_rs ? ep.row_scale[m / ep.rows_per_scale] : 1.f;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) f[q] = gelu_erf(f[q]) * rs;
+                            x = pack8(f);
+                        }
+                        if (!(G8_ABL & 32)) st16(ga.C + (int64_t)m * ga.ldc + n, x);
+                        else asm volatile("" :: "v"(x));
+                    }
+                }
+                if (pass + 1 < NPASS) G8_BAR();        // (the row reads were retired above)
+            }
+            G8_BAR();                     // (the staging region is free again; keeps the two groups' barrier counts equal per tile)
         }
     }
-    if (wr == 0) G8_BAR();
     G8_VM(0);
 }

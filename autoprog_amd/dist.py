@@ -107,6 +107,7 @@ class GradientBucketReducer:
     def zero_grad(self):
         """gradients stay attached to the slab (never set to None)"""
         self.flat.zero_()
+        self._pending_scale = 1.0               # a deferred 1/world that nobody consumed dies with the gradients it belonged to
         self._pending = [len(m) for (_, _, m) in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._handles = []
@@ -128,6 +129,13 @@ class GradientBucketReducer:
             self._pending_scale = 1.0 / self.world
         else:
             self.flat.mul_(1.0 / self.world)
+
+    @property
+    def grad_scale(self):
+        """what a reader of p.grad between finish() and the optimizer step must multiply by (gradient clipping, norm logging,
+        checkpoints): 1/world while a deferred mean is pending (defer_mean=True leaves the all-reduced SUM in the slab for
+        ap_adamw_ema_step to scale), else 1.  Reading does not consume it."""
+        return self._pending_scale
 
     def take_pending_scale(self):
         """factor that still has to be applied to the slab (1/world after a deferred-mean finish(), else 1); reading resets it"""

@@ -237,8 +237,15 @@ class TransformerBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, rs1, rs2, n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b,
-                B, N, heads, eps, k1=None, k2=None, tm1=None, tm2=None, inv_keep=1.0):
+                B, N, heads, eps, k1=None, k2=None, tm1=None, tm2=None, inv_keep=None):
         C = x.shape[-1]
+        if rs1 is not None or rs2 is not None:
+            # dW / db of proj and fc2 are formed as inv_keep * dy^T (masked input): the factor cannot be defaulted, and the
+            # masks must be binary (rs = mask / keep) -- a caller on the old signature would get gradients scaled by `keep`
+            if inv_keep is None:
+                raise ValueError("TransformerBlockFn: DropPath factors rs1 / rs2 need inv_keep = 1 / keep_prob")
+        elif inv_keep is None:
+            inv_keep = 1.0
         x2 = x.reshape(B * N, C).contiguous()
         scale = (C // heads) ** -0.5
         if rs1 is not None and k1 is None:

@@ -322,6 +322,7 @@ class PatchEmbed(nn.Module):
         self.compute_dtype = BF16          # torch.float32 runs the MIOpen stem un-autocast (parity debugging)
         self.hip_conv = os.environ.get("AP_STEM_HIP_CONV", "1") == "1"    # 3x3 / 64-channel stem convolutions on csrc/conv.hip (0: MIOpen)
         self.resize_to = None              # elastic input size: a fp32 batch of another size is resized on the way in (main_prog.py:973)
+        self.resize_in_eval = False        # the reference resizes in its TRAINING loop only; evaluation runs at the loader's resolution
 
     def forward(self, x):
         """[B,3,r,r] -> NCHW feature map (channels_last memory, bf16).  64-wide stem: resize + space-to-depth kernel, the
@@ -331,7 +332,9 @@ class PatchEmbed(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("autoprog_amd models run on the GPU only (no CPU fallback)")
         fused = self.compute_dtype == BF16
-        size = self.resize_to if self.resize_to else x.shape[-1]
+        # the stage's resolution applies to training-mode forwards (training steps and the train-mode EMA probes of a search);
+        # an eval() forward keeps the resolution it is given unless resize_in_eval is set
+        size = self.resize_to if (self.resize_to and (self.training or self.resize_in_eval)) else x.shape[-1]
         first = None
         if (fused and self.stem_conv and self.hip_conv and x.dtype == torch.float32 and x.shape[-1] == x.shape[-2] and not x.requires_grad
                 and size % 2 == 0 and tuple(self.conv[0].weight.shape) == (64, 3, 7, 7) and self.conv[0].stride[0] == 2):
@@ -520,7 +523,8 @@ class VOLO(nn.Module):
     def set_sample_config(self, config: dict):
         mask = ActiveLayerMask(config["layer_num"], config["min_layer_num"], config["max_layer_num"])
         # the reference's search configs also carry the step's resolution (main_prog.py:1824-1828); its callers resize the batch
-        # themselves -- a batch that still has another size is resized by the stem's first kernel
+        # themselves -- a TRAINING batch that still has another size is resized by the stem's first kernel (eval() forwards are
+        # left at their own resolution: PatchEmbed.resize_in_eval)
         self.patch_embed.resize_to = config.get("input_size")
         real_stage = 0
         for stage in self.network:

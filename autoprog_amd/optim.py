@@ -147,16 +147,23 @@ class FlatAdamWEma:
                 for d, bufs in zip(self.ema_decays, self.ema_buffers):
                     torch._foreach_lerp_(bufs, self._buffers, 1.0 - d)
 
-    def grow(self, old_mask, new_mask):
+    def grow(self, old_mask, new_mask, model_source="ema_last"):
         """stage transition of a progressive run ON the live slabs (prog/elastic.py; reference: create_stage_model_and_optimizer,
-        main_prog.py:1300-1430 -- load_slice_clone_ema for the model from the LAST EMA copy, load_slice_clone for EMA copy i from
-        EMA copy i, fresh optimizer, BatchNorm statistics back to their defaults).  The caller switches the model to the new stage
-        with set_sample_config afterwards."""
+        main_prog.py:1300-1430).  EMA copy i always comes from EMA copy i, the optimizer restarts, BatchNorm statistics go back to
+        their defaults.  The MODEL weights come from
+          model_source = "ema_last": the LAST EMA copy (load='slice' with load_with_clone_ema, main_prog.py:1378-1382: growth, and
+                                     the same depth under a new DropPath strength, main_prog.py:828-831), or
+          model_source = "model":    the trained model itself (load='super', main_prog.py:1389: the sub-network a search picked
+                                     out of its supernet keeps the weights the search epochs trained).
+        The caller switches the model to the new stage with set_sample_config afterwards."""
         from .prog.elastic import growth_sources
+        if model_source not in ("ema_last", "model"):
+            raise ValueError("grow: model_source must be 'ema_last' or 'model'")
         where = {name: (off, shape) for name, off, shape in self._views}
         src_of = growth_sources(list(where), old_mask, new_mask)
         with torch.no_grad():
             old = [e.clone() for e in self.ema] if self.ema else [self.p.clone()]
+            old_model = self.p.clone() if (model_source == "model" or not self.ema) else old[-1]
             for name, (off, shape) in where.items():
                 sname = src_of.get(name)
                 if sname is None:
@@ -167,7 +174,7 @@ class FlatAdamWEma:
                     n *= d
                 if tuple(sshape) != tuple(shape):
                     raise ValueError("%s <- %s: shapes differ (width growth is a state-dict operation, prog/growth.py)" % (name, sname))
-                self.p[off:off + n].copy_(old[-1][soff:soff + n])
+                self.p[off:off + n].copy_(old_model[soff:soff + n])
                 for e, eo in zip(self.ema, old):
                     e[off:off + n].copy_(eo[soff:soff + n])
             for m in self.model.modules():            # the reference's new network starts with default BatchNorm statistics

@@ -49,12 +49,28 @@ class AutoProgDriver:
         return mask
 
     def _transition(self, l, r, dp):
-        """move the live slabs to depth l (prog/elastic.py), then select (l, r, dp)"""
+        """move the live slabs to depth l (prog/elastic.py), then select (l, r, dp).  As the reference (main_prog.py:828-837): a
+        new network state is made when the depth OR the DropPath strength changes; deeper or equal depth -> load='slice' (model
+        from the last EMA copy), shallower (a search picked a sub-network of its supernet) -> load='super' (model from the
+        trained supernet); the optimizer restarts either way."""
         new_mask = ActiveLayerMask(l, self.l_min, self.l_max)
-        if self.mask is not None and l != self.current_l:
-            self.opt.grow(self.mask, new_mask)
+        if self.mask is not None and (l != self.current_l or dp != self.current_dp):
+            self.opt.grow(self.mask, new_mask, model_source="ema_last" if l >= self.current_l else "model")
         self.mask = self._activate(l, r, dp)
         self.current_l, self.current_r, self.current_dp = l, r, dp
+
+    def _rank_mean(self, values):
+        """mean over the ranks of the reducer's process group of a list of host floats (the reference reduces its probe losses
+        across ranks, main_prog.py:1213,1267 reduce_tensor): every rank ranks the candidates on the SAME numbers, so every rank
+        picks the same (r, l).  One all-reduce of one small tensor."""
+        world = getattr(self.reducer, "world", 1)
+        if world <= 1:
+            return list(values)
+        import torch.distributed as dist
+        dev = self.reducer.flat.device
+        t = torch.tensor(values, dtype=torch.float64, device=dev if dist.get_backend(self.reducer.group) != "gloo" else "cpu")
+        dist.all_reduce(t, group=self.reducer.group)
+        return (t / world).tolist()
 
     def _train_step(self, l, r, dp):
         self._activate(l, r, dp)
@@ -78,7 +94,7 @@ class AutoProgDriver:
                     images, target = self.get_batch(r)
                     tot += float(self.loss_fn(self.model(images), target))
                 out[(r, l)] = tot / self.probe_batches
-        return out
+        return dict(zip(cands, self._rank_mean([out[c] for c in cands])))
 
     def _time(self, cands):
         """mean forward+backward seconds per candidate, measured once at search start (main_prog.py:1886-1902)"""
@@ -96,7 +112,7 @@ class AutoProgDriver:
                 self.reducer.take_pending_scale()
             torch.cuda.synchronize()
             out[(r, l)] = (time.perf_counter() - t0) / self.time_steps
-        return out
+        return dict(zip(cands, self._rank_mean([out[c] for c in cands])))
 
     def search(self, stage, epoch):
         """-> chosen (r, l).  The search supernet is the largest candidate; its sub-networks are trained with one random candidate

@@ -110,3 +110,48 @@ def test_bucketed_allreduce_world_size_2():
     for p in procs:
         p.join(timeout=60)
     assert all(msg == "ok" for _, msg in out), out
+
+
+def _driver_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from autoprog_amd.prog.driver import AutoProgDriver
+        from autoprog_amd.prog import search as S
+
+        class _Reducer:                      # what AutoProgDriver._rank_mean reads of a GradientBucketReducer
+            def __init__(self):
+                self.world, self.group, self.flat = world, None, torch.zeros(4)
+        drv = AutoProgDriver(model=None, loss_fn=None, optimizer=None, reducer=_Reducer(), get_batch=None, r_list=[64, 96], l_list=[3, 6],
+                             dp_list=[0.0, 0.1], grow_epochs=[0, 2], steps_per_epoch=1)
+        cands = [(64, 3), (64, 6), (96, 3), (96, 6)]
+        # rank-local probe losses and step times that would rank the candidates DIFFERENTLY on the two ranks
+        local_loss = [[2.0, 1.0, 1.9, 0.6], [1.0, 2.4, 1.7, 1.2]][rank]
+        local_time = [[1.0, 2.0, 2.0, 4.5], [1.2, 1.8, 2.2, 3.5]][rank]
+        mean_loss = dict(zip(("r%d_l%d" % c for c in cands), drv._rank_mean(local_loss)))
+        step_time = dict(zip(("r%d_l%d" % c for c in cands), drv._rank_mean(local_time)))
+        _, _, order = S.converge_speed(mean_loss, step_time)
+        _, _, local_order = S.converge_speed(dict(zip(mean_loss, local_loss)), dict(zip(step_time, local_time)))
+        q.put((rank, order[0], local_order[0], [round(v, 9) for v in mean_loss.values()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_search_decision_is_identical_on_every_rank():
+    """AutoProgDriver ranks the candidates of a search on probe losses and step times averaged over the ranks (reference:
+    validate_trainset -> reduce_tensor, main_prog.py:1213,1267): with rank-local numbers that disagree, both ranks still pick the
+    same (r, l) -- ranks training different sub-networks would diverge silently (same-sized gradient slab)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_driver_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, pick0, local0, means0), (_, pick1, local1, means1) = res
+    assert means0 == means1 == [1.5, 1.7, 1.8, 0.9]
+    assert pick0 == pick1
+    assert local0 != local1            # the rank-local rankings really disagreed

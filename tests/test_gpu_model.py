@@ -536,6 +536,13 @@ def test_hip_stem_eval_and_elastic_resolution_vs_oracle():
     x = torch.randn(2, 3, 96, 96, device="cuda")
     model.set_sample_config(dict(layer_num=9, min_layer_num=9, max_layer_num=9, input_size=64, token_label_size=4))
     model.patch_embed.hip_conv = True          # (AP_STEM_HIP_CONV=0 runs of the suite flip the default)
+    # the stage resolution belongs to training: an eval() forward keeps its own resolution unless asked (reference: main_prog.py:973
+    # resizes in the training loop only)
+    with torch.no_grad():
+        y96 = model(x)
+    ref96 = R.volo_forward(p, x.double().cpu(), train=False, **arch)
+    assert rel(y96, ref96) < 3e-2, rel(y96, ref96)
+    model.patch_embed.resize_in_eval = True
     with torch.no_grad():
         y = model(x)
     xr = F.interpolate(x.double().cpu(), size=(64, 64), mode="bilinear", align_corners=False)

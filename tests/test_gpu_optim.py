@@ -198,6 +198,61 @@ def test_stage_transition_on_live_slabs():
         red.remove()
 
 
+def test_stage_transition_shrink_takes_the_trained_model():
+    """FlatAdamWEma.grow(model_source="model"): the sub-network a search picks out of its supernet (6 -> 4 layers) keeps the weights
+    the search epochs TRAINED (reference: load='super', main_prog.py:830-837,1389 load_super(model, prev_model)); EMA copy i comes
+    from EMA copy i; the optimizer restarts.  Checked against prog/growth.extract_subnet (the state-dict restatement of load_super).
+    The default source ("ema_last") on the same transition gives the last EMA copy instead -- the two must differ after training."""
+    from autoprog_amd.dist import GradientBucketReducer
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    from autoprog_amd.models import create_model
+    from autoprog_amd.optim import FlatAdamWEma
+    from autoprog_amd.prog import elastic, growth
+    torch.manual_seed(0)
+    model = create_model("model_variant", variant="volo_h2_l6", num_classes=16, img_size=64, stem_hidden_dim=16).cuda().train()
+    red = GradientBucketReducer(list(model.parameters()), world_size=1)
+    red.install_sink(model)
+    opt = FlatAdamWEma(model, red, lr=1e-3, weight_decay=0.05, ema_decays=[0.5, 0.6, 0.7, 0.8])
+    loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=16)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(4, 3, 64, 64, generator=g).cuda()
+    target = torch.softmax(torch.randn(4, 16, 18, generator=g) * 2, dim=1).cuda()
+    try:
+        old_mask = model.set_sample_config(dict(layer_num=6, min_layer_num=3, max_layer_num=6))
+        np.random.seed(0)
+        for _ in range(3):
+            _step(model, red, opt, loss_fn, x, target)
+        model_before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        ema_before = [{k: v.detach().clone() for k, v in opt.ema_state_dict(i).items()} for i in range(4)]
+        new_mask = elastic.make_mask(4, 3, 6)
+        opt.grow(old_mask, new_mask, model_source="model")
+        model.set_sample_config(dict(layer_num=4, min_layer_num=3, max_layer_num=6))
+        shape4 = create_model("model_variant", variant="volo_h2_l4", num_classes=16, img_size=64, stem_hidden_dim=16).state_dict()
+        skip = ("running_mean", "running_var", "num_batches_tracked")
+        want = growth.extract_subnet(shape4, elastic.export_state_dict(model_before, old_mask), base_layer=3)
+        got = elastic.export_state_dict({k: v.detach() for k, v in model.state_dict().items()}, new_mask)
+        assert set(got) == set(want)
+        differs_from_ema = False
+        want_ema3 = growth.extract_subnet(shape4, elastic.export_state_dict(ema_before[3], old_mask), base_layer=3)
+        for k, v in want.items():
+            if k.rsplit(".", 1)[-1] in skip:
+                continue
+            assert torch.equal(got[k].cpu(), v.cpu()), k
+            differs_from_ema |= not torch.equal(v.cpu(), want_ema3[k].cpu())
+        assert differs_from_ema                      # i.e. the test can tell the two sources apart
+        for i in (0, 2):
+            want_e = growth.extract_subnet(shape4, elastic.export_state_dict(ema_before[i], old_mask), base_layer=3)
+            got_e = elastic.export_state_dict(opt.ema_state_dict(i), new_mask)
+            for k, v in want_e.items():
+                if k.rsplit(".", 1)[-1] not in skip:
+                    assert torch.equal(got_e[k].cpu(), v.cpu()), (i, k)
+        assert float(opt.m.abs().sum()) == 0.0 and float(opt.v.abs().sum()) == 0.0 and opt.step_count == 0
+        losses = [_step(model, red, opt, loss_fn, x, target) for _ in range(3)]
+        assert all(np.isfinite(losses))
+    finally:
+        red.remove()
+
+
 def test_autoprog_driver_two_stage_search():
     """prog/driver.py: a miniature AutoProg run -- stage 0 opens with a search over r in {64, 96} x
     l in {3, 6} on one volo_h2_l6 supernet (random sub-network per step, EMA probes, loss * time^w ranking), the run continues at
