@@ -1247,20 +1247,18 @@ static int g8_launch(int bn, const bf16_t* A, int lda, const bf16_t* B, int ldb,
     return ap_check_launch();
 }
 
-// Where the persistent 8-phase kernel is picked.  It is the faster kernel on long reductions (1.50 PFLOP/s at 8192^3 against
-// 0.85 for k_gemm_nt) and it pays a serial tile epilogue plus a whole-CU launch boundary (128 KB of LDS: no overlap with the
-// neighbouring kernels' tails), so inside the training step it wins from K >= 768 on; AP_GEMM_8P = 0 never, 1 (default) plain /
-// bias / row-scale epilogues, 2 also the epilogues that read a second tile (faster stand-alone, slower in the D1 step).
+// Where the persistent 8-phase kernel is picked (measured INSIDE the training step, tools/instep_8p.sh; profiles/r03_gemm_instep_*):
+// every launch with K % 64 == 0, M >= 4096 and N a multiple of 192 (256 x 192 tiles) or N >= 1024 (256 x 256 tiles, last column tile
+// masked) -- 384 x 1152 plain 38.3 -> 30.7 us, + residual 45.3 -> 41.0, fc1 + GELU 61.5 -> 56.0, qkv 39.0 -> 35.0, the K = 192
+// outlooker shapes 5 - 15 % -- except the gelu' epilogue, whose staged second operand still costs more than it saves (60.6 -> 62.3).
+// AP_GEMM_8P = 0: never; 1 (default): as above; 2: the gelu' launches too.
 static int use_8p(int M, int N, int K, int ldc, const EpiArgs& ep) {          // -> 0 (no), 192 or 256 (block tile width)
     static int mode = -1;
     if (mode < 0) { const char* e = getenv("AP_GEMM_8P"); mode = e ? atoi(e) : 1; }
     if (mode == 0 || (K & 63) || K < 128 || M < 4096 || (N & 7) || (ldc & 7) || (ep.residual && (ep.ldr & 7))) return 0;
+    if (ep.dgelu_of && (mode < 2 || ep.residual)) return 0;
     const int bn = N >= 1024 ? 256 : (N % 192 == 0 ? 192 : (N % 256 == 0 ? 256 : 0));
-    if (bn == 0 || N < 192) return 0;
-    if (mode >= 3) return bn;
-    if (K < 768 || N < 384) return 0;
-    if (ep.gelu || ep.dgelu_of || ep.residual) return mode >= 2 ? bn : 0;
-    return bn;
+    return N < 192 ? 0 : bn;
 }
 
 extern "C" {

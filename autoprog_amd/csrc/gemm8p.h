@@ -223,6 +223,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
 
     f32x4 acc0[2][4][2], acc1[2][4][NT1];        // [mh][mt][nt] of part 0 / part 1
     u32x4 af[4][2], bf0[2][2], bf1[NT1][2];
+    u32x4 af1[NT1 == 1 ? 4 : 1][2];              // BN = 192: the second A half has its own registers (three phases per K-tile)
     auto zero_acc = [&]() {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -234,14 +235,15 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                 for (int d = 0; d < NT1; ++d) acc1[a][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
     };
-    auto readA = [&](const unsigned char* base, int h) {
+    auto readA_to = [&](u32x4 (&a)[4][2], const unsigned char* base, int h) {
         if (!(G8_ABL & 2)) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) af[mt][kb] = ld16(base + h * 16384 + mt * 2048 + (kb ? lane_off1 : lane_off0));
+                for (int kb = 0; kb < 2; ++kb) a[mt][kb] = ld16(base + h * 16384 + mt * 2048 + (kb ? lane_off1 : lane_off0));
         }
     };
+    auto readA = [&](const unsigned char* base, int h) { readA_to(af, base, h); };
     auto readB0 = [&](const unsigned char* base) {
         if (!(G8_ABL & 2)) {
 #pragma unroll
@@ -258,32 +260,30 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                 for (int kb = 0; kb < 2; ++kb) bf1[nt][kb] = ld16(base + nt * 2048 + (kb ? lane_off1 : lane_off0));
         }
     };
-    auto mma0 = [&](int mh) {
+    auto mma0_of = [&](int mh, const u32x4 (&a)[4][2]) {
         if (!(G8_ABL & 1)) {
-            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        acc0[mh][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(bf0[nt][kb]), as_bf16x8(af[mt][kb]), acc0[mh][mt][nt], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+                        acc0[mh][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(bf0[nt][kb]), as_bf16x8(a[mt][kb]), acc0[mh][mt][nt], 0, 0, 0);
         }
     };
-    auto mma1 = [&](int mh) {
+    auto mma1_of = [&](int mh, const u32x4 (&a)[4][2]) {
         if (!(G8_ABL & 1)) {
-            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT1; ++nt)
-                        acc1[mh][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(bf1[nt][kb]), as_bf16x8(af[mt][kb]), acc1[mh][mt][nt], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+                        acc1[mh][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(bf1[nt][kb]), as_bf16x8(a[mt][kb]), acc1[mh][mt][nt], 0, 0, 0);
         }
     };
+    auto mma0 = [&](int mh) { __builtin_amdgcn_s_setprio(1); mma0_of(mh, af); __builtin_amdgcn_s_setprio(0); };
+    auto mma1 = [&](int mh) { __builtin_amdgcn_s_setprio(1); mma1_of(mh, af); __builtin_amdgcn_s_setprio(0); };
 #define G8_BAR() __builtin_amdgcn_s_barrier()
 #define G8_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 #define G8_VM(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
@@ -292,7 +292,34 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     // One K-tile T = four phases on the buffer at byte offset bo.  A part is restaged (with K-tile T+2) two phases after the phase
     // that read it -- one phase after for B part 0, whose reads are retired by the lgkmcnt(8) in front of phase 1's first barrier --
     // and read one phase after the counted wait that retires it (phase 4's, for the whole other buffer).
+    // BN = 192 (16 / 8 / 8 / 16 MFMAs in four phases, and a half-step costs ~400 cycles whatever it holds): THREE phases of 16 MFMAs
+    // -- (0, part 0) | (0, part 1) + (1, part 1) | (1, part 0) -- with the second A half in registers of its own.  Parts of K-tile
+    // T+1 still missing go out in phase 1 (A h1, B part 1: their last reads were phase 2 of T-1), of T+2 in phases 2 (B part 0) and
+    // 3 (A h0); the counted wait of phase 3 leaves those two (4 pieces) in flight.
+    auto ktile3 = [&](int bo) {
+        if constexpr (NT1 == 1) {
+            readB0(rdB0 + bo); G8_FENCE(); readA(rdA + bo, 0); G8_FENCE();
+            if (q_tile < t_end) { dma(qa1, KS - bo, 1); dma1(KS - bo); }
+            q_advance();
+            G8_LGKM(8); G8_FENCE();
+            G8_BAR(); G8_LGKM(0); G8_FENCE();
+            mma0(0); G8_FENCE();
+            G8_BAR();
+            const bool live = q_tile < t_end;
+            readB1(rdB1 + bo); G8_FENCE(); readA_to(af1, rdA + bo, 1); G8_FENCE();
+            if (live) dma(qb0, bo, 2);
+            G8_BAR(); G8_LGKM(0); G8_FENCE();
+            __builtin_amdgcn_s_setprio(1); mma1_of(0, af); mma1_of(1, af1); __builtin_amdgcn_s_setprio(0); G8_FENCE();
+            G8_BAR();
+            if (live) { dma(qa0, bo, 0); G8_VM(4); } else { G8_VM(0); }
+            G8_FENCE();
+            G8_BAR();
+            __builtin_amdgcn_s_setprio(1); mma0_of(1, af1); __builtin_amdgcn_s_setprio(0); G8_FENCE();
+            G8_BAR();
+        }
+    };
     auto ktile = [&](int bo) {
+        if constexpr (NT1 == 1) { ktile3(bo); return; }
         // phase 1: quadrant (0, part 0); completes K-tile T+1 (A h1 into the other buffer)
         readB0(rdB0 + bo); G8_FENCE(); readA(rdA + bo, 0); G8_FENCE();
         if (q_tile < t_end) dma(qa1, KS - bo, 1);
@@ -326,7 +353,11 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     {
         dma(qb0, 0, 2); dma(qa0, 0, 0); dma1(0); dma(qa1, 0, 1);
         q_advance();
-        if (q_tile < t_end) { dma(qb0, KS, 2); dma(qa0, KS, 0); dma1(KS); G8_VM(VMN); } else { G8_VM(0); }
+        if constexpr (NT1 == 1) {
+            if (q_tile < t_end) { dma(qb0, KS, 2); dma(qa0, KS, 0); G8_VM(4); } else { G8_VM(0); }
+        } else {
+            if (q_tile < t_end) { dma(qb0, KS, 2); dma(qa0, KS, 0); dma1(KS); G8_VM(VMN); } else { G8_VM(0); }
+        }
         G8_FENCE();
         G8_BAR();
     }
