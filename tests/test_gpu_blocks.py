@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from tests._golden import load, sub
+from oracle import ref_cpu as R
 
 pytestmark = pytest.mark.gpu
 TOL = 2.5e-2
@@ -92,3 +93,101 @@ def test_patch_embed_stem_vs_reference_golden():
     with torch.no_grad():
         ye = pe(x)
     assert rel(ye, d["eval.y"]) < 3e-2, rel(ye, d["eval.y"])
+
+
+def _stem64_module(d, hip):
+    from autoprog_amd.models import volo as V
+    pe = V.PatchEmbed(stem_conv=True, stem_stride=2, patch_size=8, in_chans=3, hidden_dim=64, embed_dim=32)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sub(d, "train.w").items()}
+    for k in sd:                                   # the fixture stores the statistics AFTER the train step: start from the defaults
+        if k.endswith("running_mean"):
+            sd[k] = torch.zeros_like(sd[k])
+        elif k.endswith("running_var"):
+            sd[k] = torch.ones_like(sd[k])
+        elif k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros_like(sd[k])
+    pe.load_state_dict(sd, strict=True)
+    pe = pe.cuda().train()
+    pe.hip_conv = hip
+    return pe
+
+
+def test_hip_stem64_vs_reference_golden(monkeypatch):
+    """The 64-wide stem ON THE HIP CONVOLUTIONS (csrc/conv7.hip, csrc/conv.hip, the patch-addressed GEMM; models/volo.py:342-380)
+    against reference-generated vectors (tests/golden/stem64.npz, tools/gen_golden.py::gen_stem64): train-mode output, updated
+    running statistics, every parameter gradient, eval-mode output -- and against the CPU oracle on a second input.  Any call of
+    torch's convolution (MIOpen) fails the HIP part of the test: the narrow `stem.npz` fixture above exercises that path, not the
+    kernels.
+
+    Bounds.  Outputs and statistics: 1.5e-2 (measured 6.6e-3).  Parameter gradients behind the three training-mode BatchNorms of
+    this fixture (2 x 16 x 16 samples per channel) lose up to 13 % to bf16 ACTIVATIONS whatever computes the convolutions: the same
+    module on MIOpen's bf16 convolutions measures 0.016 - 0.123 per tensor, on fp32 convolutions 0.0000 (tools/dbg_stem64.py).  The
+    test therefore measures that independent bf16 implementation first and holds the HIP kernels to 1.3x ITS error per tensor
+    (floor 1e-2): a wrong kernel is caught, the precision recipe is not re-litigated."""
+    import torch.nn.functional as F
+    d = load("stem64")
+    x = torch.from_numpy(d["train.x"]).cuda()
+    dy = torch.from_numpy(d["train.dy"]).cuda()
+    pm = _stem64_module(d, hip=False)              # bf16 activations, MIOpen convolutions: the yardstick
+    ym = pm(x)
+    ym.backward(dy.to(ym.dtype))
+    base = {n: rel(p.grad, d["train.g." + n]) for n, p in pm.named_parameters()}
+    base_y = rel(ym, d["train.y"])
+
+    pe = _stem64_module(d, hip=True)
+
+    torch_conv2d = F.conv2d
+
+    def no_miopen(inp, *a, **k):                   # (the CPU oracle below convolves with the same function)
+        if inp.is_cuda:
+            raise AssertionError("torch conv2d called on the GPU: the 64-wide stem must run on the HIP convolution kernels")
+        return torch_conv2d(inp, *a, **k)
+    monkeypatch.setattr(F, "conv2d", no_miopen)
+    y = pe(x)
+    e_y = rel(y, d["train.y"])
+    y.backward(dy.to(y.dtype))
+    for i in (1, 4, 7):
+        bn = pe.conv[i]
+        assert rel(bn.running_mean, d["train.w.conv.%d.running_mean" % i]) < 1.5e-2, i
+        assert rel(bn.running_var, d["train.w.conv.%d.running_var" % i]) < 1.5e-2, i
+        assert int(bn.num_batches_tracked) == 1
+    errs = {n: rel(p.grad, d["train.g." + n]) for n, p in pe.named_parameters()}
+    print("stem64 train output error hip %.4f (miopen bf16 %.4f); gradient errors hip / miopen bf16:" % (e_y, base_y),
+          {k: (round(v, 4), round(base[k], 4)) for k, v in sorted(errs.items(), key=lambda kv: -kv[1])})
+    assert e_y < 1.5e-2 and e_y < 1.3 * base_y + 1e-3, (e_y, base_y)
+    bad = {k: (v, base[k]) for k, v in errs.items() if v > max(1e-2, 1.3 * base[k])}
+    assert not bad, bad
+    sd_eval = {k: torch.from_numpy(np.asarray(v)) for k, v in sub(d, "train.w").items()}      # the reference's post-step statistics
+    pe.load_state_dict(sd_eval, strict=True)
+    pe.eval()
+    with torch.no_grad():
+        ye = pe(x)
+    assert rel(ye, d["eval.y"]) < 1.5e-2, rel(ye, d["eval.y"])
+    # the CPU oracle on another input: odd batch and a feature map that does not divide the convolution tiles; forward output and the
+    # input-side quantities that do not pass through a BatchNorm backward (proj) at 1.5e-2, the rest against the oracle at the
+    # yardstick's level measured above
+    pe.train()
+    g = torch.Generator().manual_seed(5)
+    x2 = torch.randn(3, 3, 48, 48, generator=g)
+    p64 = {k: v.detach().double().cpu() for k, v in pe.state_dict().items()}
+    for k in p64:
+        if k.endswith("running_mean"):
+            p64[k] = torch.zeros_like(p64[k])
+        elif k.endswith("running_var"):
+            p64[k] = torch.ones_like(p64[k])
+        elif p64[k].dtype.is_floating_point:
+            p64[k].requires_grad_(True)
+    with torch.no_grad():
+        for i in (1, 4, 7):
+            pe.conv[i].reset_running_stats()
+    pe.zero_grad()
+    y2 = pe(x2.cuda())
+    ref = R.patch_embed(x2.double(), p64, train=True, patch_size=8, pre="")
+    dy2 = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy2)
+    y2.backward(dy2.permute(0, 3, 1, 2).cuda().to(y2.dtype))
+    assert rel(y2, ref.detach().permute(0, 3, 1, 2)) < 1.5e-2
+    errs2 = {n: rel(p.grad, p64[n].grad) for n, p in pe.named_parameters()}
+    print("stem64 vs oracle (3 x 48 x 48) gradient errors:", {k: round(v, 4) for k, v in sorted(errs2.items(), key=lambda kv: -kv[1])})
+    bad = {k: v for k, v in errs2.items() if v > (1.5e-2 if k.startswith("proj") else 1.3 * max(base.values()))}
+    assert not bad, bad

@@ -63,9 +63,11 @@ def test_volo_train_eval_vs_reference_golden(tag, variant, classes):
         if float(g.norm()) > 1e-6:
             worst[name] = float(diff.norm() / g.norm())
     print("volo_full %s: global gradient rel-L2 %.4f; worst tensors %s" % (tag, (num / den) ** 0.5, sorted(((round(v, 3), k) for k, v in worst.items()), reverse=True)[:6]))
-    # measured: global 0.058 (h2_l3) / 0.018 (h2_l6), worst tensors 0.19 / 0.085 (first block's norm1 and the 16-wide MIOpen stem)
-    assert (num / den) ** 0.5 < 0.08, (num / den) ** 0.5
-    bad = {k: v for k, v in worst.items() if v > 0.25}
+    # measured: global 0.058 (h2_l3) / 0.018 (h2_l6), worst tensors 0.187 / 0.085 (first block's norm1 and the 16-wide MIOpen stem);
+    # the bounds are 1.5x the measurement of each fixture
+    g_bound, t_bound = {"h2_l3": (0.087, 0.28), "h2_l6": (0.027, 0.13)}.get(tag, (0.087, 0.28))
+    assert (num / den) ** 0.5 < g_bound, (num / den) ** 0.5
+    bad = {k: v for k, v in worst.items() if v > t_bound}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
     load_sd(model, d, tag)                  # the train forward above updated the BN running stats once more
     model.eval()
@@ -110,7 +112,7 @@ def test_loss_curve_vs_reference_golden():
         losses.append(float(loss.detach()))
     diff = np.abs(np.array(losses) - d["losses"]) / d["losses"]
     print("loss curve hip:", losses, "ref:", d["losses"].tolist(), "reldiff:", diff.tolist())
-    assert diff.max() < 1e-2, (losses, d["losses"].tolist())
+    assert diff.max() < 4e-3, (losses, d["losses"].tolist())          # measured 1.0e-3 - 2.2e-3 relative (round 2 and 3 runs)
 
 
 def test_d1_shapes_droppath_and_oracle_agreement():
@@ -196,7 +198,7 @@ def test_volo_d5_shapes_448_vs_oracle():
     assert abs(float(loss.detach()) - float(ref_loss.detach())) < 3e-3 * float(ref_loss.detach())
     errs = {n: rel(q.grad, p[n].grad) for n, q in model.named_parameters() if float(p[n].grad.norm()) > 1e-9}
     print("D5-shape grad errors: max %.4f (%s)" % (max(errs.values()), max(errs, key=errs.get)))
-    bad = {k: v for k, v in errs.items() if v > (0.15 if k.startswith("patch_embed.") else 6e-2)}
+    bad = {k: v for k, v in errs.items() if v > (0.14 if k.startswith("patch_embed.") else 6e-2)}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
 
 
@@ -445,7 +447,7 @@ def test_loss_curve_with_fused_optimizer_and_sink():
     finally:
         red.remove()
     diff = np.abs(np.array(losses) - d["losses"]) / d["losses"]
-    assert diff.max() < 1e-2, (losses, d["losses"].tolist())
+    assert diff.max() < 4e-3, (losses, d["losses"].tolist())          # measured 1.0e-3 - 2.2e-3 relative (round 2 and 3 runs)
     ema = opt.ema_state_dict(0)
     w = dict(model.named_parameters())["head.weight"]
     assert not torch.equal(ema["head.weight"], w.detach()) and torch.isfinite(ema["head.weight"]).all()
@@ -513,7 +515,9 @@ def test_loss_curve_realistic_init_vs_reference():
     bad = {k: v for k, v in errs.items() if v > (0.1 if k.startswith("patch_embed.conv") else 2.5e-2)}
     assert not bad, bad
     assert max(norms.values()) < 6e-2, max(norms.values())
-    assert dev[0] < 1e-3 and dev[:4].max() < 2.5e-3, dev.tolist()
+    # measured (round 3): 2.3e-4 at step 0, <= 2.6e-4 over steps 0-3, 4.5e-3 worst (step 8); round 2 on another kernel arrangement
+    # 2.5e-4 / 1.6e-3 / 1.9e-2: the tail is the chaos described above, the head is held at north_star's 1e-3
+    assert dev[0] < 1e-3 and dev[:4].max() < 2e-3, dev.tolist()
     assert dev.max() < 2.5e-2, (losses, d["losses"].tolist())
     assert dev.max() < 0.1 * np.abs(d["losses_bf16_autocast"] - d["losses"]).max()
 

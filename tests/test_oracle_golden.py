@@ -133,6 +133,22 @@ def test_stem_train_and_eval():
     assert rel_err(ye.permute(0, 3, 1, 2), d["eval.y"]) < TOL
 
 
+def test_stem64_train_and_eval():
+    """the BASELINE-width stem (64 channels: the shapes the HIP convolution kernels are written for) against the reference
+    vectors of tests/golden/stem64.npz -- the oracle side of tests/test_gpu_blocks.py::test_hip_stem64_vs_reference_golden"""
+    d = load("stem64")
+    p = _params(d, "train")
+    x = torch.from_numpy(d["train.x"]).double().requires_grad_(True)
+    y = R.patch_embed(x, p, train=True, patch_size=8, pre="")
+    assert rel_err(y.permute(0, 3, 1, 2), d["train.y"]) < TOL
+    y.backward(torch.from_numpy(d["train.dy"]).double().permute(0, 2, 3, 1))
+    assert rel_err(x.grad, d["train.dx"]) < 5e-5
+    for k, gv in sub(d, "train.g").items():
+        assert rel_err(p[k].grad, gv) < 5e-5, k
+    ye = R.patch_embed(x.detach(), {k: v.detach() for k, v in p.items()}, train=False, patch_size=8, pre="")
+    assert rel_err(ye.permute(0, 3, 1, 2), d["eval.y"]) < TOL
+
+
 def test_pos_interp():
     d = load("pos_interp")
     pos = torch.from_numpy(d["pos"])

@@ -197,6 +197,30 @@ def gen_stem(ns):
     save("stem", **out)
 
 
+def gen_stem64(ns):
+    """the BASELINE-width stem (hidden_dim 64: the shapes csrc/conv7.hip and csrc/conv.hip are written for), B = 2, 32 x 32 input:
+    train-mode output, input gradient, every parameter gradient, updated running statistics, eval-mode output"""
+    out = {}
+    gen = torch.Generator().manual_seed(12)
+    pe = ns.volo.PatchEmbed(stem_conv=True, stem_stride=2, patch_size=8, in_chans=3, hidden_dim=64, embed_dim=32)
+    randomize_(pe, gen, 1.0).train()
+    with torch.no_grad():                   # keep the three 64-channel activations O(1): a 576-term convolution of N(0,1) weights is not
+        for i in (0, 3, 6):
+            pe.conv[i].weight.mul_(1.0 / (pe.conv[i].weight[0].numel() ** 0.5))
+        pe.proj.weight.mul_(1.0 / (pe.proj.weight[0].numel() ** 0.5))
+    x = torch.randn(2, 3, 32, 32, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    y = pe(xr)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    out.update({"train.x": npy(x), "train.y": npy(y), "train.dy": npy(dy), "train.dx": npy(xr.grad)})
+    out.update({"train." + k: v for k, v in sd_arrays(pe).items()})     # includes UPDATED running stats
+    out.update({"train." + k: v for k, v in grads(pe).items()})
+    pe.eval()
+    out["eval.y"] = npy(pe(x))
+    save("stem64", **out)
+
+
 def gen_pos_interp(ns):
     out = {}
     gen = torch.Generator().manual_seed(3)
@@ -419,7 +443,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
     ns = ref_import.load_reference()
-    for fn in (gen_int_tables, gen_outlook, gen_blocks, gen_stem, gen_pos_interp, gen_volo_full, gen_loss, gen_step_curve,
+    for fn in (gen_int_tables, gen_outlook, gen_blocks, gen_stem, gen_stem64, gen_pos_interp, gen_volo_full, gen_loss, gen_step_curve,
                gen_step_curve_init):
         if not only or fn.__name__[4:] in only:
             fn(ns)
