@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be loaded BEFORE the extension: both must shar
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libautoprog_hip.so")
+LIB_PATH = os.environ.get("AP_LIB_PATH") or os.path.join(_HERE, "libautoprog_hip.so")      # AP_LIB_PATH: ablation builds (tools/abl_tn.sh)
 
 
 class GemmEpilogue(Structure):

@@ -24,6 +24,7 @@
 #include <type_traits>
 #include "gemm_epi.h"
 #include "gemm8p.h"
+#include "gemm_tn8p.h"
 #ifndef AP_EXPERIMENTS
 #define AP_EXPERIMENTS 0       // 1: also build the measured-and-rejected kernels (LDS-DMA rings, persistent tiles) and their AP_GEMM_* switches
 #endif
@@ -1016,7 +1017,7 @@ k_gemm_tn_grouped(TnGroup grp) {
 // nothing but latency) disappears into a launch that has idle workgroup slots anyway.
 struct TnLnItem { const float* partial; float* dgamma; float* dbeta; int nblocks; int C; };
 struct TnLn { TnLnItem it[AP_LN_MAX_BATCH]; int count; int first; };            // first: blockIdx.x of the first reduction workgroup
-__device__ __forceinline__ void tn_ln_role(const TnLn& ln, int blk, float* red) {          // red: >= 8 * 33 floats of LDS
+__device__ __forceinline__ void tn_ln_role(const TnLn& ln, int blk, float* red) {          // red: >= (blockDim.x / 32) * 33 floats of LDS
     int y = 0, b0 = 0;
     for (int i = 0; i + 1 < ln.count; ++i) {                                     // which reduction this workgroup belongs to
         const int nb = (2 * ln.it[i].C + 31) / 32;
@@ -1024,27 +1025,26 @@ __device__ __forceinline__ void tn_ln_role(const TnLn& ln, int blk, float* red) 
     }
     const float* __restrict__ partial = ln.it[y].partial;
     const int nblocks = ln.it[y].nblocks, C = ln.it[y].C, C2 = 2 * C;
-    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;                      // 32 columns x 8 row groups
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5, RG = (int)blockDim.x >> 5;      // 32 columns x RG row groups
     const int c = (blk - b0) * 32 + cx;
     if ((blk - b0) * 32 >= C2) return;
     float s = 0.f;
     if (c < C2) {
         int b = ry;
-        for (; b + 15 * 8 < nblocks; b += 16 * 8) {                              // 16 loads in flight per thread
+        for (; b + 15 * RG < nblocks; b += 16 * RG) {                            // 16 loads in flight per thread
             float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = partial[(int64_t)(b + u * 8) * C2 + c];
+            for (int u = 0; u < 16; ++u) v[u] = partial[(int64_t)(b + u * RG) * C2 + c];
 #pragma unroll
             for (int u = 0; u < 16; ++u) s += v[u];
         }
-        for (; b < nblocks; b += 8) s += partial[(int64_t)b * C2 + c];
+        for (; b < nblocks; b += RG) s += partial[(int64_t)b * C2 + c];
     }
     red[ry * 33 + cx] = s;
     __syncthreads();
     if (ry == 0 && c < C2) {
         float t = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) t += red[r * 33 + cx];
+        for (int r = 0; r < RG; ++r) t += red[r * 33 + cx];
         if (c < C) ln.it[y].dgamma[c] += t; else ln.it[y].dbeta[c - C] += t;
     }
 }
@@ -1060,6 +1060,18 @@ k_gemm_tn_grouped_map(TnGroup grp, TnMap map, TnLn ln) {
     const TnArgs& a = grp.p[e >> 12];
     tn_tile(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N1, a.N2, a.steps_per_split, a.colsum, a.t1, a.t2, 0,
             (int)(e & 0xFFFu), sA, sB, a.cs_weight, a.cs_scale, a.slab, a.splits, a.alpha);
+}
+
+// the 192 x 192-tile, LDS-DMA weight-gradient kernel (gemm_tn8p.h) with the same placement table and LayerNorm riders
+struct T8Group { T8Item p[TN_MAX_GROUP]; int tiles[TN_MAX_GROUP]; };
+__global__ void __launch_bounds__(512, 2)
+k_gemm_tn_8p(T8Group grp, TnMap map, TnLn ln) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char t8_smem[];
+    if ((int)blockIdx.x >= ln.first) { tn_ln_role(ln, (int)blockIdx.x - ln.first, reinterpret_cast<float*>(t8_smem)); return; }
+    const unsigned e = map.e[blockIdx.x];
+    if (e == TN_MAP_IDLE) return;
+    const int pi = e >> 12, idx = e & 0xFFFu, tiles = grp.tiles[pi];
+    t8_item(grp.p[pi], idx % tiles, idx / tiles, t8_smem);
 }
 
 // one weight gradient whose B rows are patches of an NHWC feature map (PatchMap): a k x k / stride k convolution's dW
@@ -1655,6 +1667,48 @@ static bool tn_place(const TnGroup& grp, int cap, TnMap& map, int& blocks) {
     return true;
 }
 
+// Plan of the 192 x 192-tile kernel: every width a multiple of 192, whole 64-token K-tiles, plain row-major operands.  The token
+// axis is cut into ranges of `ksps` K-tiles, the smallest that leaves at most one work item per CU and fits the per-XCD placement.
+static bool tn8_plan(const ap_tn_problem* problems, int count, int n_cu, T8Group& g8, TnMap& map, int& mblocks) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("AP_GEMM_TN_8P"); enabled = e ? atoi(e) : 1; }
+    if (!enabled || count <= 0 || count > TN_MAX_GROUP) return false;
+    int64_t work = 0; int max_k = 1;
+    for (int i = 0; i < count; ++i) {
+        const ap_tn_problem& q = problems[i];
+        if (q.b_patch || q.N1 % 192 || q.N2 % 192 || q.M % 64 || q.M < 4096 || (q.lda & 7) || (q.ldb & 7)) return false;
+        if (q.colsum_weight && (reinterpret_cast<uintptr_t>(q.colsum_weight) & 3)) return false;
+        work += (int64_t)(q.N1 / 192) * (q.N2 / 192) * (q.M / 64);
+        if (q.M / 64 > max_k) max_k = q.M / 64;
+    }
+    int ksps = (int)((work + n_cu - 1) / n_cu);
+    if (ksps < 8) ksps = 8;
+    TnGroup tg;
+    for (; ksps <= max_k; ++ksps) {
+        int64_t items = 0;
+        for (int i = 0; i < count; ++i) {
+            const ap_tn_problem& q = problems[i];
+            const int tiles = (q.N1 / 192) * (q.N2 / 192), ksteps = q.M / 64, splits = (ksteps + ksps - 1) / ksps;
+            tg.p[i].t1 = q.N1 / 192; tg.p[i].t2 = q.N2 / 192; tg.p[i].splits = splits;
+            items += (int64_t)tiles * splits;
+        }
+        tg.count = count;
+        if (items <= n_cu && tn_place(tg, n_cu / 8, map, mblocks)) break;
+    }
+    if (ksps > max_k) return false;
+    for (int i = 0; i < count; ++i) {
+        const ap_tn_problem& q = problems[i];
+        T8Item& t = g8.p[i];
+        t.A = reinterpret_cast<const bf16_t*>(q.A); t.B = reinterpret_cast<const bf16_t*>(q.B); t.C = q.C; t.colsum = q.colsum_A;
+        t.cs_weight = reinterpret_cast<const bf16_t*>(q.colsum_weight);
+        t.lda = q.lda; t.ldb = q.ldb; t.ldc = q.ldc; t.M = q.M; t.t2 = q.N2 / 192; t.ksteps = q.M / 64; t.ksps = ksps;
+        t.alpha = q.alpha != 0.0f ? q.alpha : 1.0f; t.cs_scale = q.colsum_weight ? q.colsum_scale : 1.0f;
+        g8.tiles[i] = (q.N1 / 192) * (q.N2 / 192);
+    }
+    for (int i = count; i < TN_MAX_GROUP; ++i) { g8.p[i] = g8.p[0]; g8.tiles[i] = 1; }
+    return true;
+}
+
 size_t ap_gemm_tn_grouped_workspace(const ap_tn_problem* problems, int count) {
     TnGroup grp; int blocks = 0; size_t fl = 0;
     if (tn_plan(problems, count, grp, blocks, fl) != AP_OK) return 0;
@@ -1676,6 +1730,30 @@ int ap_gemm_tn_acc_grouped_ln(const ap_tn_problem* problems, int count, const ap
     TnGroup grp; int blocks = 0; size_t fl = 0;
     const int rc = tn_plan(problems, count, grp, blocks, fl);
     if (rc != AP_OK) return rc;
+    if (!workspace) {                                 // the 192 x 192-tile LDS-DMA kernel where the whole group fits it
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr;
+            n_cu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+            (void)hipFuncSetAttribute((const void*)k_gemm_tn_8p, hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES);
+            (void)hipGetLastError();
+        }
+        T8Group g8; TnMap map8; int mb8 = 0;
+        if (tn8_plan(problems, count, n_cu, g8, map8, mb8)) {
+            TnLn ln;
+            int lblocks = 0;
+            for (int i = 0; i < AP_LN_MAX_BATCH; ++i) {
+                if (i < ln_count) {
+                    const ap_ln_reduce& q = ln_items[i];
+                    ln.it[i] = TnLnItem{q.partial, q.dgamma, q.dbeta, q.n_partial, q.C}; lblocks += (2 * q.C + 31) / 32;
+                } else ln.it[i] = TnLnItem{nullptr, nullptr, nullptr, 0, 0};
+            }
+            ln.count = ln_count; ln.first = mb8;
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(k_gemm_tn_8p, dim3(mb8 + lblocks), dim3(512), T8_LDS_BYTES, (hipStream_t)stream, g8, map8, ln);
+            return ap_check_launch();
+        }
+    }
     if (workspace) {                                  // deterministic: stored partial tiles + ordered reduce instead of fp32 atomics
         if (ws_bytes < fl * sizeof(float)) return AP_ERR_SHAPE;
         float* w = reinterpret_cast<float*>(workspace);

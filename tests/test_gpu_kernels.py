@@ -192,6 +192,35 @@ def test_gemm_tn_grouped_deterministic_and_weighted_colsum(ops):
     assert rel(outs[2][0], outs[0][0]) < 1e-5
 
 
+def test_gemm_tn_8p_tile_kernel(ops):
+    """the 192 x 192-tile LDS-DMA weight-gradient kernel (csrc/gemm_tn8p.h: widths that are multiples of 192, whole 64-token K-tiles,
+    M >= 4096) against fp64: a block-shaped group with different token counts, accumulation into non-zero C, the product factor,
+    plain and mask-weighted column sums, operands with padded leading dimensions; and against the 128 x 128-tile kernel on the
+    same problems (AP_GEMM_TN_8P=0 is re-run by the environment-switch test)"""
+    specs = [(6272, 384, 1152, "w", 0.8), (6272, 1152, 384, "1", 1.0), (4096, 384, 384, "w", 1.0), (8192, 192, 576, None, 1.0),
+             (4160, 576, 192, "1", 0.5)]
+    probs, refs = [], []
+    for i, (M, N1, N2, cs_kind, alpha) in enumerate(specs):
+        la, lb = N1 + (8 if i % 2 else 0), N2 + (16 if i == 3 else 0)
+        a, b = rnd(M, la, seed=20 + i), rnd(M, lb, seed=50 + i)
+        c0 = torch.randn(N1, N2, generator=torch.Generator().manual_seed(80 + i))
+        cs0 = torch.randn(N1, generator=torch.Generator().manual_seed(95 + i))
+        w = (torch.rand(M, generator=torch.Generator().manual_seed(3 + i)) < 0.8).to(torch.bfloat16)
+        c, cs = dev(c0), (dev(cs0) if cs_kind else None)
+        if cs_kind == "w":
+            probs.append((dev(a), dev(b), c, N1, N2, cs, dev(w), 1.25, alpha))
+            rcs = cs0.double() + 1.25 * (w.double()[:, None] * a[:, :N1].double()).sum(0)
+        else:
+            probs.append((dev(a), dev(b), c, N1, N2, cs, None, 1.0, alpha))
+            rcs = cs0.double() + a[:, :N1].double().sum(0)
+        refs.append((c0.double() + alpha * (a[:, :N1].double().t() @ b[:, :N2].double()), rcs))
+    ops.gemm_tn_acc_grouped(probs)
+    for (q, (rc, rcs)) in zip(probs, refs):
+        assert rel(q[2], rc) < TOL_F32, rel(q[2], rc)
+        if q[5] is not None:
+            assert rel(q[5], rcs) < TOL_F32, rel(q[5], rcs)
+
+
 def test_mhsa_out_row_scale(ops):
     """0/1 DropPath keep mask folded into the attention output: rows of dropped samples are exact zeros, kept ones unchanged;
     the backward of a kept sample is unaffected and a dropped one (dout = 0) yields zeros.  Both kernel families."""
@@ -489,7 +518,8 @@ def test_grouped_wgrad_launch_carries_the_layernorm_reductions(ops):
 
 
 @pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_MHSA_BWD_DS": "0", "AP_MHSA_FWD_P": "0"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"}, {"AP_OUTLOOK_MFMA": "0"},
-                                 {"AP_STEM_HIP_CONV": "0"}, {"AP_ASYNC_WGRAD": "1"}, {"AP_GEMM_TN_PLACE": "0"}, {"AP_FUSE_LN_REDUCE": "0"}, {"AP_CONV_WGRAD_P": "0"}])
+                                 {"AP_STEM_HIP_CONV": "0"}, {"AP_ASYNC_WGRAD": "1"}, {"AP_GEMM_TN_PLACE": "0"}, {"AP_FUSE_LN_REDUCE": "0"}, {"AP_CONV_WGRAD_P": "0"},
+                                 {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}])
 def test_experimental_kernel_paths_stay_parity_green(env):
     """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:
     re-run the GEMM / block tests in a child process with the switch set (the switches are read once per process)"""
