@@ -1669,15 +1669,19 @@ static bool tn_place(const TnGroup& grp, int cap, TnMap& map, int& blocks) {
 
 // Plan of the 192 x 192-tile kernel: every width a multiple of 192, whole 64-token K-tiles, plain row-major operands.  The token
 // axis is cut into ranges of `ksps` K-tiles, the smallest that leaves at most one work item per CU and fits the per-XCD placement.
-static bool tn8_plan(const ap_tn_problem* problems, int count, int n_cu, T8Group& g8, TnMap& map, int& mblocks) {
+static bool tn8_fits(const ap_tn_problem& q) {
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("AP_GEMM_TN_8P"); enabled = e ? atoi(e) : 1; }
-    if (!enabled || count <= 0 || count > TN_MAX_GROUP) return false;
+    if (!enabled || !q.A || !q.B || !q.C || q.b_patch || q.N1 <= 0 || q.N2 <= 0) return false;
+    if (q.N1 % 192 || q.N2 % 192 || q.M % 64 || q.M < 4096 || (q.lda & 7) || (q.ldb & 7) || q.lda < q.N1 || q.ldb < q.N2 || q.ldc < q.N2) return false;
+    return !(q.colsum_weight && (reinterpret_cast<uintptr_t>(q.colsum_weight) & 3));
+}
+static bool tn8_plan(const ap_tn_problem* problems, int count, int n_cu, T8Group& g8, TnMap& map, int& mblocks) {
+    if (count <= 0 || count > TN_MAX_GROUP) return false;
     int64_t work = 0; int max_k = 1;
     for (int i = 0; i < count; ++i) {
         const ap_tn_problem& q = problems[i];
-        if (q.b_patch || q.N1 % 192 || q.N2 % 192 || q.M % 64 || q.M < 4096 || (q.lda & 7) || (q.ldb & 7)) return false;
-        if (q.colsum_weight && (reinterpret_cast<uintptr_t>(q.colsum_weight) & 3)) return false;
+        if (!tn8_fits(q)) return false;
         work += (int64_t)(q.N1 / 192) * (q.N2 / 192) * (q.M / 64);
         if (q.M / 64 > max_k) max_k = q.M / 64;
     }
@@ -1730,7 +1734,9 @@ int ap_gemm_tn_acc_grouped_ln(const ap_tn_problem* problems, int count, const ap
     TnGroup grp; int blocks = 0; size_t fl = 0;
     const int rc = tn_plan(problems, count, grp, blocks, fl);
     if (rc != AP_OK) return rc;
-    if (!workspace) {                                 // the 192 x 192-tile LDS-DMA kernel where the whole group fits it
+    if (!workspace) {
+        // the 192 x 192-tile LDS-DMA kernel takes the problems that fit it (with the LayerNorm riders); the rest of the group -- e.g. the
+        // 486-wide attention-weight projection of an outlooker block -- goes on in a launch of the 128 x 128-tile kernel
         static int n_cu = 0;
         if (n_cu == 0) {
             int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr;
@@ -1738,8 +1744,11 @@ int ap_gemm_tn_acc_grouped_ln(const ap_tn_problem* problems, int count, const ap
             (void)hipFuncSetAttribute((const void*)k_gemm_tn_8p, hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS_BYTES);
             (void)hipGetLastError();
         }
+        ap_tn_problem fit[AP_TN_MAX_GROUP], rest[AP_TN_MAX_GROUP];
+        int nfit = 0, nrest = 0;
+        for (int i = 0; i < count; ++i) { if (tn8_fits(problems[i])) fit[nfit++] = problems[i]; else rest[nrest++] = problems[i]; }
         T8Group g8; TnMap map8; int mb8 = 0;
-        if (tn8_plan(problems, count, n_cu, g8, map8, mb8)) {
+        if (nfit > 0 && tn8_plan(fit, nfit, n_cu, g8, map8, mb8)) {
             TnLn ln;
             int lblocks = 0;
             for (int i = 0; i < AP_LN_MAX_BATCH; ++i) {
@@ -1751,7 +1760,9 @@ int ap_gemm_tn_acc_grouped_ln(const ap_tn_problem* problems, int count, const ap
             ln.count = ln_count; ln.first = mb8;
             (void)hipGetLastError();
             hipLaunchKernelGGL(k_gemm_tn_8p, dim3(mb8 + lblocks), dim3(512), T8_LDS_BYTES, (hipStream_t)stream, g8, map8, ln);
-            return ap_check_launch();
+            const int rc8 = ap_check_launch();
+            if (rc8 != AP_OK || nrest == 0) return rc8;
+            return ap_gemm_tn_acc_grouped_ln(rest, nrest, nullptr, 0, nullptr, 0, stream);
         }
     }
     if (workspace) {                                  // deterministic: stored partial tiles + ordered reduce instead of fp32 atomics

@@ -296,16 +296,19 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     // -- (0, part 0) | (0, part 1) + (1, part 1) | (1, part 0) -- with the second A half in registers of its own.  Parts of K-tile
     // T+1 still missing go out in phase 1 (A h1, B part 1: their last reads were phase 2 of T-1), of T+2 in phases 2 (B part 0) and
     // 3 (A h0); the counted wait of phase 3 leaves those two (4 pieces) in flight.
-    auto ktile3 = [&](int bo) {
+    // STEADY (compile time): the K-tiles this one issues for belong to the SAME output tile (kt + 2 < nk), so every issue is
+    // unconditional and the loop body has no branch and no tile bookkeeping
+    auto ktile3 = [&](int bo, auto steadyc) {
+        constexpr bool STEADY = decltype(steadyc)::value;
         if constexpr (NT1 == 1) {
             readB0(rdB0 + bo); G8_FENCE(); readA(rdA + bo, 0); G8_FENCE();
-            if (q_tile < t_end) { dma(qa1, KS - bo, 1); dma1(KS - bo); }
-            q_advance();
+            if (STEADY || q_tile < t_end) { dma(qa1, KS - bo, 1); dma1(KS - bo); }
+            if constexpr (STEADY) ++q_kt; else q_advance();
             G8_LGKM(8); G8_FENCE();
             G8_BAR(); G8_LGKM(0); G8_FENCE();
             mma0(0); G8_FENCE();
             G8_BAR();
-            const bool live = q_tile < t_end;
+            const bool live = STEADY || q_tile < t_end;
             readB1(rdB1 + bo); G8_FENCE(); readA_to(af1, rdA + bo, 1); G8_FENCE();
             if (live) dma(qb0, bo, 2);
             G8_BAR(); G8_LGKM(0); G8_FENCE();
@@ -318,18 +321,19 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
             G8_BAR();
         }
     };
-    auto ktile = [&](int bo) {
-        if constexpr (NT1 == 1) { ktile3(bo); return; }
+    auto ktile = [&](int bo, auto steadyc) {
+        constexpr bool STEADY = decltype(steadyc)::value;
+        if constexpr (NT1 == 1) { ktile3(bo, steadyc); return; }
         // phase 1: quadrant (0, part 0); completes K-tile T+1 (A h1 into the other buffer)
         readB0(rdB0 + bo); G8_FENCE(); readA(rdA + bo, 0); G8_FENCE();
-        if (q_tile < t_end) dma(qa1, KS - bo, 1);
-        q_advance();
+        if (STEADY || q_tile < t_end) dma(qa1, KS - bo, 1);
+        if constexpr (STEADY) ++q_kt; else q_advance();
         G8_LGKM(8); G8_FENCE();
         G8_BAR(); G8_LGKM(0); G8_FENCE();
         mma0(0); G8_FENCE();
         G8_BAR();
         // phase 2: quadrant (0, part 1); B part 0 of K-tile T+2
-        const bool live = q_tile < t_end;
+        const bool live = STEADY || q_tile < t_end;
         readB1(rdB1 + bo); G8_FENCE();
         if (live) dma(qb0, bo, 2);
         G8_BAR(); G8_LGKM(0); G8_FENCE();
@@ -366,7 +370,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     for (int tile = t_begin; tile < t_end; tile += nxw) {
         if (wr == 1) G8_BAR();            // the second wave group runs one barrier behind the first
         zero_acc();
-        for (int kt = 0; kt < nk; ++kt) { ktile(bo); bo = KS - bo; }
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) { ktile(bo, std::true_type{}); bo = KS - bo; }
+        for (; kt < nk; ++kt) { ktile(bo, std::false_type{}); bo = KS - bo; }
         if (wr == 0) G8_BAR();            // ... and is waited for here: the eight epilogues run together
         // ---- epilogue, straight from the accumulators: lane (fr, g) holds row fr of each 16-row tile
         const int m0 = (tile / ga.tiles_n) * 256, n0 = (tile % ga.tiles_n) * BN;
@@ -432,20 +438,42 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
             const int c1 = NT1 == 2 ? (wc * WN + 32) / 8 + g : (wc * WN + 32) / 8 + (g >> 1);
             const int off0 = ((c0 ^ (fr & 7)) << 4);
             const int off1 = ((c1 ^ (fr & 7)) << 4) + (NT1 == 2 ? 0 : (g & 1) * 8);
+            // the second operand of the whole tile (residual, or the stored pre-activation of gelu') in MFMA layout, by loads hipcc does
+            // not see (it would guard every later LDS access and store with vmcnt(0)): one exposed latency per tile, under which the
+            // stream's prefetch of the next tile keeps landing.  (Staging it through LDS by DMA, pass by pass, exposed one latency per
+            // pass: gelu' at N = 1152 was 62 us against 60.6 for the 128 x 128-tile kernel.)
+            typedef typename std::conditional<NT1 == 2, u32x4, u32x2>::type in1_t;
+            // (the instantiations that spill registers take ordinary loads: a destination of an asm load may be spilled before it lands)
+            constexpr bool ASM_IN = EF >= 0 && !(NT1 == 2 && EF == (G8_BIAS | G8_RS | G8_RES));
+            u32x4 in0[2][4];
+            in1_t in1[2][4];
+            if (has_dgelu || has_res) {
+                const bf16_t* ibase = in_src + min(nb + g * 8, ga.N - 8);
+                const bf16_t* ibase1 = in_src + min(nb + 32 + g * 4 * NT1, ga.N - 4 * NT1);
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const int64_t roff = (int64_t)min(m0 + mh * 128 + wr * 64 + mt * 16 + fr, ga.M - 1) * in_ld;
+                        if constexpr (ASM_IN) {
+                            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(in0[mh][mt]) : "v"(ibase + roff) : "memory");
+                            if constexpr (NT1 == 2) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(in1[mh][mt]) : "v"(ibase1 + roff) : "memory");
+                            else asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(in1[mh][mt]) : "v"(ibase1 + roff) : "memory");
+                        } else {
+                            in0[mh][mt] = *reinterpret_cast<const u32x4*>(ibase + roff);
+                            in1[mh][mt] = *reinterpret_cast<const in1_t*>(ibase1 + roff);
+                        }
+                    }
+                G8_VM(0);
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) { asm volatile("" : "+v"(in0[mh][mt])); asm volatile("" : "+v"(in1[mh][mt])); }
+            }
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int mh = pass / (NPASS / 2), mtb = (pass % (NPASS / 2)) * PASS_MT;    // this pass: tiles mt = mtb .. mtb + PASS_MT - 1 of half mh
                 const int rbase = m0 + mh * 128 + wr * 64 + mtb * 16;                        // first matrix row of the wave group's pass
-                if (has_dgelu || has_res) {
-#pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        const int id = it * 256 + wc * 64 + lane, row = id / CPR, p = id % CPR;
-                        const bf16_t* src = in_src + (int64_t)min(rbase + row, ga.M - 1) * in_ld + min(n0 + ((p ^ (row & 7)) << 3), ga.N - 8);
-                        __builtin_amdgcn_global_load_lds(G8_GLB(src), G8_LDS(stg + (it * 256 + wc * 64) * 16), 16, 0, 0);
-                    }
-                    G8_VM(0);
-                    G8_BAR();
-                }
 #pragma unroll
                 for (int t = 0; t < PASS_MT; ++t) {
                     const int mt = mtb + t;
@@ -466,14 +494,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                         for (int q = 0; q < 4 * NT1; ++q) w[q] += bias1[q];
                     }
                     if (!rowgelu) {
-                        u32x4 i0 = {0u, 0u, 0u, 0u}, i1 = {0u, 0u, 0u, 0u};
-                        if (has_dgelu || has_res) {
-                            i0 = g8_lds_ld16(rowp + off0);
-                            if constexpr (NT1 == 2) i1 = g8_lds_ld16(rowp + off1);
-                            else { const u32x2 t2 = g8_lds_ld8(rowp + off1); i1[0] = t2[0]; i1[1] = t2[1]; }
-                            G8_LGKM(0);
-                            asm volatile("" : "+v"(i0), "+v"(i1));
-                        }
+                        const u32x4 i0 = in0[mh][mt];
+                        u32x4 i1 = {0u, 0u, 0u, 0u};
+                        if constexpr (NT1 == 2) i1 = in1[mh][mt]; else { i1[0] = in1[mh][mt][0]; i1[1] = in1[mh][mt][1]; }
                         if (has_dgelu) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) { v[2 * q] *= gelu_erf_grad(bf_lo(i0[q])); v[2 * q + 1] *= gelu_erf_grad(bf_hi(i0[q])); }

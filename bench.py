@@ -17,6 +17,8 @@ Workloads (--workload):
           0 / .033 / .067 / .1 on ONE supernet (elastic depth mask + on-device bilinear resize, main_prog.py:973), a quarter
           of the steps each; --search-mix draws (l, r) uniformly per step instead (supernet search, main_prog.py:1824-1828)
   d5      BASELINE.json configs[4] in bf16: volo_d5 at 448 px (flash MHSA, head_dim 48), default per-GPU batch 16
+  deit_base  BASELINE.json configs[3]: the DeiT-Base supernet (deit_h12_l12) under the AutoProg search mix -- one (l, r) per step
+          drawn from l in {6, 9, 12} x r in {128, 160, 192, 224} (main_prog.py:1824-1836), soft-target CE, per-GPU batch 128
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     dominant kernel (k_gemm_nt): algorithmic FLOPs and bytes of its launches in one step / their summed duration,
@@ -41,6 +43,20 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PEAK_HBM_TBS = 8.0              # HBM3E peak
 STAGES = [(9, 128, 0.0), (12, 160, 0.0333), (15, 192, 0.0667), (18, 224, 0.1)]      # prog/progressive.py:4-31 with scripts/train_autoprog.sh
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: profiles/gemm_nt_traffic.json records the hash of the tree its counters were collected on,
+    and the bench line carries `roofline.traffic` only while the sources are still those (a stale file reads as null)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "autoprog_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
 
 
 def make_target(B, C, N, device, gen):
@@ -205,7 +221,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (scripts/train_autoprog.sh: -b 128)")
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--variant", default="volo_h12_l18")
-    ap.add_argument("--workload", default="d1", choices=["d1", "stages", "d5"],
+    ap.add_argument("--workload", default="d1", choices=["d1", "stages", "d5", "deit_base"],
                     help="d5: BASELINE configs[4] in bf16 -- VOLO-D5 at 448 px (use --batch 8..16); not the default line")
     ap.add_argument("--search-mix", action="store_true", help="stages workload: uniform random (l, r) per step (supernet search)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -250,7 +266,11 @@ def main():
 
     torch.manual_seed(42 + rank)
     np.random.seed(42 + rank)
-    if args.workload == "d5":
+    DEIT_L, DEIT_R = [6, 9, 12], [128, 160, 192, 224]
+    if args.workload == "deit_base":
+        args.variant, args.res = "deit_h12_l12", 224
+        model = create_model("model_variant", variant="deit_h12_l12", drop_path_rate=0.1).to(dev).train()
+    elif args.workload == "d5":
         args.variant, args.res = "volo_d5", 448
         if args.batch == 128:
             args.batch = 16
@@ -261,6 +281,9 @@ def main():
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0)
     loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=1000)
+    if args.workload == "deit_base":
+        from autoprog_amd.loss import SoftTargetCrossEntropy
+        loss_fn = SoftTargetCrossEntropy()
     # the 1/world of the gradient mean is folded into the fused optimizer kernel (no extra pass over the 106 MB slab)
     reducer = GradientBucketReducer(list(model.parameters()), world_size=world, defer_mean=not args.no_optimizer)
     reducer.install_sink(model)
@@ -271,7 +294,23 @@ def main():
     B, res = args.batch, args.res
     gen = torch.Generator().manual_seed(42 + rank)
     images = torch.randn(B, 3, res, res, generator=gen).to(dev)
-    if args.workload == "stages":
+    if args.workload == "deit_base":
+        target = torch.softmax(torch.randn(B, 1000, generator=gen) * 3, dim=-1).to(dev)
+        random.seed(0)                 # identical (l, r) sequence on every rank
+
+        def step():
+            l, r = random.choice(DEIT_L), random.choice(DEIT_R)
+            model.set_sample_config(dict(layer_num=l, min_layer_num=DEIT_L[0], max_layer_num=DEIT_L[-1]))
+            reducer.zero_grad()
+            # the reference resizes the loader's batch to the step's resolution inside the step (main_prog.py:973-974)
+            xr = images if r == res else torch.nn.functional.interpolate(images, size=(r, r), mode="bilinear", align_corners=False)
+            loss = loss_fn(model(xr), target)
+            loss.backward()
+            reducer.finish()
+            if not args.no_optimizer:
+                opt.step()
+            return loss
+    elif args.workload == "stages":
         targets = {r: make_target(B, 1000, (r // 16) ** 2, dev, gen) for _, r, _ in STAGES}
         l_list, r_list = [s[0] for s in STAGES], [s[1] for s in STAGES]
         random.seed(0)                 # identical (l, r) sequence on every rank (reference: random.seed(epoch), main_prog.py:1861)
@@ -341,7 +380,7 @@ def main():
     # (reported under config, never part of `value`)
     fwd_bwd_ms = None
     allreduce_ms = None
-    if not args.no_optimizer and args.workload in ("d1", "d5"):
+    if not args.no_optimizer and args.workload in ("d1", "d5"):        # (the other workloads change (l, r) per step)
         def step_nb():
             reducer.zero_grad()
             loss_fn(model(images), target).backward()
@@ -386,11 +425,13 @@ def main():
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "gemm_nt_traffic.json")) as fh:
-                traffic = json.load(fh).get("hbm_bytes_per_launch")
+                tj = json.load(fh)
+            if args.workload == "d1" and tj.get("src_sha256") == kernel_source_hash():
+                traffic = tj.get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             pass
         hbm_bound = ai < ridge
-        roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": "k_gemm_nt",
+        roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": "ap_gemm_nt launches (k_gemm_nt_8p<...> + k_gemm_nt<...>)",
                     "achieved": round(tbs * 1e3 if hbm_bound else tflops, 2), "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else PEAK_BF16_TFLOPS,
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
                     "frac": round(tbs / PEAK_HBM_TBS if hbm_bound else tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
@@ -409,13 +450,17 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
-        if args.workload == "stages":
+        if args.workload == "deit_base":
+            wl = ("BASELINE.json configs[3]: deit_h12_l12 (DeiT-Base) supernet, AutoProg search mix -- uniform random l in %s x r in %s per step, "
+                  "soft-target CE, batch %d, on-device resize from %d px" % (DEIT_L, DEIT_R, B, res))
+        elif args.workload == "stages":
             wl = ("BASELINE.json configs[2]: %s supernet over the AutoProg stages (l,r) = %s, %s, batch %d, on-device resize from %d px"
                   % (args.variant, [(s[0], s[1]) for s in STAGES], "uniform random (l,r) per step" if args.search_mix else "a quarter of the steps each", B, res))
         else:
             wl = ("BASELINE.json configs[4] in bf16 (no fp8): volo_d5 448px token-label training step, batch %d" % B if args.workload == "d5"
                   else "BASELINE.json configs[1]: %s (VOLO-D1) %dpx token-label training step" % (args.variant, res))
         metric = ("images/sec/GPU (fwd+bwd) VOLO-D5 448px token-label step" if args.workload == "d5"
+                  else "images/sec/GPU (fwd+bwd) DeiT-Base AutoProg search-mix step" if args.workload == "deit_base"
                   else "images/sec/GPU (fwd+bwd) VOLO-D1 224px AutoProg step")
         line = {"metric": metric, "value": round(value, 2), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
