@@ -64,6 +64,7 @@ _SIGNATURES = {
     "ap_class_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "ap_mix_token_swap": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ap_soft_ce_fwd_bwd": (_I, [_P, _I, _P, _L, _L, _L, _I, _P, _P, _F, _L, _I, _F, _I, _P]),
+    "ap_soft_ce_sparse_fwd_bwd": (_I, [_P, _I, _P, _P, _I, _L, _L, _I, _F, _P, _P, _F, _L, _I, _P]),
     "ap_loss_combine": (_I, [_P, _L, _F, _P, _L, _F, _P, _P]),
     "ap_row_scale": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "ap_add_bcast": (_I, [_P, _P, _P, _L, _L, _P]),

@@ -25,12 +25,8 @@
 #include "gemm_epi.h"
 #include "gemm8p.h"
 #include "gemm_tn8p.h"
-#ifndef AP_EXPERIMENTS
-#define AP_EXPERIMENTS 0       // 1: also build the measured-and-rejected kernels (LDS-DMA rings, persistent tiles) and their AP_GEMM_* switches
-#endif
-#if AP_EXPERIMENTS
-#include "gemm_dma.h"
-#endif
+// (the measured-and-rejected kernels of rounds 1 and 2 -- LDS-DMA rings, persistent 256-row tiles, the ring weight-gradient kernel -- and
+// their AP_GEMM_NT_P / _RING / _DMA, AP_GEMM_TN_RING switches live under tools/gemm_lab/rejected/, outside the product library)
 #include <cstdlib>
 #include <cstdio>
 
@@ -373,377 +369,6 @@ k_gemm_nt_skinny(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict
     }
 }
 
-#if AP_EXPERIMENTS
-// ------------------------------------------------------------ gemm_nt, persistent LDS-DMA ring
-// Main forward / input-gradient GEMM for K % 64 == 0 (every Linear of the D1..D5 and DeiT models).
-// Ablation of a non-persistent 256x128 ring kernel on the qkv shape (M 25088, N 1152, K 384; rocprof +
-// on/off builds): 12 us of 40 in the epilogue, ~3 us per tile of workgroup launch/setup with one
-// 144 KB workgroup per CU, main loop at 39 % of MFMA peak.  Hence this structure:
-//   * PERSISTENT: grid = min(tiles, #CU); a workgroup (8 waves) walks its tiles, and the K-step stream is
-//     flattened over (tile, k) so the LDS-DMA ring keeps prefetching the NEXT tile while the current
-//     tile's epilogue runs (loads overlap the epilogue; no per-tile launch cost)
-//   * 128 x TBN tile (TBN = 128, or 96 when N is a multiple of 96 but not 128: 192, 576), BK = 64,
-//     3-stage ring (96 KB) filled by global_load_lds (16 B/lane), counted s_waitcnt vmcnt + one raw
-//     s_barrier per K step; LDS image [A rows | B rows] x 64 bf16 with chunk ^= row&7 applied on the
-//     SOURCE address (the DMA writes LDS linearly)
-//   * epilogue through a separate 64 KB fp32 staging tile: accumulators -> LDS (chunk-swizzled) ->
-//     each thread owns 8 consecutive columns of a row: 16-byte coalesced loads of residual / gelu input
-//     and 16-byte coalesced stores
-template <int TBN, int WM, int WN>
-__global__ void __launch_bounds__(WM * WN * 64)
-k_gemm_nt_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
-               int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ring_raw[];
-    constexpr int TBM = 128;
-    constexpr int STAGES = 3;
-    constexpr int STAGE = 256 * 64;                  // elements per stage: 128 A rows + 128 B-row slots
-    constexpr int NW = WM * WN;                      // waves per workgroup (4 or 8)
-    constexpr int NI = 32 / NW;                      // global_load_lds per thread per K step (32 row groups of 8 rows)
-    constexpr int MT = TBM / WM / 16, NTT = TBN / WN / 16;
-    bf16_t* ring = reinterpret_cast<bf16_t*>(ring_raw);
-    float* ctile = reinterpret_cast<float*>(ring_raw + (size_t)STAGES * STAGE * sizeof(bf16_t));
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int fr = lane & 15, g = lane >> 4;
-    const int nk = K >> 6;
-    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int total = my_tiles * nk;
-
-    const bf16_t* src[NI];
-    auto set_tile_src = [&](int ti) {
-        const int tile = xcd_remap(blockIdx.x + ti * gridDim.x, ntiles);
-        const int m0 = (tile / tiles_n) * TBM, n0 = (tile % tiles_n) * TBN;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int r = (wave + NW * i) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ (r & 7);
-            src[i] = (r < TBM) ? A + (int64_t)min(m0 + r, M - 1) * lda + c * 8
-                               : B + (int64_t)min(n0 + min(r - TBM, TBN - 1), N - 1) * ldb + c * 8;
-        }
-    };
-    int q_tile = 0, q_k = 0, q_stage = 0;            // issue cursor over the flattened (tile, k) stream
-    auto issue_next = [&]() {
-        if (q_k == 0) set_tile_src(q_tile);
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + q_k * 64),
-                                             (__attribute__((address_space(3))) void*)(ring + q_stage * STAGE + (wave + NW * i) * 512), 16, 0, 0);
-        if (++q_k == nk) { q_k = 0; ++q_tile; }
-        q_stage = (q_stage == STAGES - 1) ? 0 : q_stage + 1;
-    };
-
-    f32x4 acc[NTT][MT];
-    int issued = 0;
-    for (; issued < STAGES - 1 && issued < total; ++issued) issue_next();
-    int stage = 0, kt = 0, ti = 0;
-    for (int s = 0; s < total; ++s) {
-        if (kt == 0) {
-#pragma unroll
-            for (int a = 0; a < NTT; ++a)
-#pragma unroll
-                for (int b = 0; b < MT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        // K steps issued beyond s: issued - s - 1 (0..STAGES-2); wait until only those are outstanding
-        const int ahead = issued - s - 1;
-        if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (issued < total) { issue_next(); ++issued; }
-        const bf16_t* sA = ring + stage * STAGE;
-        const bf16_t* sB = sA + TBM * 64;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 xf[MT], wf[NTT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int r = wm * (TBM / WM) + i * 16 + fr;
-                xf[i] = as_bf16x8(ld16(sA + r * 64 + (((ks * 4 + g) ^ (r & 7)) << 3)));
-            }
-#pragma unroll
-            for (int i = 0; i < NTT; ++i) {
-                const int r = wn * (TBN / WN) + i * 16 + fr;
-                wf[i] = as_bf16x8(ld16(sB + r * 64 + (((ks * 4 + g) ^ (r & 7)) << 3)));
-            }
-#pragma unroll
-            for (int nt = 0; nt < NTT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
-        }
-        stage = (stage == STAGES - 1) ? 0 : stage + 1;
-        if (++kt < nk) continue;
-        kt = 0;
-        // ------------------------------------------------------------ epilogue of tile `ti`
-        const int tile = xcd_remap(blockIdx.x + ti * gridDim.x, ntiles);
-        ++ti;
-        const int m0 = (tile / tiles_n) * TBM, n0 = (tile % tiles_n) * TBN;
-        if (ep.dbg & 1) { if (acc[0][0][0] == 12345.f) C[0] = 1; continue; }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int r = wm * (TBM / WM) + mt * 16 + fr;
-#pragma unroll
-            for (int nt = 0; nt < NTT; ++nt) {
-                const int c16 = (wn * (TBN / WN) + nt * 16) / 4 + g;
-                *reinterpret_cast<f32x4*>(ctile + r * TBN + ((c16 ^ (r & 7)) << 2)) = acc[nt][mt];
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // raw barrier: the next tile's LDS-DMA stays in flight
-        constexpr int CPR = TBN / 8;                  // 8-column chunks per row
-        const bool vec_ok = ((ldc & 7) == 0) && (ep.residual == nullptr || (ep.ldr & 7) == 0);
-#pragma unroll 2
-        for (int id = tid; id < TBM * CPR; id += NW * 64) {
-            const int r = id / CPR, j = id - r * CPR;
-            const int m = m0 + r, n = n0 + 8 * j;
-            if (m >= M || n >= N) continue;
-            float v[8];
-            {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(ctile + r * TBN + (((2 * j) ^ (r & 7)) << 2));
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(ctile + r * TBN + (((2 * j + 1) ^ (r & 7)) << 2));
-                v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-            }
-            epi_chunk(v, m, n, N, ldc, vec_ok, ep, C);
-        }
-        // the staging tile is rewritten only after the next tile's nk >= 1 K-step barriers: no barrier needed here
-    }
-}
-
-// ------------------------------------------------------------ gemm_nt, persistent 256 x (32*NTF) tiles
-// The multi-workgroup 128x128 kernel above is LDS-bound (ablation on the qkv shape, DESIGN.md: the
-// ds_write/ds_read/barrier loop alone takes 16.7 us of 36 -- 0.5 KB of fragment reads per MFMA plus
-// ds_write_b128 at ~79 B/clk).  This kernel cuts the LDS cycles per FLOP:
-//   * operands go global -> LDS by LDS-DMA (global_load_lds, 16 B/lane): no VGPR round trip, no ds_write
-//   * 8 waves as 4(M) x 2(N), wave tile 64 x (16*NTF): 0.42 KB of fragment reads per MFMA at NTF = 6
-//   * persistent (one workgroup per CU), K steps flattened over (tile, k): the DMA of the next tile's first
-//     K step is in flight while the current tile's epilogue runs; 2-stage ring, one raw s_barrier per K step
-//   * epilogue per wave through a PRIVATE fp32 LDS strip (no workgroup barrier): accumulators -> strip ->
-//     rows of 8 consecutive columns per lane -> 16-byte coalesced loads/stores (epi_chunk)
-// LDS image of a stage: [256 A rows | TBN B rows] x 64 bf16, 16-B chunk index XORed with row&7 (applied on
-// the DMA SOURCE address; the DMA writes LDS linearly).
-template <int NTF>
-__global__ void __launch_bounds__(512)
-k_gemm_nt_p(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, bf16_t* __restrict__ C, int ldc,
-            int M, int N, int K, int tiles_n, int ntiles, EpiArgs ep) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char p_raw[];
-    constexpr int TBM = 256, TBN = 32 * NTF, ROWS = TBM + TBN;
-    constexpr int STAGE = ROWS * 64;                 // bf16 elements per stage
-    constexpr int NI = ROWS / 64;                    // LDS-DMA instructions per wave per K step (8 rows each, 8 waves)
-    constexpr int WN_COLS = TBN / 2;                 // columns per wave
-    constexpr int STRIP = 16 * WN_COLS;              // floats per wave staging strip
-    static_assert(ROWS % 64 == 0, "stage rows split over 8 waves x 8 rows");
-    bf16_t* ring = reinterpret_cast<bf16_t*>(p_raw);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* strip = reinterpret_cast<float*>(p_raw + (size_t)2 * STAGE * sizeof(bf16_t)) + wave * STRIP;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int fr = lane & 15, g = lane >> 4;
-    const int nk = K >> 6;
-    const int G = gridDim.x;
-    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
-    const int total = my_tiles * nk;
-
-    // per-lane DMA source offsets (elements) of the tile being prefetched
-    uint32_t soff[NI];                               // element offsets < 2^32 (checked by the launcher)
-    auto set_tile_src = [&](int ti) {
-        const int tile = xcd_remap(blockIdx.x + ti * G, ntiles);
-        int m0 = (tile / tiles_n) * TBM, n0 = (tile % tiles_n) * TBN;
-        if (ep.dbg & 8) { m0 = 0; n0 = 0; }           // ablation: every workgroup streams the same (cache-resident) panels
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int r = (wave + 8 * i) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ (r & 7);
-            soff[i] = (r < TBM) ? (uint32_t)min(m0 + r, M - 1) * (uint32_t)lda + c * 8
-                                : (uint32_t)min(n0 + (r - TBM), N - 1) * (uint32_t)ldb + c * 8;
-        }
-    };
-    int q_tile = 0, q_k = 0;
-    constexpr int NIA = (NI + 1) / 2;                // pieces of part A (issued first), the rest is part B
-    auto issue_part = [&](int stage, int i0, int i1) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if (i < i0 || i >= i1) continue;
-            const int r0 = (wave + 8 * i) * 8;                       // wave-uniform first row of this 8-row piece
-            const bf16_t* base = (r0 < TBM) ? A : B;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + soff[i] + q_k * 64),
-                                             (__attribute__((address_space(3))) void*)(ring + stage * STAGE + r0 * 64), 16, 0, 0);
-        }
-    };
-    auto issue_a = [&](int stage) {
-        if (q_k == 0) set_tile_src(q_tile);
-        issue_part(stage, 0, NIA);
-    };
-    auto issue_b = [&](int stage) {
-        issue_part(stage, NIA, NI);
-        if (++q_k == nk) { q_k = 0; ++q_tile; }
-    };
-    auto issue = [&](int stage) { issue_a(stage); issue_b(stage); };
-
-    f32x4 acc[NTF][4];
-    bf16x8 xf0[4], wf0[NTF], xf1[4], wf1[NTF];       // two fragment sets: reads of one are interleaved with the MFMAs of the other
-    auto frags = [&](const bf16_t* st, int ks, bf16x8* xf, bf16x8* wf) {
-        const bf16_t* sA = st;
-        const bf16_t* sB = st + TBM * 64;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = wm * 64 + i * 16 + fr;
-            xf[i] = as_bf16x8(ld16(sA + r * 64 + (((ks * 4 + g) ^ (r & 7)) << 3)));
-        }
-#pragma unroll
-        for (int i = 0; i < NTF; ++i) {
-            const int r = wn * WN_COLS + i * 16 + fr;
-            wf[i] = as_bf16x8(ld16(sB + r * 64 + (((ks * 4 + g) ^ (r & 7)) << 3)));
-        }
-    };
-    auto mfmas = [&](const bf16x8* xf, const bf16x8* wf) {
-#if (AP_ABL & 4)
-        {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, xf[t])));
-#pragma unroll
-            for (int t = 0; t < NTF; ++t) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, wf[t])));
-            return;
-        }
-#endif
-#pragma unroll
-        for (int nt = 0; nt < NTF; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
-    };
-#ifdef AP_STAMP
-    unsigned long long t_start = 0, r_start = 0;
-    if (ep.stamps) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
-#endif
-    constexpr int NRD = 4 + NTF;                     // ds_read_b128 per half step
-    constexpr int NMF = 4 * NTF;                     // MFMAs per half step
-    // prologue: two K steps in flight, first fragments in registers
-    if (total > 0) issue(0);
-    if (total > 1) {
-        issue(1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (total > 0) frags(ring, 0, xf0, wf0);
-    int kt = 0, ti = 0;
-    bool stores_in_flight = false;                   // the previous step ended with an unguarded (full-tile) epilogue
-    for (int s = 0; s < total; ++s) {
-        const bf16_t* cur = ring + (s & 1) * STAGE;
-        const bf16_t* nxt = ring + ((s + 1) & 1) * STAGE;
-        if (kt == 0) {
-#pragma unroll
-            for (int a = 0; a < NTF; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // first-half fragments (issued one half step ago)
-        // ---- first half: MFMAs on set 0, the reads of set 1 slotted between them (1 read : 2 MFMAs)
-#if !(AP_ABL & 32)
-        frags(cur, 1, xf1, wf1);
-#endif
-        mfmas(xf0, wf0);
-#pragma unroll
-        for (int i = 0; i < NRD; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 2 * NRD, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave is done reading stage `cur`
-        // ... and its pieces of step s+1 have landed.  They are OLDER than the >= 12 global stores of a full-tile epilogue the
-        // previous step may have issued (counters retire in order), so after such an epilogue only "all but the 12 youngest"
-        // is waited for: the stores drain in the background instead of stalling the first step of every tile.
-        if (stores_in_flight) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stores_in_flight = false;
-        __builtin_amdgcn_s_barrier();                                // true for every wave: `cur` is free, `nxt` is complete
-        // ---- second half: MFMAs on set 1 with the DMA of step s+2 and the first-half reads of step s+1 between them.
-        // Past the end the DMA fetches (row-clamped, in-bounds) data nobody reads and the reads are unused: no branches here.
-        if (q_k == 0) set_tile_src(q_tile);
-        {
-            const bf16_t* sA = nxt;
-            const bf16_t* sB = nxt + TBM * 64;
-            const int dst = (s & 1) * STAGE;
-#pragma unroll
-            for (int j = 0; j < NMF; ++j) {
-#if (AP_ABL & 4)
-                if (j < 4) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, xf1[j]))); else if (j < NRD) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, wf1[j - 4])));
-#else
-                acc[j >> 2][j & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[j >> 2], xf1[j & 3], acc[j >> 2][j & 3], 0, 0, 0);
-#endif
-#if !(AP_ABL & 32)
-                if (j < 4) {
-                    const int r = wm * 64 + j * 16 + fr;
-                    xf0[j] = as_bf16x8(ld16(sA + r * 64 + ((g ^ (r & 7)) << 3)));
-                } else if (j < NRD) {
-                    const int r = wn * WN_COLS + (j - 4) * 16 + fr;
-                    wf0[j - 4] = as_bf16x8(ld16(sB + r * 64 + ((g ^ (r & 7)) << 3)));
-                }
-#endif
-#if !(AP_ABL & 16)
-                if ((j & 1) && (j >> 1) < NI) {
-                    const int i = j >> 1;
-                    const int r0 = (wave + 8 * i) * 8;
-                    const bf16_t* base = (r0 < TBM) ? A : B;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + soff[i] + q_k * 64),
-                                                     (__attribute__((address_space(3))) void*)(ring + dst + r0 * 64), 16, 0, 0);
-                }
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (++q_k == nk) { q_k = 0; ++q_tile; }
-        if (++kt < nk) continue;
-        kt = 0;
-        // ------------------------------------------------------------ epilogue of tile `ti` (wave-private)
-        const int tile = xcd_remap(blockIdx.x + ti * G, ntiles);
-        ++ti;
-        const int m0 = (tile / tiles_n) * TBM + wm * 64, n0 = (tile % tiles_n) * TBN + wn * WN_COLS;
-        if (ep.dbg & 1) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int a = 0; a < NTF; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
-            if (sacc == 12345.678f) C[0] = 1;
-            continue;
-        }
-        const bool vec_ok = ((ldc & 7) == 0) && (ep.residual == nullptr || (ep.ldr & 7) == 0);
-        constexpr int CPR = WN_COLS / 8;              // 8-column chunks per strip row
-        constexpr int ITEMS = 16 * CPR / 64;          // chunks per lane per 16-row strip
-        static_assert((16 * CPR) % 64 == 0, "strip chunks split evenly over the wave");
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-            for (int nt = 0; nt < NTF; ++nt)
-                *reinterpret_cast<f32x4*>(strip + fr * WN_COLS + (((nt * 4 + g) ^ (fr & 7)) << 2)) = acc[nt][mt];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private strip: no barrier needed
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                const int id = lane + 64 * it;
-                const int r = id / CPR, j = id - r * CPR;
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + r * WN_COLS + (((2 * j) ^ (r & 7)) << 2));
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + r * WN_COLS + (((2 * j + 1) ^ (r & 7)) << 2));
-                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                const int m = m0 + mt * 16 + r, n = n0 + 8 * j;
-                if (m < M && n < N) epi_chunk(v, m, n, N, ldc, vec_ok, ep, C);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // strip reads done before the next strip overwrites it
-        }
-        stores_in_flight = vec_ok && (m0 + 64 <= M) && (n0 + WN_COLS <= N);     // every lane stored all its 4 * ITEMS chunks
-    }
-#ifdef AP_STAMP
-    if (ep.stamps && blockIdx.x == 0 && tid == 0) {
-        ep.stamps[0] = __builtin_amdgcn_s_memtime() - t_start;
-        ep.stamps[1] = __builtin_amdgcn_s_memrealtime() - r_start;
-        ep.stamps[2] = total;
-    }
-#endif
-}
-
-#endif  // AP_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------ wgrad
 #define TM 64          // tokens per step (MFMA reduction)
@@ -1105,121 +730,6 @@ k_tn_reduce(TnGroup grp) {
     }
 }
 
-#if AP_EXPERIMENTS
-// --------------------------------------------------------------------- wgrad, LDS-DMA ring
-// Same reduction as k_gemm_tn for the full 64-token steps of [0, M - M%64): 8 waves (2 x 4, wave tile
-// 64 x 32), operand tiles [64 tok][128] filled by global_load_lds into a 4-stage ring (128 KB), three
-// steps in flight behind a counted s_waitcnt vmcnt and ONE raw s_barrier per step (the register-staged
-// kernel needs two barriers + 8 ds_write_b128 per step and was latency bound at ~280 TFLOP/s).
-// The LDS image is written linearly by the DMA (4 rows of 256 B per wave instruction), so the
-// transposed-read swizzle tn_swz(row) is applied to the per-lane SOURCE chunk.  Columns beyond N1/N2
-// are clamped (they only feed output rows/cols that are never stored).
-__global__ void __launch_bounds__(512)
-k_gemm_tn_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
-               int steps_total, int N1, int N2, int steps_per_split, float* __restrict__ colsum) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char tn_raw[];
-    constexpr int STAGES = 4;
-    constexpr int STAGE = 2 * TM * 128;              // elements: A tile then B tile
-    constexpr int NI = 4;
-    bf16_t* ring = reinterpret_cast<bf16_t*>(tn_raw);
-    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-    const int step_begin = blockIdx.z * steps_per_split;
-    const int step_end = min(steps_total, step_begin + steps_per_split);
-    const int nsteps = step_end - step_begin;
-    if (nsteps <= 0) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 2, wk = wave & 3;         // 2 x 4 waves: 64 (n1) x 32 (n2) per wave
-    // DMA sources: row group rg = wave + 8*i covers 4 token rows of the A tile (rg < 16) or the B tile
-    const bf16_t* src[NI];
-    int64_t sstride[NI];
-    const int lastA = (N1 - 1 - n0) >> 3, lastB = (N2 - 1 - k0) >> 3;        // last valid 16-B chunk of this tile
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int rg = wave + 8 * i;
-        const bool isA = rg < 16;
-        const int r = (rg & 15) * 4 + (lane >> 4);
-        int c = (lane & 15) ^ tn_swz(r);
-        c = min(c, isA ? lastA : lastB);
-        src[i] = isA ? A + (int64_t)(step_begin * TM + r) * lda + n0 + c * 8 : B + (int64_t)(step_begin * TM + r) * ldb + k0 + c * 8;
-        sstride[i] = (int64_t)TM * (isA ? lda : ldb);
-    }
-    auto issue = [&](int t, int stage) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int rg = wave + 8 * i;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + t * sstride[i]),
-                                             (__attribute__((address_space(3))) void*)(ring + stage * STAGE + rg * 512), 16, 0, 0);
-        }
-    };
-    f32x4 acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool do_colsum = (colsum != nullptr) && (blockIdx.y == 0) && (wk == 0);
-    f32x4 csum[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) csum[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
-
-    int issued = 0;
-    for (; issued < STAGES - 1 && issued < nsteps; ++issued) issue(issued, issued);
-    int stage = 0;
-    for (int t = 0; t < nsteps; ++t) {
-        const int ahead = issued - t - 1;            // steps in flight beyond t: 0..STAGES-2
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (issued < nsteps) { issue(issued, (stage + STAGES - 1) % STAGES); ++issued; }
-        const bf16_t* sA = ring + stage * STAGE;
-        const bf16_t* sB = sA + TM * 128;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], bfr[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = tr_frag(sA, ks * 32, wn * 64 + i * 16, lane);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) bfr[i] = tr_frag(sB, ks * 32, wk * 32 + i * 16, lane);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], bfr[kt], acc[nt][kt], 0, 0, 0);
-            if (do_colsum) {
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) csum[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nt], ones, csum[nt], 0, 0, 0);
-            }
-        }
-        stage = (stage == STAGES - 1) ? 0 : stage + 1;
-    }
-    const int fr = lane & 15, g = lane >> 4;
-    if (do_colsum && fr == 0) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * 64 + nt * 16 + 4 * g + r;
-                if (n < N1) atomicAdd(colsum + n, csum[nt][r]);
-            }
-    }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            const int kk = k0 + wk * 32 + kt * 16 + fr;
-            if (kk >= N2) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * 64 + nt * 16 + 4 * g + r;
-                if (n < N1) atomicAdd(C + (int64_t)n * ldc + kk, acc[nt][kt][r]);
-            }
-        }
-}
-
-#endif  // AP_EXPERIMENTS
 
 // launch of the persistent 8-phase kernel (gemm8p.h): one instantiation per epilogue flavour of the training step, a generic one
 // for anything else
@@ -1298,103 +808,6 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         hipLaunchKernelGGL(k_gemm_nt_skinny, dim3((N + 31) / 32, (M + 63) / 64), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, ep);
         return ap_check_launch();
     }
-#if AP_EXPERIMENTS
-    // LDS-DMA ring kernels of gemm_dma.h (round-2 lab, profiles/r02_gemm_lab.txt): AP_GEMM_NT_DMA=1 routes plain / bias-only launches
-    // with N % 192 == 0 and K % 64 == 0 to the persistent 256x192 tile (up to 8 % faster than the kernel below on cold operands
-    // for N = 192 / 384, slower with epilogue operands: its direct epilogue reads them in 64-byte row segments).  Default off.
-    static int use_dma = -1;
-    if (use_dma < 0) { const char* e = getenv("AP_GEMM_NT_DMA"); use_dma = e ? atoi(e) : 0; }
-    if (use_dma && (K & 63) == 0 && N % 192 == 0 && M >= 2048 && !ep.gelu && !ep.dgelu_of && !ep.residual && !ep.row_scale &&
-        (int64_t)M * lda < (1ll << 32) && (int64_t)N * ldb < (1ll << 32)) {
-        static int n_cu = 0;
-        if (n_cu == 0) { int dev = 0; hipGetDevice(&dev); hipDeviceProp_t pr; n_cu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
-        const int tm = (M + 255) / 256, tn = N / 192, nt = tm * tn;
-        const int grid = nt < n_cu ? nt : n_cu;
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)k_gemm_nt_dma2<256, 192, 4, 2, 2, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 448 * 128);
-            (void)hipFuncSetAttribute((const void*)k_gemm_nt_dma3<256, 192, 4, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 448 * 64);
-            attr_done = true;
-            (void)hipGetLastError();
-        }
-        if (use_dma == 3) hipLaunchKernelGGL((k_gemm_nt_dma3<256, 192, 4, 2, 4>), dim3(grid), dim3(512), 4 * 448 * 64, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
-        else hipLaunchKernelGGL((k_gemm_nt_dma2<256, 192, 4, 2, 2, 64, 1>), dim3(grid), dim3(512), 2 * 448 * 128, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
-        return ap_check_launch();
-    }
-    static int force_small = -1;
-    // the persistent one-workgroup-per-CU ring kernel measured ~8 % slower than the multi-workgroup 128x128
-    // kernel with the same coalesced epilogue (DESIGN.md "GEMM experiments"); kept selectable for tuning
-    if (force_small < 0) { const char* e = getenv("AP_GEMM_NT_RING"); force_small = (e && e[0] == '1') ? 0 : 1; }
-    if ((K & 63) == 0 && !force_small) {
-        static int n_cu = 0;
-        if (n_cu == 0) { int dev = 0; hipGetDevice(&dev); hipDeviceProp_t pr; n_cu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
-        const size_t lds = (size_t)3 * 256 * 64 * sizeof(bf16_t) + (size_t)128 * 128 * sizeof(float);       // 96 KB ring + 64 KB staging
-        const bool narrow = (N % 96 == 0) && (N % 128 != 0);
-        const int tbn = narrow ? 96 : 128;
-        const int tm = (M + 127) / 128, tn = (N + tbn - 1) / tbn, nt = tm * tn;
-        const int grid = nt < n_cu ? nt : n_cu;
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)k_gemm_nt_ring<128, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)k_gemm_nt_ring<96, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
-        (void)hipGetLastError();
-        static int cfg4 = -1;
-        if (cfg4 < 0) { const char* e = getenv("AP_GEMM_4WAVE"); cfg4 = (e && e[0] == '1') ? 1 : 0;
-            (void)hipFuncSetAttribute((const void*)k_gemm_nt_ring<128, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
-        if (narrow) hipLaunchKernelGGL((k_gemm_nt_ring<96, 4, 2>), dim3(grid), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
-        else if (cfg4) hipLaunchKernelGGL((k_gemm_nt_ring<128, 2, 2>), dim3(grid), dim3(256), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
-        else hipLaunchKernelGGL((k_gemm_nt_ring<128, 2, 4>), dim3(grid), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
-        return ap_check_launch();
-    }
-    // persistent 256-row-tile kernel (k_gemm_nt_p): AP_GEMM_NT_P=1 always (when eligible), 4/6 always with that NTF, -2 where it
-    // measured faster STANDALONE on the VOLO-D1 list (long reductions into narrow outputs: 30 vs 37 us on the dfc1 / dqkv
-    // shapes); default 0 = never: inside the training step the same launches measured 39.5 us (a 256-workgroup x 160 KB launch
-    // cannot start on a CU until the previous kernel has drained from it) and the step was 0.1 ms slower with it.
-    static int use_p = -100;
-    if (use_p == -100) { const char* e = getenv("AP_GEMM_NT_P"); use_p = e ? atoi(e) : 0; }
-    const bool p_ok = (K & 63) == 0 && M >= 256 && (int64_t)M * lda < (1ll << 32) && (int64_t)N * ldb < (1ll << 32);
-    const bool p_auto = K >= 512 && N >= 256 && N <= 512 && N % 64 == 0 && M >= 8192 && !ep.gelu && !ep.dgelu_of;
-    if (p_ok && (use_p > 0 || (use_p == -2 && p_auto))) {
-        static int n_cu = 0;
-        if (n_cu == 0) { int dev = 0; hipGetDevice(&dev); hipDeviceProp_t pr; n_cu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
-        const int ntf = (use_p == 4 || use_p == 6) ? use_p : ((N % 192 == 0 || N > 768) && (N % 128 != 0 || N % 192 == 0) ? 6 : 4);
-        const int tbn = 32 * ntf;
-        const int tm = (M + 255) / 256, tn = (N + tbn - 1) / tbn, nt = tm * tn;
-        const int grid = nt < n_cu ? nt : n_cu;
-        const size_t lds = (size_t)2 * (256 + tbn) * 64 * sizeof(bf16_t) + (size_t)8 * 16 * (tbn / 2) * sizeof(float);
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)k_gemm_nt_p<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_gemm_nt_p<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done = true;
-            (void)hipGetLastError();
-        }
-#ifdef AP_STAMP
-        static unsigned long long* d_stamps = nullptr;
-        if (getenv("AP_GEMM_STAMPS")) {
-            if (!d_stamps) (void)hipMalloc((void**)&d_stamps, 8 * 16 * 8);
-            (void)hipMemset(d_stamps, 0, 8 * 16 * 8);
-            ep.stamps = d_stamps;
-        }
-#endif
-        if (ntf == 6) hipLaunchKernelGGL((k_gemm_nt_p<6>), dim3(grid), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
-        else hipLaunchKernelGGL((k_gemm_nt_p<4>), dim3(grid), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn, nt, ep);
-#ifdef AP_STAMP
-        if (ep.stamps) {
-            unsigned long long h[128];
-            (void)hipDeviceSynchronize();
-            (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
-            static int printed = 0;
-            if (printed++ == 3)
-                fprintf(stderr, "stamps: memtime %llu ticks, realtime %llu ticks (100 MHz) -> %.1f us, %.0f memtime ticks/us, %llu steps, %.0f ticks/step\n",
-                        h[0], h[1], h[1] / 100.0, h[0] / (h[1] / 100.0), h[2], (double)h[0] / (double)h[2]);
-        }
-#endif
-        return ap_check_launch();
-    }
-#endif  // AP_EXPERIMENTS
     // tile selection (measured on the VOLO-D1 shape list, tools/bench_gemm.py): AP_GEMM_NT_TILE forces a variant
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("AP_GEMM_NT_TILE"); forced = e ? atoi(e) : 0; }
@@ -1528,26 +941,6 @@ int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* 
     if ((lda & 7) || (ldb & 7) || lda < N1 || ldb < N2 || ldc < N2) return AP_ERR_SHAPE;
     const int t1 = (N1 + 127) / 128, t2 = (N2 + 127) / 128;
     int full_steps = 0;
-#if AP_EXPERIMENTS
-    static int tn_old = -1;
-    if (tn_old < 0) { const char* e = getenv("AP_GEMM_TN_RING"); tn_old = (e && e[0] == '1') ? 0 : 1; }   // ring variant lost to the multi-workgroup kernel
-    full_steps = tn_old ? 0 : M / TM;
-    if (full_steps > 0) {
-        // ring kernel over the full 64-token steps: ~1 workgroup per CU, >= 8 steps per workgroup
-        int splits = (256 + t1 * t2 - 1) / (t1 * t2);
-        if (splits > full_steps / 8) splits = full_steps / 8;
-        if (splits < 1) splits = 1;
-        const int sps = (full_steps + splits - 1) / splits;
-        splits = (full_steps + sps - 1) / sps;
-        const size_t lds = (size_t)4 * 2 * TM * 128 * sizeof(bf16_t);
-        static bool attr_done = false;
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)k_gemm_tn_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(k_gemm_tn_ring, dim3(t1, t2, splits), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, full_steps, N1, N2, sps, colsum_A);
-        const int rc = ap_check_launch();
-        if (rc != AP_OK) return rc;
-    }
-#endif
     const int done = full_steps * TM;
     if (done < M) {                                   // token tail (or everything when the ring is disabled)
         const int Mt = M - done;

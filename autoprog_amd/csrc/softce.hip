@@ -111,6 +111,78 @@ k_soft_ce(const bf16_t* __restrict__ logits, int ldx, const float* __restrict__ 
     }
 }
 
+// The same loss on the token-label target in its SOURCE form.  The reference builds the dense class-major [B,C,2+N] tensor from
+// top-K (class, score) label maps plus label smoothing on the GPU every step (main_prog.py:994-1004, tlt create_token_label_target)
+// and the dense kernel above then reads 4 B per (row, class) of it -- 101 MB at B = 128.  Here a row's target is
+//     t[c] = (1 - s) * sum_k [idx_k == c] * val_k + s / C
+// formed in registers from its K pairs: logits in, dlogits out, nothing else.  One wave per row, a lane owns class pairs
+// 2 (lane + 64 i).  Pairs of row r = (b, n), b = r / rows_per_batch, sit at pairs + b * p_sb + n * p_sn (K entries each).
+#define CE_MAXK 16
+__global__ void __launch_bounds__(256)
+k_soft_ce_sparse(const bf16_t* __restrict__ logits, int ldx, const int* __restrict__ idx, const float* __restrict__ val, int K,
+                 int64_t p_sb, int64_t p_sn, int rows_per_batch, float smoothing, float* __restrict__ row_loss,
+                 bf16_t* __restrict__ dlogits, float gscale, int64_t M, int C) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const bf16_t* xr = logits + row * ldx;
+    unsigned lraw[CE_MAXV];
+#pragma unroll
+    for (int i = 0; i < CE_MAXV; ++i) lraw[i] = *reinterpret_cast<const unsigned*>(xr + min(2 * (lane + 64 * i), ldx - 2));
+    const int64_t b = row / rows_per_batch, n = row - b * rows_per_batch;
+    const int64_t po = b * p_sb + n * p_sn;
+    // the row's pairs: lane k holds pair k, every lane reads them by shuffle
+    const int my_i = lane < K ? idx[po + lane] : -1;
+    const float my_v = lane < K ? val[po + lane] * (1.0f - smoothing) : 0.f;
+    const float base = smoothing / (float)C;
+    float xv[CE_MAXV][2], tv[CE_MAXV][2];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < CE_MAXV; ++i) {
+        const int c = 2 * (lane + 64 * i);
+        xv[i][0] = c < C ? bf_lo(lraw[i]) : -3.0e38f;
+        xv[i][1] = c + 1 < C ? bf_hi(lraw[i]) : -3.0e38f;
+        tv[i][0] = c < C ? base : 0.f;
+        tv[i][1] = c + 1 < C ? base : 0.f;
+        mx = fmaxf(mx, fmaxf(xv[i][0], xv[i][1]));
+    }
+    for (int k = 0; k < K; ++k) {
+        const int ci = __shfl(my_i, k, 64);
+        const float cv = __shfl(my_v, k, 64);
+        const int owner = (ci >> 1) & 63, slot = ci >> 7;          // class ci = 2 * (owner + 64 * slot) + (ci & 1)
+        if (ci >= 0 && ci < C && lane == owner) {
+#pragma unroll
+            for (int i = 0; i < CE_MAXV; ++i) if (i == slot) tv[i][ci & 1] += cv;
+        }
+    }
+    mx = group_max<64>(mx);
+    float se = 0.f, st = 0.f, stx = 0.f;
+#pragma unroll
+    for (int i = 0; i < CE_MAXV; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (2 * (lane + 64 * i) + k < C) {
+                se += __expf(xv[i][k] - mx);
+                st += tv[i][k];
+                stx += tv[i][k] * xv[i][k];
+            }
+        }
+    se = group_sum<64>(se); st = group_sum<64>(st); stx = group_sum<64>(stx);
+    const float lse = mx + __logf(se);
+    if (lane == 0) row_loss[row] = lse * st - stx;
+    bf16_t* dr = dlogits + row * ldx;
+#pragma unroll
+    for (int i = 0; i < CE_MAXV; ++i) {
+        const int c = 2 * (lane + 64 * i);
+        if (c < ldx) {
+            float d0 = 0.f, d1 = 0.f;
+            if (c < C) d0 = gscale * (__expf(xv[i][0] - lse) * st - tv[i][0]);
+            if (c + 1 < C) d1 = gscale * (__expf(xv[i][1] - lse) * st - tv[i][1]);
+            *reinterpret_cast<unsigned*>(dr + c) = pack_bf2(d0, d1);
+        }
+    }
+}
+
 // loss = wa * sum(a[0:na]) + wb * sum(b[0:nb]) in one workgroup (the two CE terms of the token-label loss, loss/cross_entropy.py:154-156)
 __global__ void __launch_bounds__(1024)
 k_loss_combine(const float* __restrict__ a, int64_t na, float wa, const float* __restrict__ b, int64_t nb, float wb, float* __restrict__ out) {
@@ -151,5 +223,18 @@ extern "C" int ap_soft_ce_fwd_bwd(const ap_bf16* logits, int ldx, const float* t
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_soft_ce, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, logits, ldx, target, t_sb, t_sc,
                        t_sn, rows_per_batch, row_loss, dlogits, grad_scale, M, C, tiles, mix_lam, mix_batches);
+    return ap_check_launch();
+}
+
+extern "C" int ap_soft_ce_sparse_fwd_bwd(const ap_bf16* logits, int ldx, const int* idx, const float* val, int K, int64_t p_sb, int64_t p_sn,
+                                         int rows_per_batch, float smoothing, float* row_loss, ap_bf16* dlogits, float grad_scale,
+                                         int64_t M, int C, ap_stream_t stream) {
+    if (!logits || !idx || !val || !row_loss || !dlogits) return AP_ERR_NULL;
+    if (C <= 0 || ldx < C || (ldx & 7) || rows_per_batch <= 0 || M < 0 || K <= 0 || K > CE_MAXK || smoothing < 0.f || smoothing >= 1.f) return AP_ERR_SHAPE;
+    if (ldx > 64 * 2 * CE_MAXV) return AP_ERR_UNSUPPORTED;
+    if (M == 0) return AP_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_soft_ce_sparse, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const bf16_t*>(logits), ldx,
+                       idx, val, K, p_sb, p_sn, rows_per_batch, smoothing, row_loss, reinterpret_cast<bf16_t*>(dlogits), grad_scale, M, C);
     return ap_check_launch();
 }

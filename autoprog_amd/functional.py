@@ -577,6 +577,49 @@ class TokenLabelCEFn(torch.autograd.Function):
         return dc, da.reshape(B, N, C), None, None, None, None
 
 
+class SparseTokenLabelCEFn(torch.autograd.Function):
+    """TokenLabelCrossEntropy on the token-label target in its SOURCE form -- top-K (class, score) pairs per slot [B, 2+N, K] and a
+    label-smoothing strength -- instead of the dense [B,C,2+N] tensor the reference builds from them on the GPU every step
+    (main_prog.py:994-1004; loss/cross_entropy.py:136-156 for the loss itself).  Same three launches as TokenLabelCEFn; the
+    mix-token class target lam * t[b] + (1 - lam) * t[B-1-b] is 2K pairs per image (a [B, 2K] concatenation, built here)."""
+
+    @staticmethod
+    def forward(ctx, x_cls, x_aux, idx, val, smoothing, lam, cls_weight, dense_weight):
+        B, N, C = x_aux.shape
+        K = idx.shape[-1]
+        ld = ops.round_up(C, 8)
+
+        def padded(x2d):
+            if ld == C and x2d.is_contiguous():
+                return x2d
+            xp = torch.zeros((x2d.shape[0], ld), dtype=BF16, device=x2d.device)
+            xp[:, :C] = x2d
+            return xp
+        idx, val = idx.contiguous(), val.contiguous()
+        rl_aux, d_aux = ops.soft_ce_sparse_fwd_bwd(padded(x_aux.reshape(B * N, C)), C, idx[:, 2:], val[:, 2:], (2 + N) * K, K, N, smoothing,
+                                                   dense_weight / (B * N))
+        if lam < 1:
+            ci = torch.cat([idx[:, 1], idx[:, 1].flip(0)], dim=1).contiguous()
+            cv = torch.cat([val[:, 1] * lam, val[:, 1].flip(0) * (1.0 - lam)], dim=1).contiguous()
+        else:
+            ci, cv = idx[:, 1].contiguous(), val[:, 1].contiguous()
+        rl_cls, d_cls = ops.soft_ce_sparse_fwd_bwd(padded(x_cls.reshape(B, C)), C, ci, cv, ci.shape[1], 0, 1, smoothing, cls_weight / B)
+        ctx.save_for_backward(d_cls, d_aux)
+        ctx.dims = (B, N, C)
+        return ops.loss_combine(rl_cls, cls_weight / B, rl_aux, dense_weight / (B * N))
+
+    @staticmethod
+    def backward(ctx, g):
+        d_cls, d_aux = ctx.saved_tensors
+        B, N, C = ctx.dims
+        gs = g.reshape(1).float().contiguous()
+        dc = ops.row_scale(d_cls, gs, d_cls.shape[0])
+        da = ops.row_scale(d_aux, gs, d_aux.shape[0])
+        dc = dc if dc.shape[1] == C else dc[:, :C]
+        da = da if da.shape[1] == C else da[:, :C]
+        return dc, da.reshape(B, N, C), None, None, None, None, None, None
+
+
 class OutlookCoreFn(torch.autograd.Function):
     """unfold -> softmax -> attn@v -> fold (models/volo.py:83-98) on v [B,H,W,C], logits [B*h*w, ld]."""
 

@@ -1,2 +1,2 @@
 from .cross_entropy import (SoftTargetCrossEntropy, TokenLabelGTCrossEntropy,  # noqa: F401
-                            TokenLabelSoftTargetCrossEntropy, TokenLabelCrossEntropy)
+                            TokenLabelSoftTargetCrossEntropy, TokenLabelCrossEntropy, SparseTokenLabelTarget)

@@ -60,6 +60,12 @@ class _TokenLabelBase(nn.Module):
         output, aux_output, bb = x
         bbx1, bby1, bbx2, bby2 = bb
         B, N, C = aux_output.shape
+        if isinstance(target, SparseTokenLabelTarget):
+            if type(self)._adjust_cls is _TokenLabelBase._adjust_cls and target.idx.is_cuda and target.idx.shape[1] == 2 + N:
+                lam = 1 - ((bbx2 - bbx1) * (bby2 - bby1) / N)
+                return AF.SparseTokenLabelCEFn.apply(output.to(torch.bfloat16), aux_output.to(torch.bfloat16), target.idx, target.val,
+                                                     target.smoothing, float(lam), float(self.cls_weight), float(self.dense_weight))
+            target = target.dense(C)
         target = target.float()
         if target.dim() == 3 and type(self)._adjust_cls is _TokenLabelBase._adjust_cls and target.is_cuda:
             # the production case (TokenLabelCrossEntropy with token labels): three launches, see functional.TokenLabelCEFn
@@ -84,6 +90,23 @@ class _TokenLabelBase(nn.Module):
 
 class TokenLabelCrossEntropy(_TokenLabelBase):
     """reference TokenLabelCrossEntropy (loss/cross_entropy.py:112-156)"""
+
+
+class SparseTokenLabelTarget:
+    """The token-label target before it is densified: `idx` int32 and `val` fp32, both [B, 2 + N, K] (slot 0 ground truth, slot 1
+    image level, slots 2.. tokens: SURVEY.md appendix A.2), and the label-smoothing strength.  dense() is what the reference's
+    create_token_label_target hands to its loss: [B, C, 2 + N] with t = (1 - s) * scatter(val) + s / C."""
+
+    def __init__(self, idx, val, smoothing=0.1):
+        if idx.shape != val.shape or idx.dim() != 3:
+            raise ValueError("SparseTokenLabelTarget: idx and val must both be [B, 2 + N, K]")
+        self.idx, self.val, self.smoothing = idx.to(torch.int32), val.float(), float(smoothing)
+
+    def dense(self, classes):
+        B, S, K = self.idx.shape
+        t = torch.zeros(B, classes, S, dtype=torch.float32, device=self.val.device)
+        t.scatter_add_(1, self.idx.long().permute(0, 2, 1), self.val.permute(0, 2, 1))
+        return t * (1.0 - self.smoothing) + self.smoothing / classes
 
 
 class TokenLabelGTCrossEntropy(_TokenLabelBase):

@@ -419,6 +419,21 @@ def soft_ce_fwd_bwd(logits, C, target, t_sb, t_sc, t_sn, rows_per_batch, grad_sc
     return row_loss, dlogits
 
 
+def soft_ce_sparse_fwd_bwd(logits, C, idx, val, p_sb, p_sn, rows_per_batch, smoothing, grad_scale):
+    """soft-target CE against top-K (class, score) pairs + label smoothing (the token-label target before it is densified);
+    idx int32 / val fp32 with K = idx.shape[-1] pairs per row at b * p_sb + n * p_sn.  Returns (row_loss fp32 [M], dlogits bf16)."""
+    _req(logits, BF16, "logits")
+    if not (idx.is_cuda and idx.dtype == torch.int32 and val.is_cuda and val.dtype == torch.float32):
+        raise AutoProgHipError("sparse targets: idx must be CUDA int32 and val CUDA fp32")
+    M, ldx = logits.shape
+    row_loss = torch.empty(M, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    check(lib.ap_soft_ce_sparse_fwd_bwd(logits.data_ptr(), ldx, idx.data_ptr(), val.data_ptr(), int(idx.shape[-1]), int(p_sb), int(p_sn),
+                                        int(rows_per_batch), float(smoothing), row_loss.data_ptr(), dlogits.data_ptr(), float(grad_scale), M, C, _stream()),
+          "ap_soft_ce_sparse_fwd_bwd")
+    return row_loss, dlogits
+
+
 def row_scale(x, scale, rows_per_scale):
     _req(x, BF16, "x"); _req(scale, torch.float32, "scale")
     C = x.shape[-1]

@@ -59,13 +59,17 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-def make_target(B, C, N, device, gen):
-    """token-label style soft targets [B,C,2+N]: top-5 sparse labels mixed with smoothing 0.1
-    (SURVEY.md section 8(d) row M2)."""
-    t = torch.zeros(B, C, 2 + N)
+def make_target(B, C, N, device, gen, sparse=False):
+    """token-label style soft targets: top-5 (class, score) label maps per slot with label smoothing 0.1 (SURVEY.md section 8(d) row
+    M2).  sparse=False: the dense fp32 [B,C,2+N] tensor the reference builds from them on the GPU every step (main_prog.py:994-1004);
+    sparse=True: the label maps themselves ([B,2+N,5] indices and scores) -- the loss kernel forms the target rows in registers."""
     idx = torch.randint(0, C, (B, 5, 2 + N), generator=gen)
     val = torch.rand(B, 5, 2 + N, generator=gen)
     val = val / val.sum(1, keepdim=True)
+    if sparse:
+        from autoprog_amd.loss import SparseTokenLabelTarget
+        return SparseTokenLabelTarget(idx.permute(0, 2, 1).contiguous().to(device), val.permute(0, 2, 1).contiguous().to(device), smoothing=0.1)
+    t = torch.zeros(B, C, 2 + N)
     t.scatter_(1, idx, val)
     t = t * 0.9 + 0.1 / C
     return t.to(device)
@@ -224,6 +228,9 @@ def main():
     ap.add_argument("--workload", default="d1", choices=["d1", "stages", "d5", "deit_base"],
                     help="d5: BASELINE configs[4] in bf16 -- VOLO-D5 at 448 px (use --batch 8..16); not the default line")
     ap.add_argument("--search-mix", action="store_true", help="stages workload: uniform random (l, r) per step (supernet search)")
+    ap.add_argument("--dense-target", action="store_true",
+                    help="feed the token-label target as the dense fp32 [B,1000,2+N] tensor (default: the top-5 label maps it is built from; the CE "
+                         "kernel forms the same target rows in registers, main_prog.py:994-1004 folded into the loss)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-roofline", action="store_true")
@@ -311,7 +318,7 @@ def main():
                 opt.step()
             return loss
     elif args.workload == "stages":
-        targets = {r: make_target(B, 1000, (r // 16) ** 2, dev, gen) for _, r, _ in STAGES}
+        targets = {r: make_target(B, 1000, (r // 16) ** 2, dev, gen, sparse=not args.dense_target) for _, r, _ in STAGES}
         l_list, r_list = [s[0] for s in STAGES], [s[1] for s in STAGES]
         random.seed(0)                 # identical (l, r) sequence on every rank (reference: random.seed(epoch), main_prog.py:1861)
         counter = [0]
@@ -335,7 +342,7 @@ def main():
         images_per_step = B
     else:
         n_tok = (res // 16) ** 2
-        target = make_target(B, 1000, n_tok, dev, gen)
+        target = make_target(B, 1000, n_tok, dev, gen, sparse=not args.dense_target)
 
         def step():
             reducer.zero_grad()
@@ -471,6 +478,9 @@ def main():
                 "config": {"workload": wl,
                            "model": args.variant, "global_batch": B * world, "per_gpu_batch": B, "res": res, "parallelism": "dp%d" % world,
                            "step": "fwd+loss+bwd" + ("" if args.no_optimizer else "+AdamW+4xEMA") + ("+RCCL grad all-reduce" if world > 1 else ""),
+                           "target": ("soft-target [B,1000]" if args.workload == "deit_base" else
+                                      "dense fp32 [B,1000,2+N]" if args.dense_target else
+                                      "top-5 label maps [B,2+N,5] + smoothing 0.1, densified inside the CE kernel (== the dense tensor of main_prog.py:994-1004)"),
                            "final_loss": round(final_loss, 4),
                            "fwd_loss_bwd_only_ms_per_step": None if fwd_bwd_ms is None else round(fwd_bwd_ms, 3)},
                 "roofline": roofline, "cpu_baseline": cpu}

@@ -89,3 +89,35 @@ def test_token_label_gt_full_class_count():
     lo.backward()
     assert abs(float(loss.detach()) - float(lo.detach())) < 5e-4
     assert rel(cg.grad, cr.grad) < 6e-3 and rel(ag.grad, ar.grad) < 6e-3
+
+
+def test_sparse_token_label_ce_equals_dense_on_the_densified_target():
+    """ap_soft_ce_sparse_fwd_bwd / SparseTokenLabelCEFn (the token-label target construction of
+    main_prog.py:994-1004 folded into the CE kernel): the loss on top-5 (class, score) pairs + label smoothing equals the dense
+    kernel on the densified [B,C,2+N] target -- loss to 1e-6 relative, both logit gradients to bf16 rounding -- with and without
+    the mix-token box (lam < 1), with repeated indices in a slot, at 1000 classes; and equals the oracle's token_label_ce."""
+    from autoprog_amd.loss import TokenLabelCrossEntropy, SparseTokenLabelTarget
+    B, N, C, K = 6, 49, 1000, 5
+    g = torch.Generator().manual_seed(7)
+    idx = torch.randint(0, C, (B, 2 + N, K), generator=g)
+    idx[0, 3, 1] = idx[0, 3, 0]                       # a repeated class inside one slot accumulates
+    val = torch.rand(B, 2 + N, K, generator=g)
+    val = val / val.sum(-1, keepdim=True)
+    sp = SparseTokenLabelTarget(idx.cuda(), val.cuda(), smoothing=0.1)
+    dense = sp.dense(C)
+    assert dense.shape == (B, C, 2 + N) and abs(float(dense.sum(1).mean()) - 1.0) < 1e-5
+    x_cls = (torch.randn(B, C, generator=g) * 2).cuda().to(torch.bfloat16)
+    x_aux = (torch.randn(B, N, C, generator=g) * 2).cuda().to(torch.bfloat16)
+    loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=C)
+    for bb in ((0, 0, 0, 0), (1, 2, 5, 6)):
+        outs = []
+        for tgt in (dense, sp):
+            xc, xa = x_cls.clone().requires_grad_(True), x_aux.clone().requires_grad_(True)
+            loss = loss_fn((xc, xa, bb), tgt)
+            loss.backward()
+            outs.append((float(loss.detach()), xc.grad.float().cpu(), xa.grad.float().cpu()))
+        (l0, gc0, ga0), (l1, gc1, ga1) = outs
+        assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
+        assert float((gc0 - gc1).norm() / gc0.norm()) < 2e-3 and float((ga0 - ga1).norm() / ga0.norm()) < 2e-3
+        ref = R.token_label_ce((x_cls.double().cpu(), x_aux.double().cpu(), bb), dense.double().cpu(), 0.5, 1.0)
+        assert abs(l1 - float(ref)) < 2e-5 * abs(float(ref)), (l1, float(ref))

@@ -282,3 +282,36 @@ def test_loss_curve_realistic_init_ten_adamw_steps():
             for name, gn in zip(d["g0_norms_names"], d["g0_norms"]):
                 assert abs(float(train[str(name)].grad.norm()) - float(gn)) <= 1e-9 * float(gn) + 1e-15, name
         opt.step()
+
+
+def test_vit_block_against_an_independent_statement():
+    """DeiT rows D2 / D3: timm 0.4.5 is not under /root/reference, so the oracle's ViT block (oracle/ref_cpu.py vit_block) cannot be
+    pinned against reference vectors.  Second, independent statement of the same pre-LN block: torch.nn.MultiheadAttention (packed
+    in_proj = qkv, out_proj = proj -- torch's own attention code path, none of the oracle's) + nn.LayerNorm + nn.Linear / exact-erf
+    nn.GELU, in fp64, wired x + attn(LN1 x), x + mlp(LN2 x) as timm's Block.forward.  Outputs and all gradients agree to 1e-10."""
+    torch.manual_seed(0)
+    B, N, C, heads, hidden = 3, 17, 48, 3, 192
+    mha = torch.nn.MultiheadAttention(C, heads, bias=True, batch_first=True).double()
+    ln1, ln2 = torch.nn.LayerNorm(C, eps=1e-6).double(), torch.nn.LayerNorm(C, eps=1e-6).double()
+    fc1, fc2, act = torch.nn.Linear(C, hidden).double(), torch.nn.Linear(hidden, C).double(), torch.nn.GELU()
+    for m in (mha, ln1, ln2, fc1, fc2):
+        for q in m.parameters():
+            torch.nn.init.normal_(q, std=0.3)
+    x = torch.randn(B, N, C, dtype=torch.float64, requires_grad=True)
+    h = ln1(x)
+    y1 = x + mha(h, h, h, need_weights=False)[0]
+    y = y1 + fc2(act(fc1(ln2(y1))))
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    p = {"b.norm1.weight": ln1.weight, "b.norm1.bias": ln1.bias, "b.norm2.weight": ln2.weight, "b.norm2.bias": ln2.bias,
+         "b.attn.qkv.weight": mha.in_proj_weight, "b.attn.qkv.bias": mha.in_proj_bias,
+         "b.attn.proj.weight": mha.out_proj.weight, "b.attn.proj.bias": mha.out_proj.bias,
+         "b.mlp.fc1.weight": fc1.weight, "b.mlp.fc1.bias": fc1.bias, "b.mlp.fc2.weight": fc2.weight, "b.mlp.fc2.bias": fc2.bias}
+    po = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    xo = x.detach().clone().requires_grad_(True)
+    yo = R.vit_block(xo, po, "b.", heads, eps=1e-6)
+    yo.backward(dy)
+    assert rel_err(yo, y.detach()) < 1e-10
+    assert rel_err(xo.grad, x.grad) < 1e-10
+    for k in p:
+        assert rel_err(po[k].grad, p[k].grad) < 1e-10, k

@@ -9,7 +9,7 @@
 #include <vector>
 #include <functional>
 #include <algorithm>
-#include "../../autoprog_amd/csrc/gemm_dma.h"
+#include "rejected/gemm_dma.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 

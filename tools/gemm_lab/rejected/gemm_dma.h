@@ -13,7 +13,7 @@
 // (wave-uniform base + lane * 16 B), so the bank swizzle (16-byte chunk index ^ key(row)) is applied to the per-lane
 // SOURCE address and again on the fragment reads.
 #pragma once
-#include "gemm_epi.h"
+#include "../../../autoprog_amd/csrc/gemm_epi.h"
 
 #ifndef AP_DMA_ABL
 #define AP_DMA_ABL 0      // timing-only ablation builds (tools/gemm_lab): 2 = no fragment reads / MFMAs, 4 = no DMA
