@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("AP_LIB_PATH") or os.path.join(_HERE, "libautoprog_hip
 
 class GemmEpilogue(Structure):
     _fields_ = [("bias", c_void_p), ("gelu", c_int), ("preact_out", c_void_p), ("dgelu_of", c_void_p),
-                ("row_scale", c_void_p), ("rows_per_scale", c_int), ("residual", c_void_p), ("ldr", c_int)]
+                ("row_scale", c_void_p), ("rows_per_scale", c_int), ("residual", c_void_p), ("ldr", c_int), ("mul_by", c_void_p)]
 
 
 class TnProblem(Structure):

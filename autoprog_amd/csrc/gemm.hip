@@ -126,13 +126,14 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
     // the epilogue (384x384 + residual: 32.7 us against 19.6 us plain before this, for 19 MB more traffic).  Full tiles only.
     constexpr int NPRE = TM * TN / 8 / NTH;
     constexpr int CPR_E = TN / 8;
-    const bf16_t* esrc = ep.dgelu_of ? ep.dgelu_of : ep.residual;
-    const int elds = ep.dgelu_of ? ldc : ep.ldr;
+    const bf16_t* emul = ep.dgelu_of ? ep.dgelu_of : ep.mul_by;          // the factor tile (gelu' input or stored derivative), else the residual
+    const bf16_t* esrc = emul ? emul : ep.residual;
+    const int elds = emul ? ldc : ep.ldr;
     // (the staged epilogue's (pass, iteration) -> chunk map is the row-major one only when a pass is a whole number of thread sweeps)
     // The chunks live in the staging registers themselves (chunk c in ra0[c] / rb0[c - NA]): no register beyond the main loop's.
     constexpr bool PFOK = PRE && !DEPI && PF == 1 && (NPRE <= NA + NB) && ((EROWS * (TN / 8)) % NTH == 0) && (TM % EROWS == 0) && (NTH % (TN / 8) == 0);
     static_assert(PFOK || !PRE, "PRE is instantiated only for tiles whose staged epilogue sweeps whole rows of chunks");
-    const bool pf = PFOK && esrc != nullptr && (ep.dgelu_of == nullptr || ep.residual == nullptr) && (ldc & 7) == 0 && (elds & 7) == 0 &&
+    const bool pf = PFOK && esrc != nullptr && (emul == nullptr || ep.residual == nullptr) && (ldc & 7) == 0 && (elds & 7) == 0 &&
                     m0 + TM <= M && n0 + TN <= N && !(ep.dbg & 2);
     auto pre = [&](int c) -> u32x4& { return c < NA ? ra0[c < NA ? c : 0] : rb0[c >= NA && c < NA + NB ? c - NA : 0]; };
     // addresses = one uniform tile base (+ a uniform per-chunk step) + ONE 32-bit per-thread offset: a single VGPR across the main loop
@@ -749,6 +750,8 @@ static void g8_pick(const G8Args& ga, const EpiArgs& ep, int grid, hipStream_t s
         case G8_BIAS | G8_GELU | G8_RS: g8_go<NT1, G8_BIAS | G8_GELU | G8_RS>(ga, ep, grid, st); break;
         case G8_DGELU: g8_go<NT1, G8_DGELU>(ga, ep, grid, st); break;
         case G8_DGELU | G8_RS: g8_go<NT1, G8_DGELU | G8_RS>(ga, ep, grid, st); break;
+        case G8_MUL: g8_go<NT1, G8_MUL>(ga, ep, grid, st); break;
+        case G8_MUL | G8_RS: g8_go<NT1, G8_MUL | G8_RS>(ga, ep, grid, st); break;
         case G8_BIAS | G8_RES: g8_go<NT1, G8_BIAS | G8_RES>(ga, ep, grid, st); break;
         case G8_BIAS | G8_RS | G8_RES: g8_go<NT1, G8_BIAS | G8_RS | G8_RES>(ga, ep, grid, st); break;
         default: g8_go<NT1, -1>(ga, ep, grid, st); break;
@@ -779,6 +782,7 @@ static int use_8p(int M, int N, int K, int ldc, const EpiArgs& ep) {          //
     if (mode < 0) { const char* e = getenv("AP_GEMM_8P"); mode = e ? atoi(e) : 1; }
     if (mode == 0 || (K & 63) || K < 128 || M < 4096 || (N & 7) || (ldc & 7) || (ep.residual && (ep.ldr & 7))) return 0;
     if (ep.dgelu_of && (mode < 2 || ep.residual)) return 0;
+    if (ep.mul_by && ep.residual) return 0;
     const int bn = N >= 1024 ? 256 : (N % 192 == 0 ? 192 : (N % 256 == 0 ? 256 : 0));
     return N < 192 ? 0 : bn;
 }
@@ -790,13 +794,15 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     if (!A || !B || !C) return AP_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0) return AP_ERR_SHAPE;
     if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N) return AP_ERR_SHAPE;
-    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}, nullptr, nullptr};
+    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}, nullptr, nullptr, nullptr};
     { const char* e = getenv("AP_GEMM_DBG"); if (e) ep.dbg = atoi(e); }
     if (epi) {
-        ep.bias = epi->bias; ep.gelu = epi->gelu; ep.preact = epi->preact_out; ep.dgelu_of = epi->dgelu_of;
+        ep.bias = epi->bias; ep.gelu = epi->gelu; ep.preact = epi->preact_out; ep.dgelu_of = epi->dgelu_of; ep.mul_by = epi->mul_by;
         ep.row_scale = epi->row_scale; ep.rows_per_scale = epi->rows_per_scale > 0 ? epi->rows_per_scale : 1;
         ep.residual = epi->residual; ep.ldr = epi->ldr;
         if (ep.residual && ep.ldr < N) return AP_ERR_SHAPE;
+        if (ep.mul_by && ep.dgelu_of) return AP_ERR_SHAPE;
+        if (ep.gelu < 0 || ep.gelu > 2 || (ep.gelu == 2 && !ep.preact)) return AP_ERR_SHAPE;
     }
     (void)hipGetLastError();
     static int skinny = -1;
@@ -875,7 +881,7 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         case 10: NT_LAUNCH(128, 192, 2, 2) break;
         case 11: NT_LAUNCH(64, 192, 2, 2) break;
         default:
-            if (lds_epi && (ep.residual != nullptr) != (ep.dgelu_of != nullptr) && !(ep.dbg & 2)) {    // epilogue reads ONE more tile: prefetching instantiation
+            if (lds_epi && (ep.residual != nullptr) != (ep.dgelu_of != nullptr || ep.mul_by != nullptr) && !(ep.dbg & 2)) {    // epilogue reads ONE more tile: prefetching instantiation
                 const int tm_ = (M + 127) / 128, tn_ = (N + 127) / 128, nt_ = tm_ * tn_;
                 hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, false, 1, true>), dim3(nt_), dim3(256), 0, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, tn_, nt_, ep);
             } else NT_LAUNCH(128, 128, 2, 2)
@@ -890,7 +896,7 @@ int ap_gemm_nt_fp8(const unsigned char* A, int lda, const unsigned char* B, int 
     if (!A || !B || !C || !dq_a || !dq_b) return AP_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0) return AP_ERR_SHAPE;
     if ((K & 15) || (lda & 15) || (ldb & 15) || lda < K || ldb < K || ldc < N) return AP_ERR_SHAPE;       // 16-byte chunks of e4m3
-    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}, dq_a, dq_b};
+    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}, dq_a, dq_b, nullptr};
     if (epi) {
         ep.bias = epi->bias; ep.gelu = epi->gelu; ep.preact = epi->preact_out; ep.dgelu_of = epi->dgelu_of;
         ep.row_scale = epi->row_scale; ep.rows_per_scale = epi->rows_per_scale > 0 ? epi->rows_per_scale : 1;
@@ -917,7 +923,7 @@ int ap_gemm_nt_patch(const ap_bf16* A, const ap_bf16* B, int ldb, ap_bf16* C, in
                      const float* bias, const ap_patch_map* map, int side, ap_stream_t stream) {
     if (!A || !B || !C || !map) return AP_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (ldb & 7) || ldb < K) return AP_ERR_SHAPE;
-    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}, nullptr, nullptr};
+    EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}, nullptr, nullptr, nullptr};
     if (!patch_map_device(map, ep.pm)) return AP_ERR_SHAPE;
     if ((int64_t)M >= (int64_t)(0xFFFFFFFFu / (unsigned)map->group)) return AP_ERR_SHAPE;       // exactness bound of the magic division
     (void)hipGetLastError();

@@ -125,9 +125,10 @@ __device__ __forceinline__ void g8_epi(float* v, int m, int n, int ldc, const Ep
 // epilogue flavour of an instantiation (EF >= 0: bits known at compile time; EF < 0: read from the arguments at run time).  The
 // generic epilogue is ~25 KB of code that a CU runs once or twice per launch, cold: an instantiation per flavour of the training
 // step keeps what is fetched to what is used (2.8 us -> see DESIGN.md on the 25088 x 384 x 1152 launch).
-enum { G8_BIAS = 1, G8_GELU = 2, G8_DGELU = 4, G8_RS = 8, G8_RES = 16 };
+enum { G8_BIAS = 1, G8_GELU = 2, G8_DGELU = 4, G8_RS = 8, G8_RES = 16, G8_MUL = 32 };
 __host__ __device__ inline int g8_flavour(const EpiArgs& ep) {
-    return (ep.bias ? G8_BIAS : 0) | (ep.gelu ? G8_GELU : 0) | (ep.dgelu_of ? G8_DGELU : 0) | (ep.row_scale ? G8_RS : 0) | (ep.residual ? G8_RES : 0);
+    return (ep.bias ? G8_BIAS : 0) | (ep.gelu ? G8_GELU : 0) | (ep.dgelu_of ? G8_DGELU : 0) | (ep.row_scale ? G8_RS : 0) | (ep.residual ? G8_RES : 0) |
+           (ep.mul_by ? G8_MUL : 0);
 }
 
 // NT1: B part 1 holds NT1 16-column tiles per wave (1: 256 x 192 block tile, 2: 256 x 256).
@@ -138,6 +139,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     const bool has_dgelu = EF < 0 ? ep.dgelu_of != nullptr : (EF & G8_DGELU) != 0;
     const bool has_rs = EF < 0 ? ep.row_scale != nullptr : (EF & G8_RS) != 0;
     const bool has_res = EF < 0 ? ep.residual != nullptr : (EF & G8_RES) != 0;
+    const bool has_mul = EF < 0 ? ep.mul_by != nullptr : (EF & G8_MUL) != 0;
     constexpr int WN = 32 + 16 * NT1, BN = 4 * WN;
     constexpr int VMN = 4 + NT1;                 // DMA instructions of the three parts in flight behind a counted wait
     constexpr int KS = 49152 + 8192 * NT1;       // bytes of a K-tile buffer (A h0 | A h1 | B part 0 | B part 1); the two buffers are adjacent
@@ -419,8 +421,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
             // ds_write_b128 then hit 8 different bank quads, and a DMA / row read still covers whole 128-byte lines.
             unsigned char* const stg = g8_smem + STG + wr * GRP;
             const unsigned stg_a = g8_lds_addr(stg);
-            const bf16_t* const in_src = has_dgelu ? ep.dgelu_of : (has_res ? ep.residual : nullptr);
-            const int in_ld = has_dgelu ? ga.ldc : ep.ldr;
+            const bf16_t* const in_src = has_dgelu ? ep.dgelu_of : has_mul ? ep.mul_by : (has_res ? ep.residual : nullptr);
+            const int in_ld = (has_dgelu || has_mul) ? ga.ldc : ep.ldr;
             const bool rowgelu = has_gelu;                        // GELU (and what follows it) is applied in the row phase
             constexpr int CPR = BN / 8;                               // 16-byte chunks per staged row
             constexpr int NIT = 16 * PASS_MT * CPR / 256;             // chunks per lane and pass (6 / 4)
@@ -447,7 +449,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
             constexpr bool ASM_IN = EF >= 0 && !(NT1 == 2 && EF == (G8_BIAS | G8_RS | G8_RES));
             u32x4 in0[2][4];
             in1_t in1[2][4];
-            if (has_dgelu || has_res) {
+            if (has_dgelu || has_mul || has_res) {
                 const bf16_t* ibase = in_src + min(nb + g * 8, ga.N - 8);
                 const bf16_t* ibase1 = in_src + min(nb + 32 + g * 4 * NT1, ga.N - 4 * NT1);
 #pragma unroll
@@ -503,13 +505,19 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
 #pragma unroll
                             for (int q = 0; q < 2 * NT1; ++q) { w[2 * q] *= gelu_erf_grad(bf_lo(i1[q])); w[2 * q + 1] *= gelu_erf_grad(bf_hi(i1[q])); }
                         }
+                        if (has_mul) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { v[2 * q] *= bf_lo(i0[q]); v[2 * q + 1] *= bf_hi(i0[q]); }
+#pragma unroll
+                            for (int q = 0; q < 2 * NT1; ++q) { w[2 * q] *= bf_lo(i1[q]); w[2 * q + 1] *= bf_hi(i1[q]); }
+                        }
                         if (has_rs) {
 #pragma unroll
                             for (int q = 0; q < 8; ++q) v[q] *= rs;
 #pragma unroll
                             for (int q = 0; q < 4 * NT1; ++q) w[q] *= rs;
                         }
-                        if (has_res && !has_dgelu) {
+                        if (has_res && !has_dgelu && !has_mul) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) { v[2 * q] += bf_lo(i0[q]); v[2 * q + 1] += bf_hi(i0[q]); }
 #pragma unroll
@@ -543,13 +551,25 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                     u32x4 x = xs[it];
                     if (m < ga.M && n < ga.N) {
                         if (rowgelu) {
-                            // x = the bf16-rounded pre-activation (bias included): stored as it is, the activation applied to the rounded value
-                            if (ep.preact) st16(ep.preact + (int64_t)m * ga.ldc + n, x);
+                            // x = the bf16-rounded pre-activation (bias included): the activation is applied to the rounded value; what is stored
+                            // beside the output is x itself, or (gelu = 2) its activation derivative -- all the backward needs of it
                             float f[8];
                             unpack8(x, f);
                             const float rs = has_rs ? ep.row_scale[m / ep.rows_per_scale] : 1.f;
+                            if (ep.gelu == 2) {
+                                float gp[8];
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) f[q] = gelu_erf(f[q]) * rs;
+                                for (int q = 0; q < 8; ++q) {
+                                    float c, e; gelu_parts(f[q], c, e);
+                                    gp[q] = fmaf(f[q] * 0.39894228040143268f, e, c);
+                                    f[q] = f[q] * c * rs;
+                                }
+                                st16(ep.preact + (int64_t)m * ga.ldc + n, pack8(gp));
+                            } else {
+                                if (ep.preact) st16(ep.preact + (int64_t)m * ga.ldc + n, x);
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) f[q] = gelu_erf(f[q]) * rs;
+                            }
                             x = pack8(f);
                         }
                         if (!(G8_ABL & 32)) st16(ga.C + (int64_t)m * ga.ldc + n, x);

@@ -29,6 +29,7 @@ struct EpiArgs {
     int rows_per_scale; const bf16_t* residual; int ldr; int dbg; unsigned long long* stamps;
     PatchMap pm;                // used by the PATCH instantiations of k_gemm_nt only
     const float* dq_a; const float* dq_b;     // fp8 instantiation: device scalars, accumulators are multiplied by dq_a[0] * dq_b[0] first
+    const bf16_t* mul_by;       // out = v * mul_by[m,n] (ld = ldc): the stored activation derivative of a gelu = 2 forward
 };
 
 // epilogue of 8 consecutive output columns [n, n+8) of row m held in v[] (fp32 accumulators):
@@ -52,21 +53,24 @@ __device__ __forceinline__ void epi_chunk(float* v, int m, int n, int N, int ldc
     if (ep.gelu) {
         if (ep.preact) {
             bf16_t* p = ep.preact + (int64_t)m * ldc + n;
-            if (full) st16(p, pack8(v));
-            else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) if (q < nval) p[q] = f2bf(v[q]);
-            }
             // the activation is applied to the ROUNDED pre-activation so that backward (which reads the
-            // stored bf16 h) differentiates exactly what forward computed
+            // stored bf16 h, or the derivative stored here) differentiates exactly what forward computed
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = bf2f(f2bf(v[q]));
+            float sv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sv[q] = ep.gelu == 2 ? gelu_erf_grad(v[q]) : v[q];
+            if (full) st16(p, pack8(sv));
+            else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (q < nval) p[q] = f2bf(sv[q]);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]);
     }
-    if (ep.dgelu_of) {
-        const bf16_t* hp = ep.dgelu_of + (int64_t)m * ldc + n;
+    if (ep.dgelu_of || ep.mul_by) {
+        const bf16_t* hp = (ep.dgelu_of ? ep.dgelu_of : ep.mul_by) + (int64_t)m * ldc + n;
         float h[8];
         if (has_pre) unpack8(pre, h);
         else if (full) unpack8(ld16(hp), h);
@@ -74,8 +78,13 @@ __device__ __forceinline__ void epi_chunk(float* v, int m, int n, int N, int ldc
 #pragma unroll
             for (int q = 0; q < 8; ++q) h[q] = (q < nval) ? bf2f(hp[q]) : 0.f;
         }
+        if (ep.dgelu_of) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] *= gelu_erf_grad(h[q]);
+            for (int q = 0; q < 8; ++q) v[q] *= gelu_erf_grad(h[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] *= h[q];
+        }
     }
     if (ep.row_scale) {
         const float rs = ep.row_scale[m / ep.rows_per_scale];
@@ -85,7 +94,7 @@ __device__ __forceinline__ void epi_chunk(float* v, int m, int n, int N, int ldc
     if (ep.residual) {
         const bf16_t* rp = ep.residual + (int64_t)m * ep.ldr + n;
         float h[8];
-        if (has_pre && !ep.dgelu_of) unpack8(pre, h);
+        if (has_pre && !ep.dgelu_of && !ep.mul_by) unpack8(pre, h);
         else if (full) unpack8(ld16(rp), h);
         else {
 #pragma unroll

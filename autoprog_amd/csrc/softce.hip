@@ -118,67 +118,79 @@ k_soft_ce(const bf16_t* __restrict__ logits, int ldx, const float* __restrict__ 
 // formed in registers from its K pairs: logits in, dlogits out, nothing else.  One wave per row, a lane owns class pairs
 // 2 (lane + 64 i).  Pairs of row r = (b, n), b = r / rows_per_batch, sit at pairs + b * p_sb + n * p_sn (K entries each).
 #define CE_MAXK 16
+#define CE_SR 4            // rows per wave, all of their loads issued before the first is reduced
 __global__ void __launch_bounds__(256)
 k_soft_ce_sparse(const bf16_t* __restrict__ logits, int ldx, const int* __restrict__ idx, const float* __restrict__ val, int K,
                  int64_t p_sb, int64_t p_sn, int rows_per_batch, float smoothing, float* __restrict__ row_loss,
                  bf16_t* __restrict__ dlogits, float gscale, int64_t M, int C) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
-    if (row >= M) return;
-    const bf16_t* xr = logits + row * ldx;
-    unsigned lraw[CE_MAXV];
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * CE_SR;
+    if (row0 >= M) return;
+    unsigned lraw[CE_SR][CE_MAXV];
+    int my_i[CE_SR];
+    float my_v[CE_SR];
 #pragma unroll
-    for (int i = 0; i < CE_MAXV; ++i) lraw[i] = *reinterpret_cast<const unsigned*>(xr + min(2 * (lane + 64 * i), ldx - 2));
-    const int64_t b = row / rows_per_batch, n = row - b * rows_per_batch;
-    const int64_t po = b * p_sb + n * p_sn;
-    // the row's pairs: lane k holds pair k, every lane reads them by shuffle
-    const int my_i = lane < K ? idx[po + lane] : -1;
-    const float my_v = lane < K ? val[po + lane] * (1.0f - smoothing) : 0.f;
+    for (int r = 0; r < CE_SR; ++r) {
+        const int64_t row = min(row0 + r, M - 1);
+        const bf16_t* xr = logits + row * ldx;
+#pragma unroll
+        for (int i = 0; i < CE_MAXV; ++i) lraw[r][i] = *reinterpret_cast<const unsigned*>(xr + min(2 * (lane + 64 * i), ldx - 2));
+        const int64_t b = row / rows_per_batch, n = row - b * rows_per_batch;
+        const int64_t po = b * p_sb + n * p_sn;
+        my_i[r] = lane < K ? idx[po + lane] : -1;                    // lane k holds pair k of the row
+        my_v[r] = lane < K ? val[po + lane] * (1.0f - smoothing) : 0.f;
+    }
     const float base = smoothing / (float)C;
-    float xv[CE_MAXV][2], tv[CE_MAXV][2];
-    float mx = -3.0e38f;
 #pragma unroll
-    for (int i = 0; i < CE_MAXV; ++i) {
-        const int c = 2 * (lane + 64 * i);
-        xv[i][0] = c < C ? bf_lo(lraw[i]) : -3.0e38f;
-        xv[i][1] = c + 1 < C ? bf_hi(lraw[i]) : -3.0e38f;
-        tv[i][0] = c < C ? base : 0.f;
-        tv[i][1] = c + 1 < C ? base : 0.f;
-        mx = fmaxf(mx, fmaxf(xv[i][0], xv[i][1]));
-    }
-    for (int k = 0; k < K; ++k) {
-        const int ci = __shfl(my_i, k, 64);
-        const float cv = __shfl(my_v, k, 64);
-        const int owner = (ci >> 1) & 63, slot = ci >> 7;          // class ci = 2 * (owner + 64 * slot) + (ci & 1)
-        if (ci >= 0 && ci < C && lane == owner) {
+    for (int r = 0; r < CE_SR; ++r) {
+        const int64_t row = row0 + r;
+        if (row >= M) break;
+        float xv[CE_MAXV][2], tv[CE_MAXV][2];
+        float mx = -3.0e38f;
 #pragma unroll
-            for (int i = 0; i < CE_MAXV; ++i) if (i == slot) tv[i][ci & 1] += cv;
+        for (int i = 0; i < CE_MAXV; ++i) {
+            const int c = 2 * (lane + 64 * i);
+            xv[i][0] = c < C ? bf_lo(lraw[r][i]) : -3.0e38f;
+            xv[i][1] = c + 1 < C ? bf_hi(lraw[r][i]) : -3.0e38f;
+            tv[i][0] = c < C ? base : 0.f;
+            tv[i][1] = c + 1 < C ? base : 0.f;
+            mx = fmaxf(mx, fmaxf(xv[i][0], xv[i][1]));
         }
-    }
-    mx = group_max<64>(mx);
-    float se = 0.f, st = 0.f, stx = 0.f;
+        // the K pairs are wave-uniform once read with v_readlane: class ci = 2 * (owner + 64 * slot) + (ci & 1) lives in ONE lane
+        for (int k = 0; k < K; ++k) {
+            const int ci = __builtin_amdgcn_readlane(my_i[r], k);
+            const float cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_v[r]), k));
+            if (ci < 0 || ci >= C) continue;
+            const int owner = (ci >> 1) & 63, slot = ci >> 7, odd = ci & 1;
+            const float add = lane == owner ? cv : 0.f;
 #pragma unroll
-    for (int i = 0; i < CE_MAXV; ++i)
+            for (int i = 0; i < CE_MAXV; ++i) { tv[i][0] += (i == slot && !odd) ? add : 0.f; tv[i][1] += (i == slot && odd) ? add : 0.f; }
+        }
+        mx = group_max<64>(mx);
+        float se = 0.f, st = 0.f, stx = 0.f;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (2 * (lane + 64 * i) + k < C) {
-                se += __expf(xv[i][k] - mx);
-                st += tv[i][k];
-                stx += tv[i][k] * xv[i][k];
+        for (int i = 0; i < CE_MAXV; ++i)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (2 * (lane + 64 * i) + k < C) {
+                    se += __expf(xv[i][k] - mx);
+                    st += tv[i][k];
+                    stx += tv[i][k] * xv[i][k];
+                }
             }
-        }
-    se = group_sum<64>(se); st = group_sum<64>(st); stx = group_sum<64>(stx);
-    const float lse = mx + __logf(se);
-    if (lane == 0) row_loss[row] = lse * st - stx;
-    bf16_t* dr = dlogits + row * ldx;
+        se = group_sum<64>(se); st = group_sum<64>(st); stx = group_sum<64>(stx);
+        const float lse = mx + __logf(se);
+        if (lane == 0) row_loss[row] = lse * st - stx;
+        bf16_t* dr = dlogits + row * ldx;
 #pragma unroll
-    for (int i = 0; i < CE_MAXV; ++i) {
-        const int c = 2 * (lane + 64 * i);
-        if (c < ldx) {
-            float d0 = 0.f, d1 = 0.f;
-            if (c < C) d0 = gscale * (__expf(xv[i][0] - lse) * st - tv[i][0]);
-            if (c + 1 < C) d1 = gscale * (__expf(xv[i][1] - lse) * st - tv[i][1]);
-            *reinterpret_cast<unsigned*>(dr + c) = pack_bf2(d0, d1);
+        for (int i = 0; i < CE_MAXV; ++i) {
+            const int c = 2 * (lane + 64 * i);
+            if (c < ldx) {
+                float d0 = 0.f, d1 = 0.f;
+                if (c < C) d0 = gscale * (__expf(xv[i][0] - lse) * st - tv[i][0]);
+                if (c + 1 < C) d1 = gscale * (__expf(xv[i][1] - lse) * st - tv[i][1]);
+                *reinterpret_cast<unsigned*>(dr + c) = pack_bf2(d0, d1);
+            }
         }
     }
 }
@@ -234,7 +246,7 @@ extern "C" int ap_soft_ce_sparse_fwd_bwd(const ap_bf16* logits, int ldx, const i
     if (ldx > 64 * 2 * CE_MAXV) return AP_ERR_UNSUPPORTED;
     if (M == 0) return AP_OK;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_soft_ce_sparse, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const bf16_t*>(logits), ldx,
+    hipLaunchKernelGGL(k_soft_ce_sparse, dim3((unsigned)((M + 4 * CE_SR - 1) / (4 * CE_SR))), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const bf16_t*>(logits), ldx,
                        idx, val, K, p_sb, p_sn, rows_per_batch, smoothing, row_loss, reinterpret_cast<bf16_t*>(dlogits), grad_scale, M, C);
     return ap_check_launch();
 }

@@ -129,8 +129,9 @@ def layernorm_bwd_reduce_batched(items):
 
 # ------------------------------------------------------------------------------------- gemm
 def gemm_nt(a, b, n=None, k=None, bias=None, gelu=False, preact_out=None, dgelu_of=None, row_scale=None,
-            rows_per_scale=1, residual=None, out=None, ldc=None):
-    """out[M, :n] = epilogue(a[M, :k] @ b[:n, :k]^T); a/b bf16 2-D (row stride = shape[1])."""
+            rows_per_scale=1, residual=None, out=None, ldc=None, preact_grad=False, mul_by=None):
+    """out[M, :n] = epilogue(a[M, :k] @ b[:n, :k]^T); a/b bf16 2-D (row stride = shape[1]).
+    preact_grad: with gelu, preact_out receives gelu'(h) instead of h; its backward passes that tensor as mul_by."""
     _req(a, BF16, "a"); _req(b, BF16, "b")
     M = a.shape[0]
     n = b.shape[0] if n is None else n
@@ -142,9 +143,10 @@ def gemm_nt(a, b, n=None, k=None, bias=None, gelu=False, preact_out=None, dgelu_
         ldc = out.shape[1]
     epi = GemmEpilogue()
     epi.bias = bias.data_ptr() if bias is not None else None
-    epi.gelu = 1 if gelu else 0
+    epi.gelu = (2 if preact_grad else 1) if gelu else 0
     epi.preact_out = preact_out.data_ptr() if preact_out is not None else None
     epi.dgelu_of = dgelu_of.data_ptr() if dgelu_of is not None else None
+    epi.mul_by = mul_by.data_ptr() if mul_by is not None else None
     epi.row_scale = row_scale.data_ptr() if row_scale is not None else None
     epi.rows_per_scale = int(rows_per_scale)
     epi.residual = residual.data_ptr() if residual is not None else None
@@ -185,6 +187,7 @@ def gemm_nt_fp8(a8, b8, dq_a, dq_b, n=None, bias=None, gelu=False, preact_out=No
     epi.gelu = 1 if gelu else 0
     epi.preact_out = preact_out.data_ptr() if preact_out is not None else None
     epi.dgelu_of = None
+    epi.mul_by = None
     epi.row_scale = row_scale.data_ptr() if row_scale is not None else None
     epi.rows_per_scale = int(rows_per_scale)
     epi.residual = residual.data_ptr() if residual is not None else None

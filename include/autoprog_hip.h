@@ -94,13 +94,16 @@ int ap_gemm_nt_patch(const ap_bf16* A, const ap_bf16* B, int ldb, ap_bf16* C, in
 
 typedef struct ap_gemm_epilogue {
     const float* bias;          /* [N] or NULL */
-    int gelu;                   /* 1: out = gelu_erf(v) (models/volo.py:157) */
-    ap_bf16* preact_out;        /* with gelu: also store v (pre-activation) here, ld = ldc */
+    int gelu;                   /* 1: out = gelu_erf(v) (models/volo.py:157); 2: the same, and preact_out receives gelu'(v) instead of v */
+    ap_bf16* preact_out;        /* with gelu: also store v (the pre-activation; gelu = 2: its activation derivative) here, ld = ldc */
     const ap_bf16* dgelu_of;    /* out = v * gelu'(dgelu_of[m,n]) (backward of the above), ld = ldc */
     const float* row_scale;     /* [ceil(M/rows_per_scale)] or NULL */
     int rows_per_scale;
     const ap_bf16* residual;    /* [M,N] with leading dimension ldr, or NULL */
     int ldr;
+    const ap_bf16* mul_by;      /* out = v * mul_by[m,n] (ld = ldc), applied where dgelu_of is: the backward of gelu = 2, whose forward stored
+                                 * gelu'(h) -- the only thing the backward needs of h (autograd of models/volo.py:157) -- so that it is a
+                                 * multiplication instead of ~18 instructions per element; not together with dgelu_of.  (ABI version 3) */
 } ap_gemm_epilogue;
 int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C, int ldc,
                int M, int N, int K, const ap_gemm_epilogue* epi, ap_stream_t stream);

@@ -44,7 +44,7 @@ def dev(t):
 # ------------------------------------------------------------------------------------------
 def test_abi_loaded(ops):
     from autoprog_amd._lib import lib, LIB_PATH
-    assert lib.ap_abi_version() == 2
+    assert lib.ap_abi_version() == 3
     assert LIB_PATH.endswith("libautoprog_hip.so")
 
 
@@ -97,9 +97,11 @@ def test_gemm_nt_plain_and_bias(ops, M, N, K):
     assert rel(out[:, :N], ref + bias.double()) < TOL_BF16
 
 
-@pytest.mark.parametrize("M,N,K", [(392, 576, 192), (128, 1152, 384), (1, 384, 384), (200, 200, 1152), (256, 32, 32)])
+@pytest.mark.parametrize("M,N,K", [(392, 576, 192), (128, 1152, 384), (1, 384, 384), (200, 200, 1152), (256, 32, 32),
+                                   (4352, 576, 192), (4200, 1152, 384), (4100, 384, 1152)])
 def test_gemm_nt_epilogues(ops, M, N, K):
-    """second to fifth shapes: the few-rows kernel (M <= 256: class-attention blocks, cls heads)"""
+    """second to fifth shapes: the few-rows kernel (M <= 256: class-attention blocks, cls heads); the last three: the persistent
+    8-phase kernel (M >= 4096; 256 x 192 and 256 x 256 tiles, ragged last row tile)"""
     rps = max(1, M // 2)
     a, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
     bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
@@ -123,6 +125,16 @@ def test_gemm_nt_epilogues(ops, M, N, K):
     R.gelu(hr).backward(torch.ones(M, N, dtype=torch.float64))
     out = ops.gemm_nt(dev(a), dev(w), dgelu_of=dev(hh))
     assert rel(out, (a.double() @ w.double().t()) * hr.grad) < TOL_BF16
+    # the same pair with the activation DERIVATIVE stored by the forward (gelu = 2) and multiplied in by the backward (mul_by): what the
+    # blocks use -- gelu'(h) is all the backward needs of h (autograd of models/volo.py:157)
+    gp = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    out2 = ops.gemm_nt(dev(a), dev(w), bias=dev(bias), gelu=True, preact_out=gp, preact_grad=True, row_scale=dev(rs), rows_per_scale=rps)
+    hb = lin.to(torch.bfloat16).double().requires_grad_(True)             # the rounded pre-activation the activation is applied to
+    R.gelu(hb).backward(torch.ones(M, N, dtype=torch.float64))
+    assert rel(gp, hb.grad) < TOL_BF16
+    assert rel(out2, R.gelu(hb.detach()) * rs.double().repeat_interleave(rps)[:M, None]) < TOL_BF16
+    out3 = ops.gemm_nt(dev(a), dev(w), mul_by=gp, row_scale=dev(rs), rows_per_scale=rps)
+    assert rel(out3, (a.double() @ w.double().t()) * gp.double().cpu() * rs.double().repeat_interleave(rps)[:M, None]) < TOL_BF16
 
 
 @pytest.mark.parametrize("M,N1,N2", [(1024, 128, 128), (1000, 192, 576), (3000, 486, 192), (25088 // 8, 1152, 384), (130, 1000, 384),
@@ -519,7 +531,7 @@ def test_grouped_wgrad_launch_carries_the_layernorm_reductions(ops):
 
 @pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_MHSA_BWD_DS": "0", "AP_MHSA_FWD_P": "0"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"}, {"AP_OUTLOOK_MFMA": "0"},
                                  {"AP_STEM_HIP_CONV": "0"}, {"AP_ASYNC_WGRAD": "1"}, {"AP_GEMM_TN_PLACE": "0"}, {"AP_FUSE_LN_REDUCE": "0"}, {"AP_CONV_WGRAD_P": "0"},
-                                 {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}])
+                                 {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}, {"AP_GELU_STORE_GRAD": "0"}])
 def test_experimental_kernel_paths_stay_parity_green(env):
     """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:
     re-run the GEMM / block tests in a child process with the switch set (the switches are read once per process)"""
@@ -534,7 +546,7 @@ def test_experimental_kernel_paths_stay_parity_green(env):
         sel, files = "conv3x3", ["tests/test_gpu_kernels.py"]
     elif "STEM" in key:
         sel, files = "d1_shapes or hip_stem or patch_embed", ["tests/test_gpu_model.py", "tests/test_gpu_blocks.py"]
-    elif "WGRAD" in key or "FUSE_LN" in key:
+    elif "WGRAD" in key or "FUSE_LN" in key or "GELU" in key:
         sel, files = "vs_reference_golden or grad_sink", ["tests/test_gpu_blocks.py", "tests/test_gpu_model.py"]
     else:
         sel, files = "gemm and not experimental", ["tests/test_gpu_kernels.py"]

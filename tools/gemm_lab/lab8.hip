@@ -59,6 +59,8 @@ static void lab_pick(const G8Args& ga, const EpiArgs& ep, int grid, hipStream_t 
         case G8_BIAS | G8_GELU | G8_RS: lab_go<NT1, G8_BIAS | G8_GELU | G8_RS>(ga, ep, grid, st); break;
         case G8_DGELU: lab_go<NT1, G8_DGELU>(ga, ep, grid, st); break;
         case G8_DGELU | G8_RS: lab_go<NT1, G8_DGELU | G8_RS>(ga, ep, grid, st); break;
+        case G8_MUL: lab_go<NT1, G8_MUL>(ga, ep, grid, st); break;
+        case G8_MUL | G8_RS: lab_go<NT1, G8_MUL | G8_RS>(ga, ep, grid, st); break;
         case G8_BIAS | G8_RS | G8_RES: lab_go<NT1, G8_BIAS | G8_RS | G8_RES>(ga, ep, grid, st); break;
         default: lab_go<NT1, -1>(ga, ep, grid, st); break;
     }
@@ -120,6 +122,8 @@ int main(int argc, char** argv) {
             if (s.epi == "res") { ep.residual = Rs[i]; ep.ldr = ldc; }
             if (s.epi == "brr") { ep.bias = bias; ep.row_scale = rsc; ep.rows_per_scale = 196; ep.residual = Rs[i]; ep.ldr = ldc; }
             if (s.epi == "dgrs") { ep.dgelu_of = Hs[i]; ep.row_scale = rsc; ep.rows_per_scale = 196; }
+            if (s.epi == "mulrs") { ep.mul_by = Hs[i]; ep.row_scale = rsc; ep.rows_per_scale = 196; }
+            if (s.epi == "gelu2rs") { ep.bias = bias; ep.gelu = 2; ep.preact = pre; ep.row_scale = rsc; ep.rows_per_scale = 196; }
             if (s.epi == "gelurs") { ep.bias = bias; ep.gelu = 1; ep.preact = pre; ep.row_scale = rsc; ep.rows_per_scale = 196; }
             return ep;
         };
@@ -127,7 +131,7 @@ int main(int argc, char** argv) {
             EpiArgs ep = mk(i, Hs[i]);
             ap_gemm_epilogue e; memset(&e, 0, sizeof(e));
             e.bias = ep.bias; e.gelu = ep.gelu; e.preact_out = ep.preact; e.dgelu_of = ep.dgelu_of; e.residual = ep.residual; e.ldr = ep.ldr;
-            e.row_scale = ep.row_scale; e.rows_per_scale = ep.rows_per_scale;
+            e.row_scale = ep.row_scale; e.rows_per_scale = ep.rows_per_scale; e.mul_by = ep.mul_by;
             return ap_gemm_nt(As[i], s.K, Bs[i], s.K, C2[i], ldc, s.M, s.N, s.K, &e, st) == 0;
         };
         // correctness on set 0 (the gelu case writes its pre-activation to R so that H stays the dgelu input of other runs)
