@@ -34,7 +34,9 @@ class PatchMap(Structure):
     _fields_ = [("group", c_int), ("group_stride", c_int), ("row_stride", c_int), ("kseg", c_int), ("kseg_stride", c_int)]
 
 
-TN_MAX_GROUP = 8
+TN_MAX_GROUP = 32          # AP_TN_MAX_GROUP
+TN_MAX_GROUP_DET = 8       # the deterministic mode (workspace) takes 8
+LN_MAX_BATCH = 12          # AP_LN_MAX_BATCH
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 _SIGNATURES = {
     "ap_abi_version": (c_int, []),

@@ -689,14 +689,21 @@ k_gemm_tn_grouped_map(TnGroup grp, TnMap map, TnLn ln) {
 }
 
 // the 192 x 192-tile, LDS-DMA weight-gradient kernel (gemm_tn8p.h) with the same placement table and LayerNorm riders
-struct T8Group { T8Item p[TN_MAX_GROUP]; int tiles[TN_MAX_GROUP]; };
+// (up to AP_TN_MAX_GROUP = 32 problems -- the Linear layers of six transformer blocks, or of two and four outlooker blocks -- and one work item per CU: its own, smaller
+// placement table, entry = problem << 11 | split * tiles + tile; the three arguments stay under 4 KB)
+#define T8_MAP_MAX 320
+#define T8_MAP_SHIFT 11
+struct T8Map { unsigned short e[T8_MAP_MAX]; };
+struct T8Group { T8Item p[AP_TN_MAX_GROUP]; int tiles[AP_TN_MAX_GROUP]; };
+static_assert(sizeof(T8Group) + sizeof(T8Map) + sizeof(TnLn) <= 4096, "kernel arguments of k_gemm_tn_8p");
+static_assert(sizeof(TnGroup) + sizeof(TnMap) + sizeof(TnLn) <= 4096, "kernel arguments of k_gemm_tn_grouped_map");
 __global__ void __launch_bounds__(512, 2)
-k_gemm_tn_8p(T8Group grp, TnMap map, TnLn ln) {
+k_gemm_tn_8p(T8Group grp, T8Map map, TnLn ln) {
     extern __shared__ __attribute__((aligned(16))) unsigned char t8_smem[];
     if ((int)blockIdx.x >= ln.first) { tn_ln_role(ln, (int)blockIdx.x - ln.first, reinterpret_cast<float*>(t8_smem)); return; }
     const unsigned e = map.e[blockIdx.x];
     if (e == TN_MAP_IDLE) return;
-    const int pi = e >> 12, idx = e & 0xFFFu, tiles = grp.tiles[pi];
+    const int pi = e >> T8_MAP_SHIFT, idx = e & ((1u << T8_MAP_SHIFT) - 1u), tiles = grp.tiles[pi];
     t8_item(grp.p[pi], idx % tiles, idx / tiles, t8_smem);
 }
 
@@ -966,10 +973,24 @@ int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* 
     return AP_OK;
 }
 
+static int tn_grouped_128(const ap_tn_problem* problems, int count, const ap_ln_reduce* ln_items, int ln_count,
+                          void* workspace, size_t ws_bytes, ap_stream_t stream);
 // plan of a grouped launch: token splits per problem such that the launch fills the resident workgroup capacity once
-static int tn_plan(const ap_tn_problem* problems, int count, TnGroup& grp, int& total_blocks, size_t& slab_floats) {
+static int tn_validate(const ap_tn_problem* problems, int count) {
     if (!problems) return AP_ERR_NULL;
     if (count <= 0 || count > AP_TN_MAX_GROUP) return AP_ERR_SHAPE;
+    for (int i = 0; i < count; ++i) {
+        const ap_tn_problem& q = problems[i];
+        if (!q.A || !q.B || !q.C) return AP_ERR_NULL;
+        if (q.M <= 0 || q.N1 <= 0 || q.N2 <= 0) return AP_ERR_SHAPE;
+        if ((q.lda & 7) || q.lda < q.N1 || q.ldc < q.N2) return AP_ERR_SHAPE;
+        if (!q.b_patch && ((q.ldb & 7) || q.ldb < q.N2)) return AP_ERR_SHAPE;         // patch-addressed B has no leading dimension
+    }
+    return AP_OK;
+}
+static int tn_plan(const ap_tn_problem* problems, int count, TnGroup& grp, int& total_blocks, size_t& slab_floats) {
+    if (!problems) return AP_ERR_NULL;
+    if (count <= 0 || count > TN_MAX_GROUP) return AP_ERR_SHAPE;
     // Two 256-thread workgroups are resident per CU: the launch should fill that single wave of workgroups as fully as
     // possible but never spill into a second one (measured on the D1 blocks: 450 workgroups 125 us, 540 -> 175 us).
     static int capacity = 0;
@@ -1075,8 +1096,42 @@ static bool tn8_fits(const ap_tn_problem& q) {
     if (q.N1 % 192 || q.N2 % 192 || q.M % 64 || q.M < 4096 || (q.lda & 7) || (q.ldb & 7) || q.lda < q.N1 || q.ldb < q.N2 || q.ldc < q.N2) return false;
     return !(q.colsum_weight && (reinterpret_cast<uintptr_t>(q.colsum_weight) & 3));
 }
-static bool tn8_plan(const ap_tn_problem* problems, int count, int n_cu, T8Group& g8, TnMap& map, int& mblocks) {
-    if (count <= 0 || count > TN_MAX_GROUP) return false;
+// placement for the 8p kernel: as tn_place, but a (problem, token range) that does not fit the least loaded XCD any more is CUT over
+// XCDs (consecutive tiles share their A column block): with six blocks in a launch the table is nearly full -- 240 of 256 slots
+struct T8Plan { int tiles, splits; };
+static bool t8_place(const T8Plan* pl, int count, int cap, T8Map& map, int& blocks) {
+    struct G { int p, s, n; };
+    G g[T8_MAP_MAX]; int ng = 0;
+    for (int i = 0; i < count; ++i) {
+        if (pl[i].tiles * pl[i].splits > (1 << T8_MAP_SHIFT)) return false;
+        for (int s = 0; s < pl[i].splits; ++s) { if (ng == T8_MAP_MAX) return false; g[ng++] = G{i, s, pl[i].tiles}; }
+    }
+    for (int i = 1; i < ng; ++i) {                       // insertion sort by size, descending, stable
+        const G v = g[i]; int j = i - 1;
+        while (j >= 0 && g[j].n < v.n) { g[j + 1] = g[j]; --j; }
+        g[j + 1] = v;
+    }
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < T8_MAP_MAX; ++i) map.e[i] = TN_MAP_IDLE;
+    for (int i = 0; i < ng; ++i) {
+        int t = 0;
+        while (t < g[i].n) {
+            int x = 0;
+            for (int k = 1; k < 8; ++k) if (load[k] < load[x]) x = k;
+            int take = g[i].n - t;
+            if (take > cap - load[x]) take = cap - load[x];
+            if (take <= 0 || (load[x] + take) * 8 > T8_MAP_MAX) return false;
+            for (int u = 0; u < take; ++u) map.e[(load[x] + u) * 8 + x] = (unsigned short)((g[i].p << T8_MAP_SHIFT) | (g[i].s * g[i].n + t + u));
+            load[x] += take; t += take;
+        }
+    }
+    int mx = 0;
+    for (int k = 0; k < 8; ++k) if (load[k] > mx) mx = load[k];
+    blocks = mx * 8;
+    return true;
+}
+static bool tn8_plan(const ap_tn_problem* problems, int count, int n_cu, T8Group& g8, T8Map& map, int& mblocks) {
+    if (count <= 0 || count > AP_TN_MAX_GROUP) return false;
     int64_t work = 0; int max_k = 1;
     for (int i = 0; i < count; ++i) {
         const ap_tn_problem& q = problems[i];
@@ -1086,17 +1141,16 @@ static bool tn8_plan(const ap_tn_problem* problems, int count, int n_cu, T8Group
     }
     int ksps = (int)((work + n_cu - 1) / n_cu);
     if (ksps < 8) ksps = 8;
-    TnGroup tg;
+    T8Plan pl[AP_TN_MAX_GROUP];
     for (; ksps <= max_k; ++ksps) {
         int64_t items = 0;
         for (int i = 0; i < count; ++i) {
             const ap_tn_problem& q = problems[i];
-            const int tiles = (q.N1 / 192) * (q.N2 / 192), ksteps = q.M / 64, splits = (ksteps + ksps - 1) / ksps;
-            tg.p[i].t1 = q.N1 / 192; tg.p[i].t2 = q.N2 / 192; tg.p[i].splits = splits;
-            items += (int64_t)tiles * splits;
+            const int ksteps = q.M / 64;
+            pl[i].tiles = (q.N1 / 192) * (q.N2 / 192); pl[i].splits = (ksteps + ksps - 1) / ksps;
+            items += (int64_t)pl[i].tiles * pl[i].splits;
         }
-        tg.count = count;
-        if (items <= n_cu && tn_place(tg, n_cu / 8, map, mblocks)) break;
+        if (items <= n_cu && t8_place(pl, count, n_cu / 8, map, mblocks)) break;
     }
     if (ksps > max_k) return false;
     for (int i = 0; i < count; ++i) {
@@ -1107,8 +1161,11 @@ static bool tn8_plan(const ap_tn_problem* problems, int count, int n_cu, T8Group
         t.lda = q.lda; t.ldb = q.ldb; t.ldc = q.ldc; t.M = q.M; t.t2 = q.N2 / 192; t.ksteps = q.M / 64; t.ksps = ksps;
         t.alpha = q.alpha != 0.0f ? q.alpha : 1.0f; t.cs_scale = q.colsum_weight ? q.colsum_scale : 1.0f;
         g8.tiles[i] = (q.N1 / 192) * (q.N2 / 192);
+        t.shared_out = 0;
+        for (int j = 0; j < count; ++j)
+            if (j != i && (problems[j].C == q.C || (q.colsum_A && problems[j].colsum_A == q.colsum_A))) t.shared_out = 1;
     }
-    for (int i = count; i < TN_MAX_GROUP; ++i) { g8.p[i] = g8.p[0]; g8.tiles[i] = 1; }
+    for (int i = count; i < AP_TN_MAX_GROUP; ++i) { g8.p[i] = g8.p[0]; g8.tiles[i] = 1; }
     return true;
 }
 
@@ -1129,13 +1186,13 @@ int ap_gemm_tn_acc_grouped_ln(const ap_tn_problem* problems, int count, const ap
         if (!ln_items[i].partial || !ln_items[i].dgamma || !ln_items[i].dbeta) return AP_ERR_NULL;
         if (ln_items[i].n_partial <= 0 || ln_items[i].C <= 0) return AP_ERR_SHAPE;
     }
-    bool ln_done = ln_count == 0;
-    TnGroup grp; int blocks = 0; size_t fl = 0;
-    const int rc = tn_plan(problems, count, grp, blocks, fl);
-    if (rc != AP_OK) return rc;
+    {
+        const int rcv = tn_validate(problems, count);
+        if (rcv != AP_OK) return rcv;
+    }
     if (!workspace) {
         // the 192 x 192-tile LDS-DMA kernel takes the problems that fit it (with the LayerNorm riders); the rest of the group -- e.g. the
-        // 486-wide attention-weight projection of an outlooker block -- goes on in a launch of the 128 x 128-tile kernel
+        // 486-wide attention-weight projection of an outlooker block -- goes on in launches of the 128 x 128-tile kernel, 8 problems each
         static int n_cu = 0;
         if (n_cu == 0) {
             int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr;
@@ -1146,7 +1203,8 @@ int ap_gemm_tn_acc_grouped_ln(const ap_tn_problem* problems, int count, const ap
         ap_tn_problem fit[AP_TN_MAX_GROUP], rest[AP_TN_MAX_GROUP];
         int nfit = 0, nrest = 0;
         for (int i = 0; i < count; ++i) { if (tn8_fits(problems[i])) fit[nfit++] = problems[i]; else rest[nrest++] = problems[i]; }
-        T8Group g8; TnMap map8; int mb8 = 0;
+        T8Group g8; T8Map map8; int mb8 = 0;
+        bool riders_done = false;
         if (nfit > 0 && tn8_plan(fit, nfit, n_cu, g8, map8, mb8)) {
             TnLn ln;
             int lblocks = 0;
@@ -1160,10 +1218,31 @@ int ap_gemm_tn_acc_grouped_ln(const ap_tn_problem* problems, int count, const ap
             (void)hipGetLastError();
             hipLaunchKernelGGL(k_gemm_tn_8p, dim3(mb8 + lblocks), dim3(512), T8_LDS_BYTES, (hipStream_t)stream, g8, map8, ln);
             const int rc8 = ap_check_launch();
-            if (rc8 != AP_OK || nrest == 0) return rc8;
-            return ap_gemm_tn_acc_grouped_ln(rest, nrest, nullptr, 0, nullptr, 0, stream);
+            if (rc8 != AP_OK) return rc8;
+            riders_done = true;
+        } else { for (int i = 0; i < nfit; ++i) rest[nrest++] = fit[i]; }
+        if (nrest == 0 && riders_done) return AP_OK;
+        if (nrest > TN_MAX_GROUP || (nrest > 0 && riders_done)) {
+            for (int i0 = 0; i0 < nrest; i0 += TN_MAX_GROUP) {
+                const int n = nrest - i0 < TN_MAX_GROUP ? nrest - i0 : TN_MAX_GROUP;
+                const bool with_ln = !riders_done;
+                const int rcc = tn_grouped_128(rest + i0, n, with_ln ? ln_items : nullptr, with_ln ? ln_count : 0, nullptr, 0, stream);
+                if (rcc != AP_OK) return rcc;
+                riders_done = true;
+            }
+            return AP_OK;
         }
     }
+    return tn_grouped_128(problems, count, ln_items, ln_count, workspace, ws_bytes, stream);
+}
+
+// the 128 x 128-tile kernels: at most TN_MAX_GROUP problems, optional deterministic mode
+static int tn_grouped_128(const ap_tn_problem* problems, int count, const ap_ln_reduce* ln_items, int ln_count,
+                          void* workspace, size_t ws_bytes, ap_stream_t stream) {
+    bool ln_done = ln_count == 0;
+    TnGroup grp; int blocks = 0; size_t fl = 0;
+    const int rc = tn_plan(problems, count, grp, blocks, fl);
+    if (rc != AP_OK) return rc;
     if (workspace) {                                  // deterministic: stored partial tiles + ordered reduce instead of fp32 atomics
         if (ws_bytes < fl * sizeof(float)) return AP_ERR_SHAPE;
         float* w = reinterpret_cast<float*>(workspace);

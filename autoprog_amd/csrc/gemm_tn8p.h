@@ -42,6 +42,7 @@ struct T8Item {            // one problem of a grouped launch
     const bf16_t* A; const bf16_t* B; float* C; float* colsum; const bf16_t* cs_weight;
     int lda, ldb, ldc, M, t2, ksteps, ksps;          // t2: column tiles; ksteps: 64-token K-tiles of the problem; ksps: K-tiles per work item
     float alpha, cs_scale;
+    int shared_out;                                  // another problem of the launch adds to the same C / column sum: atomics even when unsplit
 };
 
 // The transposed reads are inline asm: behind a pending LDS-DMA hipcc guards every LDS read it can see with s_waitcnt vmcnt(0)
@@ -220,7 +221,7 @@ __device__ __forceinline__ void t8_item(const T8Item& it, int tile, int split, u
     if (cs_w) run(Yes{}, Yes{}); else if (cs_wave) run(Yes{}, No{}); else run(No{}, No{});
     if (w1 == 0) T8_BAR();
 
-    // ---- partial tile -> C (fp32 atomics: 4 rows x 64 bytes per wave-instruction)
+    // ---- partial tile -> C (4 rows x 64 bytes per wave-instruction)
     const int fr = lane & 15;
     if (T8_ABL & 8) {
 #pragma unroll
@@ -230,6 +231,30 @@ __device__ __forceinline__ void t8_item(const T8Item& it, int tile, int split, u
         return;
     }
     float* const crow = it.C + (int64_t)(n1_0 + w1 * 96 + 4 * g) * it.ldc + n2_0 + w2 * 48 + fr;
+    const float sc = it.cs_weight ? it.cs_scale : 1.0f;
+    if (it.ksps >= it.ksteps && !it.shared_out) {
+        // the item is the problem's whole token axis: nobody else adds to this tile, so C += is a plain read-add-store (the chip adds
+        // 1.3 TB/s of fp32 atomics against ~6 TB/s of stores, and a launch holds one 144 KB tile per CU whatever it is cut into)
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            float old[3][4];
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) old[b][r] = crow[(int64_t)(a * 16 + r) * it.ldc + b * 16];
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) crow[(int64_t)(a * 16 + r) * it.ldc + b * 16] = fmaf(acc[a][b][r], it.alpha, old[b][r]);
+        }
+        if (cs_wave && fr == 0) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { float* q = it.colsum + n1_0 + w1 * 96 + a * 16 + 4 * g + r; *q = fmaf(csum[a][r], sc, *q); }
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -237,7 +262,6 @@ __device__ __forceinline__ void t8_item(const T8Item& it, int tile, int split, u
 #pragma unroll
             for (int r = 0; r < 4; ++r) atomicAdd(crow + (int64_t)(a * 16 + r) * it.ldc + b * 16, acc[a][b][r] * it.alpha);
     if (cs_wave && fr == 0) {
-        const float sc = it.cs_weight ? it.cs_scale : 1.0f;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll

@@ -106,6 +106,8 @@ class GradientBucketReducer:
     # ------------------------------------------------------------------ step API
     def zero_grad(self):
         """gradients stay attached to the slab (never set to None)"""
+        from . import functional
+        functional.reset_wgrad_window()         # (a backward pass that raised may have left problems behind)
         self.flat.zero_()
         self._pending_scale = 1.0               # a deferred 1/world that nobody consumed dies with the gradients it belonged to
         self._pending = [len(m) for (_, _, m) in self.buckets]

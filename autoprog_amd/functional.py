@@ -108,10 +108,12 @@ def _param_grad_buffers(params):
     return _zeros_like_params(params), False
 
 
-def _finish_param_grads(params, bufs, sink_used):
+def _finish_param_grads(params, bufs, sink_used, deferred=False):
     if not sink_used:
         join_wgrad_stream()              # autograd consumes these buffers on the current stream
         return bufs
+    if deferred:                         # the weight-gradient window delivers them (flush_wgrad_window)
+        return [None] * len(params)
     if _grad_sink.needs_stream_join():
         join_wgrad_stream()              # a bucket all-reduce may be launched from param_ready
     for p in params:
@@ -158,7 +160,11 @@ _wgrad_batch = None
 
 
 class wgrad_batch:
-    """with wgrad_batch(): ... _linear_bwd calls ... ; the collected weight gradients launch on exit"""
+    """with wgrad_batch(): ... _linear_bwd calls ... ; the collected weight gradients launch on exit -- or, with `sunk` (the gradients
+    accumulate in place into param.grad, nothing is returned to autograd), join the weight-gradient window of the backward pass"""
+
+    def __init__(self, sunk=False, params=()):
+        self.sunk, self.params, self.deferred = sunk, params, False
 
     def __enter__(self):
         global _wgrad_batch
@@ -171,7 +177,9 @@ class wgrad_batch:
         global _wgrad_batch
         pending, _wgrad_batch = _wgrad_batch, self.prev
         if exc[0] is None:
-            if pending and not async_wgrad and fuse_ln_reduce:
+            if self.sunk and pending and _window_add(pending, self.ln, self.params):
+                self.deferred = True
+            elif pending and not async_wgrad and fuse_ln_reduce:
                 _launch_wgrads(pending, self.ln)                 # the block's LayerNorm dgamma / dbeta reductions ride in the weight-gradient launch
             else:
                 if self.ln:
@@ -179,6 +187,76 @@ class wgrad_batch:
                 if pending:
                     _launch_wgrads(pending)
         return False
+
+
+# The weight-gradient window.  A block's own launch has 40 output tiles (192 x 192) for 256 CUs, so every problem is cut into ~6 token
+# ranges whose partial tiles meet in fp32 atomics: 21-27 us of a ~100 us launch, bound by the chip's atomic rate, not by anything the
+# kernel does.  Nothing in the backward chain reads a weight gradient, so the blocks' problems are collected -- operands kept alive by
+# the references held here -- and launched once about one tile per CU has come together (six transformer blocks of VOLO-D1): no token
+# axis is cut, the tiles leave as plain read-add-stores (ops.gemm_tn_acc_grouped / k_gemm_tn_8p), results become reproducible.
+# The end of the backward pass flushes what is left (an autograd engine callback).  Only with a gradient sink: the gradients land in
+# param.grad in place, and the sink hears param_ready() at the flush instead of at the end of the block.
+# AP_WGRAD_WINDOW: tiles per launch (0 = one launch per block, the behaviour before).
+WGRAD_WINDOW = int(os.environ.get("AP_WGRAD_WINDOW", "256"))
+_window = {"problems": [], "ln": [], "params": [], "tiles": 0, "armed": False}
+
+
+def _tiles_192(prob):
+    a, c, n1, n2 = prob[0], prob[2], prob[3], prob[4]
+    n1 = c.shape[0] if n1 is None else n1
+    n2 = c.shape[1] if n2 is None else n2
+    if n1 % 192 or n2 % 192 or a.shape[0] % 64 or a.shape[0] < 4096 or (len(prob) > 9 and prob[9] is not None):
+        return 0                      # not a problem of the 192 x 192-tile kernel: rides along, costs no slot
+    return (n1 // 192) * (n2 // 192)
+
+
+def _window_add(problems, ln, params):
+    """-> True when the window took the block's weight gradients"""
+    from ._lib import TN_MAX_GROUP, LN_MAX_BATCH
+    if WGRAD_WINDOW <= 0 or async_wgrad or not fuse_ln_reduce or ops.deterministic:
+        return False
+    if len(problems) > TN_MAX_GROUP or len(ln) > LN_MAX_BATCH:
+        return False
+    w = _window
+    if not w["armed"]:
+        try:                          # inside a backward pass: the engine calls back when it is over
+            torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_window)
+        except RuntimeError:
+            return False
+        w["armed"] = True
+    tiles = sum(_tiles_192(q) for q in problems)
+    if w["problems"] and (w["tiles"] + tiles > WGRAD_WINDOW or len(w["problems"]) + len(problems) > TN_MAX_GROUP
+                          or len(w["ln"]) + len(ln) > LN_MAX_BATCH):
+        _window_launch()
+    w["problems"] += problems
+    w["ln"] += ln
+    w["params"] += [p for p in params if p is not None]
+    w["tiles"] += tiles
+    return True
+
+
+def _window_launch():
+    w = _window
+    problems, ln, params = w["problems"], w["ln"], w["params"]
+    w["problems"], w["ln"], w["params"], w["tiles"] = [], [], [], 0
+    if problems:
+        ops.gemm_tn_acc_grouped(problems, ln=ln)
+    elif ln:
+        ops.layernorm_bwd_reduce_batched(ln)
+    if _grad_sink is not None:
+        for p in params:
+            _grad_sink.param_ready(p)
+
+
+def flush_wgrad_window():
+    """launch what the window holds (the end of every backward pass does; harmless when it is empty)"""
+    _window["armed"] = False
+    _window_launch()
+
+
+def reset_wgrad_window():
+    """drop what a backward pass that raised left behind"""
+    _window.update(problems=[], ln=[], params=[], tiles=0, armed=False)
 
 
 fuse_ln_reduce = os.environ.get("AP_FUSE_LN_REDUCE", "1") != "0"
@@ -287,7 +365,7 @@ class TransformerBlockFn(torch.autograd.Function):
         bufs, sunk = _param_grad_buffers(params)
         (dn1w, dn1b, dqkv_w, dqkv_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = bufs
         dy2 = dy.reshape(x2.shape).contiguous()
-        with wgrad_batch() as batch:         # the four weight gradients (and the two LayerNorm parameter gradients) launch together on exit
+        with wgrad_batch(sunk, params) as batch:         # the four weight gradients (and the two LayerNorm parameter gradients) launch together: on exit, or with the window's
             # MLP branch
             dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, row_scale=rs2, rows_per_scale=N, cs_weight=tm2, inv_keep=inv_keep, **_gelu_bwd_kw(h))
             dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b)
@@ -297,7 +375,7 @@ class TransformerBlockFn(torch.autograd.Function):
             dqkv = ops.mhsa_bwd(qkv, o, do, lse, B, N, heads, scale)      # dropped samples: do = 0, so the masked rows of o do not matter
             dxn1 = _linear_bwd(dqkv, xn1, qkv_w, dqkv_w, dqkv_b)
             dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b, defer=batch.ln)
-        return (dx.view(dy.shape), None, None, *_finish_param_grads(params, bufs, sunk), None, None, None, None, None, None, None, None, None)
+        return (dx.view(dy.shape), None, None, *_finish_param_grads(params, bufs, sunk, batch.deferred), None, None, None, None, None, None, None, None, None)
 
 
 # ----------------------------------------------------------------------------- class block
@@ -341,7 +419,7 @@ class ClassBlockFn(torch.autograd.Function):
         bufs, sunk = _param_grad_buffers(params)
         (dn1w, dn1b, dkv_w, dkv_b, dq_w, dq_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = bufs
         g = dc2.contiguous()
-        with wgrad_batch() as batch:
+        with wgrad_batch() as batch:          # (not in the weight-gradient window: 12 small problems for one 8-tile one)
             dh = _linear_bwd(g, a, fc2_w, dfc2_w, dfc2_b, **_gelu_bwd_kw(h))
             dn2 = _linear_bwd(dh, n2, fc1_w, dfc1_w, dfc1_b)
             dc1 = ops.layernorm_bwd(dn2, c1, n2w, m2, r2, g, dn2w, dn2b, defer=batch.ln)
@@ -354,7 +432,7 @@ class ClassBlockFn(torch.autograd.Function):
             dnc = ops.gemm_nt(dq, wq_t, n=wq_t.shape[0], k=wq_t.shape[1], residual=dnc_kv)      # dq Wq + dkv_c Wkv in one epilogue
             dcls = ops.layernorm_bwd(dnc, c0, n1w, mc, rc, dc1, dn1w, dn1b)       # reduced at once: it shares dn1w / dn1b with the deferred
             dtok = ops.layernorm_bwd(dnt, t0, n1w, mt, rt, None, dn1w, dn1b, defer=batch.ln)      # token piece (two deferred sums into one vector would race)
-        return (dcls.view(ctx.shapes[0]), dtok.view(ctx.shapes[1]), *_finish_param_grads(params, bufs, sunk), None, None, None, None)
+        return (dcls.view(ctx.shapes[0]), dtok.view(ctx.shapes[1]), *_finish_param_grads(params, bufs, sunk, batch.deferred), None, None, None, None)
 
 
 # ------------------------------------------------------------------------- outlooker block
@@ -395,7 +473,7 @@ class OutlookerBlockFn(torch.autograd.Function):
         bufs, sunk = _param_grad_buffers(params)
         (dn1w, dn1b, dv_w, dv_b, dattn_w, dattn_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = bufs
         dy2 = dy.reshape(T, C).contiguous()
-        with wgrad_batch() as batch:         # the five weight gradients launch together on exit
+        with wgrad_batch(sunk, params) as batch:         # the five weight gradients launch together: on exit, or with the window's
             dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, **_gelu_bwd_kw(h))
             dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b)
             dx1 = ops.layernorm_bwd(dxn2, x1, n2w, m2, r2, dy2, dn2w, dn2b, defer=batch.ln)
@@ -405,7 +483,7 @@ class OutlookerBlockFn(torch.autograd.Function):
             dxn1 = _linear_bwd(dv.view(T, C), xn1, v_w, dv_w, dv_b)
             ops.avgpool2_bwd_acc(dpooled.view(B, (H + 1) // 2, (W + 1) // 2, C), dxn1.view(B, H, W, C))
             dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b, defer=batch.ln)
-        return (dx.view(dy.shape), *_finish_param_grads(params, bufs, sunk), None, None)
+        return (dx.view(dy.shape), *_finish_param_grads(params, bufs, sunk, batch.deferred), None, None)
 
 
 # --------------------------------------------------------------------- fine-grained pieces

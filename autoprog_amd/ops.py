@@ -117,10 +117,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, defer=None):
 
 
 def layernorm_bwd_reduce_batched(items):
-    """items: the entries layernorm_bwd(..., defer=items) appended; one launch per 4 LayerNorms"""
-    from ._lib import LnReduce
-    for i0 in range(0, len(items), 4):
-        chunk = items[i0:i0 + 4]
+    """items: the entries layernorm_bwd(..., defer=items) appended; one launch per LN_MAX_BATCH LayerNorms"""
+    from ._lib import LnReduce, LN_MAX_BATCH
+    for i0 in range(0, len(items), LN_MAX_BATCH):
+        chunk = items[i0:i0 + LN_MAX_BATCH]
         arr = (LnReduce * len(chunk))()
         for q, (ws, n, C, dg, db) in zip(arr, chunk):
             q.partial, q.n_partial, q.C, q.dgamma, q.dbeta = ws.data_ptr(), n, C, dg.data_ptr(), db.data_ptr()
@@ -250,14 +250,15 @@ def gemm_tn_acc_grouped(problems, ln=None):
     """problems: list of (a, b, c, n1, n2, colsum[, colsum_weight, colsum_scale[, alpha[, b_patch]]]) as for gemm_tn_acc; ONE launch for
     the whole list (chunks of 8).  colsum_weight: bf16 per-token weights of the column sum (DropPath keep mask), colsum_scale its factor;
     alpha: factor of the product (c += alpha * a^T b); b_patch: PatchMap -- b is then an NHWC feature map whose patches are the rows.
-    ln: deferred LayerNorm reductions (the entries layernorm_bwd(..., defer=...) appended, at most 4): they ride in the first launch."""
-    from ._lib import TnProblem, TN_MAX_GROUP, LnReduce
+    ln: deferred LayerNorm reductions (the entries layernorm_bwd(..., defer=...) appended): LN_MAX_BATCH of them ride in the first launch."""
+    from ._lib import TnProblem, TN_MAX_GROUP, TN_MAX_GROUP_DET, LnReduce, LN_MAX_BATCH
     ln = list(ln) if ln else []
-    if len(ln) > 4:
-        layernorm_bwd_reduce_batched(ln[4:])
-        ln = ln[:4]
-    for i0 in range(0, len(problems), TN_MAX_GROUP):
-        chunk = problems[i0:i0 + TN_MAX_GROUP]
+    if len(ln) > LN_MAX_BATCH:
+        layernorm_bwd_reduce_batched(ln[LN_MAX_BATCH:])
+        ln = ln[:LN_MAX_BATCH]
+    per = TN_MAX_GROUP_DET if deterministic else TN_MAX_GROUP
+    for i0 in range(0, len(problems), per):
+        chunk = problems[i0:i0 + per]
         arr = (TnProblem * len(chunk))()
         keep = []
         for q, prob in zip(arr, chunk):

@@ -71,7 +71,7 @@ int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, co
 /* the same without the dgamma / dbeta reduction: the per-workgroup partial rows stay in `workspace` (which must live until the
  * batched reduction ran), *n_partial receives their count; ap_layernorm_bwd_reduce_batched then reduces up to AP_LN_MAX_BATCH
  * LayerNorms (all of one block) in ONE launch: dgamma / dbeta += column sums of the partial rows */
-#define AP_LN_MAX_BATCH 4
+#define AP_LN_MAX_BATCH 12
 typedef struct ap_ln_reduce { const float* partial; int n_partial; int C; float* dgamma; float* dbeta; } ap_ln_reduce;
 int ap_layernorm_bwd_partial(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* mean, const float* rstd,
                              const ap_bf16* dres, ap_bf16* dx, int64_t rows, int C, void* workspace, size_t ws_bytes, int* n_partial,
@@ -118,10 +118,12 @@ int ap_gemm_nt_fp8(const unsigned char* A, int lda, const unsigned char* B, int 
  * optional fused bias gradient: colsum_A[n] += sum_m A[m,n] (NULL to skip) */
 int ap_gemm_tn_acc(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, float* C, int ldc,
                    int M, int N1, int N2, float* colsum_A, ap_stream_t stream);
-/* the same for up to AP_TN_MAX_GROUP problems in ONE launch (all Linear layers of a block: the reference's autograd
- * issues one addmm per layer, models/volo.py:67-71,156-158,180-182): the launch's workgroups are shared between the
- * problems, so each is split over fewer token ranges and adds fewer fp32 partial tiles atomically */
-#define AP_TN_MAX_GROUP 8
+/* the same for up to AP_TN_MAX_GROUP problems in ONE launch (all Linear layers of a block, or of several blocks: the
+ * reference's autograd issues one addmm per layer, models/volo.py:67-71,156-158,180-182): the launch's workgroups are shared
+ * between the problems, so each is split over fewer token ranges and adds fewer fp32 partial tiles atomically -- with the
+ * weight gradients of ~6 transformer blocks in one launch no problem is split at all and the partial tiles are plain
+ * read-add-stores (the atomics of a block's own launch were 21-27 us of its ~100).  The deterministic mode takes at most 8. */
+#define AP_TN_MAX_GROUP 32
 typedef struct ap_tn_problem {
     const ap_bf16* A; int lda;      /* [M,N1] */
     const ap_bf16* B; int ldb;      /* [M,N2] */

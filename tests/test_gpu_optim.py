@@ -290,3 +290,37 @@ def test_autoprog_driver_two_stage_search():
         assert torch.equal(opt.p, before)
     finally:
         red.remove()
+
+
+def test_weight_gradient_window_matches_one_launch_per_block(monkeypatch):
+    """functional's weight-gradient window: the blocks' weight gradients (and LayerNorm parameter gradients) leave in a few launches
+    for the whole backward pass instead of one per block, and param.grad holds the same numbers (only the order of fp32 additions
+    differs); the window is empty after the pass; AP_WGRAD_WINDOW=0 is the per-block behaviour"""
+    from autoprog_amd import functional as AF, ops
+    model, red, opt, loss_fn, x, target = _setup()
+    try:
+        calls = []
+        real = ops.gemm_tn_acc_grouped
+        monkeypatch.setattr(ops, "gemm_tn_acc_grouped", lambda problems, ln=None: (calls.append((len(problems), len(ln or []))), real(problems, ln=ln))[1])
+        grads = {}
+        for window in (0, 256):
+            monkeypatch.setattr(AF, "WGRAD_WINDOW", window)
+            calls.clear()
+            np.random.seed(0); torch.manual_seed(0)
+            red.zero_grad()
+            loss_fn(model(x), target).backward()
+            red.finish()
+            torch.cuda.synchronize()
+            grads[window] = red.flat.detach().clone()
+            launches = [c for c in calls if c[0] > 1]
+            if window:
+                assert len(launches) < n_block_launches and sum(c[0] for c in calls) == n_problems and sum(c[1] for c in calls) == n_ln
+                assert not AF._window["problems"] and not AF._window["armed"]
+            else:
+                n_block_launches, n_problems, n_ln = len(launches), sum(c[0] for c in calls), sum(c[1] for c in calls)
+                assert n_block_launches >= 3
+        assert float(grads[0].abs().max()) > 0
+        err = float((grads[256] - grads[0]).norm() / grads[0].norm())
+        assert err < 1e-5, err
+    finally:
+        red.remove()
