@@ -50,6 +50,7 @@ class GradientBucketReducer:
         self._launched = [False] * len(self.buckets)
         self._handles = []
         self._seen = set()
+        self._held = set()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.world > 1 else []
         self._owned = {id(p) for p in self.params}
         self._no_sink = set()
@@ -70,8 +71,15 @@ class GradientBucketReducer:
         return self.world > 1
 
     def param_ready(self, p):
+        self._held.discard(id(p))
         if self.world > 1:
             self._on_grad(p)
+
+    def hold(self, params):
+        """the gradients of these parameters are still to be written (functional's weight-gradient window holds their problems): autograd
+        runs their AccumulateGrad nodes -- and the post-accumulate hook -- when the block's backward returns, with nothing to accumulate;
+        that must not count as ready.  param_ready() releases them."""
+        self._held.update(id(p) for p in params if p is not None)
 
     def install_sink(self, model=None):
         """let the fused block backward passes accumulate straight into the slab (no per-parameter
@@ -90,7 +98,7 @@ class GradientBucketReducer:
     def _on_grad(self, p):
         # idempotent per step: autograd may still run the AccumulateGrad node (and this hook) of a parameter
         # whose gradient the fused backward already delivered through param_ready()
-        if id(p) in self._seen:
+        if id(p) in self._seen or id(p) in self._held:
             return
         self._seen.add(id(p))
         b = self._bucket_of[id(p)]
@@ -114,11 +122,13 @@ class GradientBucketReducer:
         self._launched = [False] * len(self.buckets)
         self._handles = []
         self._seen = set()
+        self._held = set()
 
     def finish(self):
         """call after backward(): reduce buckets whose hooks did not all fire (skipped layers), wait
         for every collective and turn sums into means."""
         from . import functional
+        functional.flush_wgrad_window()         # (empty after a backward pass: the autograd engine's final callback has flushed it)
         functional.join_wgrad_stream()          # side-stream weight gradients land before anyone reads the slab
         if self.world <= 1:
             return

@@ -228,6 +228,8 @@ def _window_add(problems, ln, params):
     if w["problems"] and (w["tiles"] + tiles > WGRAD_WINDOW or len(w["problems"]) + len(problems) > TN_MAX_GROUP
                           or len(w["ln"]) + len(ln) > LN_MAX_BATCH):
         _window_launch()
+    if hasattr(_grad_sink, "hold"):
+        _grad_sink.hold(params)       # (autograd fires their post-accumulate hooks when the block's backward returns)
     w["problems"] += problems
     w["ln"] += ln
     w["params"] += [p for p in params if p is not None]

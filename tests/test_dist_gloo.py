@@ -89,6 +89,43 @@ def _worker(rank, world, port, q):
                 acc += g / world
         for got, want in zip([p.grad for p in net.parameters()], ref):
             assert torch.allclose(got, want, atol=1e-6), (rank, "sink")
+        # deferred delivery (functional's weight-gradient window): the fused backward only NOTES its weight gradient, tells the sink to
+        # hold() the parameter -- autograd's post-accumulate hook fires when the backward returns, with nothing written yet -- and the
+        # end of the backward pass writes all of them and calls param_ready().  No bucket may leave before that.
+        pending = []
+
+        class DeferredLinear(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w):
+                ctx.save_for_backward(x, w)
+                return x @ w.t()
+
+            @staticmethod
+            def backward(ctx, dy):
+                x, w = ctx.saved_tensors
+                if not pending:
+                    torch.autograd.Variable._execution_engine.queue_callback(deliver)
+                pending.append((w, dy, x))
+                red.hold([w])
+                return dy @ w, None
+
+        def deliver():
+            assert not any(red._launched), "a bucket left before its held members were written"
+            for w, dy, x in pending:
+                w.grad += dy.t() @ x
+                red.param_ready(w)
+            pending.clear()
+
+        red.zero_grad()
+        h = x
+        for i, lin in enumerate(lins):
+            h = DeferredLinear.apply(h, lin.weight) + lin.bias
+            h = torch.relu(h) if i < 2 else h
+        h.pow(2).mean().backward()
+        assert not pending and all(red._launched)          # the last param_ready completed the bucket: launched before finish()
+        red.finish()
+        for got, want in zip([p.grad for p in net.parameters()], ref):
+            assert torch.allclose(got, want, atol=1e-6), (rank, "deferred sink")
         m = reduce_scalar_mean(torch.tensor(float(rank)), world)
         assert float(m) == pytest.approx((world - 1) / 2)
         q.put((rank, "ok"))
