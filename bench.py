@@ -450,7 +450,8 @@ def main():
                     "gemm_ms_per_step": round(ms / nprobe, 3), "gemm_gflop_per_step": round(flops / nprobe / 1e9, 1)}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # (the CPU twin is the VOLO-D1 token-label step of the default workload; the other workloads report no CPU baseline)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("d1", "stages") and args.variant.startswith("volo_h"):
         threads = min(os.cpu_count() or 1, 64)
         cpu = cpu_baseline(args.variant, res, args.cpu_seconds, threads)
 

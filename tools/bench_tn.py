@@ -1,5 +1,6 @@
 """Weight-gradient (TN) group timing on the VOLO-D1 block shapes, operands rotated over > 256 MiB: tools/bench_tn.py [reps]
-Compares AP_GEMM_TN_8P=1 (csrc/gemm_tn8p.h) with =0 (128 x 128-tile kernel) -- run once per setting (the switch is read once)."""
+Compares AP_GEMM_TN_8P=1 (csrc/gemm_tn8p.h) with =0 (128 x 128-tile kernel) -- run once per setting (the switch is read once).
+Second table: the same problems of SIX transformer blocks in ONE launch (what functional's weight-gradient window issues), per block."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from autoprog_amd import ops
@@ -31,3 +32,18 @@ for name, (M, dims) in SHAPES.items():
     fl = sum(2.0 * M * n1 * n2 for n1, n2, _ in dims)
     by = sum(2.0 * M * (n1 + n2) for n1, n2, _ in dims)
     print("%-28s AP_GEMM_TN_8P=%s  %7.1f us  %6.0f TFLOP/s  %5.2f TB/s operands" % (name, os.environ.get("AP_GEMM_TN_8P", "1"), us, fl / us * 1e-6, by / us * 1e-6))
+
+# ---- six transformer blocks in one launch: 240 tiles, no token axis cut, plain read-add-stores (operands of every block distinct)
+M, dims = SHAPES["transformer block (C=384)"]
+for nblk in (1, 2, 3, 6):
+    sets = [sum((group(M, dims, 10 * s + b) for b in range(nblk)), []) for s in range(2)]
+    for s in sets: ops.gemm_tn_acc_grouped(s)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for r in range(reps): ops.gemm_tn_acc_grouped(sets[r % 2])
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    fl = nblk * sum(2.0 * M * n1 * n2 for n1, n2, _ in dims)
+    by = nblk * sum(2.0 * M * (n1 + n2) for n1, n2, _ in dims)
+    print("%d transformer block(s) per launch   %7.1f us = %6.1f us per block  %6.0f TFLOP/s  %5.2f TB/s operands" % (nblk, us, us / nblk, fl / us * 1e-6, by / us * 1e-6))
