@@ -33,7 +33,7 @@ txt = open("gpurun_out/%s_pmc_counters.txt" % R).read()
 blocks = re.split(r"\n(?=\S)", txt)
 fetch = write = n = 0.0
 for b in blocks:
-    if b.startswith("void k_gemm_nt<") or b.startswith("k_gemm_nt"):
+    if b.startswith("void k_gemm_nt<") or b.startswith("void k_gemm_nt_8p<") or b.startswith("k_gemm_nt_skinny"):
         mf = re.search(r"FETCH_SIZE\s+avg\s+([\d.]+)\s+over (\d+)", b); mw = re.search(r"WRITE_SIZE\s+avg\s+([\d.]+)", b)
         if mf and mw:
             k = int(mf.group(2)); fetch += float(mf.group(1)) * k; write += float(mw.group(1)) * k; n += k
