@@ -17,9 +17,17 @@ import torch.distributed as dist
 
 
 class GradientBucketReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, world_size=None, defer_mean=False):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, world_size=None, defer_mean=False, comm_dtype=None):
         """defer_mean: finish() leaves the all-reduced SUM in the slab and the consumer applies 1/world itself
-        (optim.FlatAdamWEma folds it into the fused update kernel via take_pending_scale(): no extra pass over the slab)."""
+        (optim.FlatAdamWEma folds it into the fused update kernel via take_pending_scale(): no extra pass over the slab).
+        comm_dtype: torch.bfloat16 (or AP_GRAD_COMM_DTYPE=bf16) sends every bucket as bf16 -- half the bytes per xGMI link; the slab
+        and the sum stay fp32 on each rank (the bucket is rounded once before the exchange, the exchanged sum is written back as fp32).
+        Default: fp32 buckets, the reference's arithmetic (ApexDDP / DDP all-reduce fp32 gradients, main_prog.py:538-550)."""
+        import os
+        if comm_dtype is None and os.environ.get("AP_GRAD_COMM_DTYPE", "").lower() in ("bf16", "bfloat16"):
+            comm_dtype = torch.bfloat16
+        self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
+        self._staged = []                  # (bucket range, bf16 copy) of the buckets in flight
         self.defer_mean = defer_mean
         self._pending_scale = 1.0
         self.params = [p for p in params if p.requires_grad]
@@ -109,7 +117,11 @@ class GradientBucketReducer:
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
-        self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        buf = self.flat[s:e]
+        if self.comm_dtype is not None:
+            buf = buf.to(self.comm_dtype)
+            self._staged.append((s, e, buf))
+        self._handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     # ------------------------------------------------------------------ step API
     def zero_grad(self):
@@ -121,6 +133,7 @@ class GradientBucketReducer:
         self._pending = [len(m) for (_, _, m) in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._handles = []
+        self._staged = []
         self._seen = set()
         self._held = set()
 
@@ -137,6 +150,9 @@ class GradientBucketReducer:
                 self._launch(b)
         for h in self._handles:
             h.wait()
+        for s, e, buf in self._staged:
+            self.flat[s:e].copy_(buf)
+        self._staged = []
         if self.defer_mean:
             self._pending_scale = 1.0 / self.world
         else:

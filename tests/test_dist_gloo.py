@@ -126,6 +126,16 @@ def _worker(rank, world, port, q):
         red.finish()
         for got, want in zip([p.grad for p in net.parameters()], ref):
             assert torch.allclose(got, want, atol=1e-6), (rank, "deferred sink")
+        # bf16 buckets (comm_dtype): half the bytes on the wire, fp32 slab; equal to the fp32 exchange within bf16 rounding of the buckets
+        red.remove()
+        red = GradientBucketReducer(list(net.parameters()), bucket_bytes=512, world_size=world, comm_dtype=torch.bfloat16)
+        torch.manual_seed(300 + rank)
+        red.zero_grad()
+        net(torch.randn(8, 16)).pow(2).mean().backward()
+        red.finish()
+        for got, want in zip([p.grad for p in net.parameters()], ref):
+            assert got.dtype == torch.float32 and torch.allclose(got, want, rtol=2e-2, atol=1e-3), (rank, "bf16 buckets")
+        assert any(not torch.equal(got, want) for got, want in zip([p.grad for p in net.parameters()], ref))
         m = reduce_scalar_mean(torch.tensor(float(rank)), world)
         assert float(m) == pytest.approx((world - 1) / 2)
         q.put((rank, "ok"))
