@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("AP_LIB_PATH") or os.path.join(_HERE, "libautoprog_hip
 
 class GemmEpilogue(Structure):
     _fields_ = [("bias", c_void_p), ("gelu", c_int), ("preact_out", c_void_p), ("dgelu_of", c_void_p),
-                ("row_scale", c_void_p), ("rows_per_scale", c_int), ("residual", c_void_p), ("ldr", c_int), ("mul_by", c_void_p)]
+                ("row_scale", c_void_p), ("rows_per_scale", c_int), ("residual", c_void_p), ("ldr", c_int), ("mul_by", c_void_p),
+                ("q8_out", c_void_p), ("q8_scale", c_void_p), ("q8_amax", c_void_p)]
 
 
 class TnProblem(Structure):
@@ -47,6 +48,7 @@ _SIGNATURES = {
     "ap_resize_bilinear_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ap_droppath_masks": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ap_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
+    "ap_layernorm_fwd_fp8": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "ap_layernorm_bwd_workspace": (ctypes.c_size_t, [_L, _I]),
     "ap_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, _P]),
     "ap_gemm_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, POINTER(GemmEpilogue), _P]),
@@ -86,6 +88,7 @@ _SIGNATURES["ap_conv7_s2d_wgrad"] = (_I, [_P, _P, _P, _I, _I, _I, _P, ctypes.c_s
 _SIGNATURES["ap_layernorm_bwd_partial"] = (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, POINTER(c_int), _P])
 _SIGNATURES["ap_layernorm_bwd_reduce_batched"] = (_I, [_P, _I, _P])
 _SIGNATURES["ap_quantize_fp8"] = (_I, [_P, _P, _L, _P, _P, _P])
+_SIGNATURES["ap_quantize_fp8_multi"] = (_I, [_P, _I, _P, _P, _P])
 _SIGNATURES["ap_gemm_nt_fp8"] = (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, POINTER(GemmEpilogue), _P])
 _SIGNATURES["ap_gemm_nt_patch"] = (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, POINTER(PatchMap), _I, _P])
 _SIGNATURES["ap_bn_relu_fwd_partials"] = (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P])

@@ -764,7 +764,26 @@ static void g8_pick(const G8Args& ga, const EpiArgs& ep, int grid, hipStream_t s
         default: g8_go<NT1, -1>(ga, ep, grid, st); break;
     }
 }
-static int g8_launch(int bn, const bf16_t* A, int lda, const bf16_t* B, int ldb, bf16_t* C, int ldc, int M, int N, int K, const EpiArgs& ep, hipStream_t st) {
+// the fp8 instantiations (ap_gemm_nt_fp8: the forward Linear layers of the configs[4] step): the flavours a transformer block's forward uses
+template <int NT1, int EF>
+static void g8_go_fp8(const G8Args& ga, const EpiArgs& ep, int grid, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_gemm_nt_8p<NT1, EF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS_BYTES); attr = true; (void)hipGetLastError(); }
+    hipLaunchKernelGGL((k_gemm_nt_8p<NT1, EF, true>), dim3(grid), dim3(512), G8_LDS_BYTES, st, ga, ep);
+}
+template <int NT1>
+static void g8_pick_fp8(const G8Args& ga, const EpiArgs& ep, int grid, hipStream_t st) {
+    switch (g8_flavour(ep)) {
+        case 0: g8_go_fp8<NT1, 0>(ga, ep, grid, st); break;
+        case G8_BIAS: g8_go_fp8<NT1, G8_BIAS>(ga, ep, grid, st); break;
+        case G8_BIAS | G8_GELU: g8_go_fp8<NT1, G8_BIAS | G8_GELU>(ga, ep, grid, st); break;
+        case G8_BIAS | G8_GELU | G8_RS: g8_go_fp8<NT1, G8_BIAS | G8_GELU | G8_RS>(ga, ep, grid, st); break;
+        case G8_BIAS | G8_RES: g8_go_fp8<NT1, G8_BIAS | G8_RES>(ga, ep, grid, st); break;
+        case G8_BIAS | G8_RS | G8_RES: g8_go_fp8<NT1, G8_BIAS | G8_RS | G8_RES>(ga, ep, grid, st); break;
+        default: g8_go_fp8<NT1, -1>(ga, ep, grid, st); break;
+    }
+}
+static int g8_launch(int bn, const bf16_t* A, int lda, const bf16_t* B, int ldb, bf16_t* C, int ldc, int M, int N, int K, const EpiArgs& ep, hipStream_t st, bool fp8 = false) {
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr;
@@ -775,7 +794,8 @@ static int g8_launch(int bn, const bf16_t* A, int lda, const bf16_t* B, int ldb,
     ga.tiles_n = (N + bn - 1) / bn; ga.ntiles = ((M + 255) / 256) * ga.tiles_n;
     const int cap = n_cu & ~7, want = (ga.ntiles + 7) & ~7;        // a multiple of 8: the kernel deals tiles per XCD label
     const int grid = want < cap ? want : cap;
-    if (bn == 192) g8_pick<1>(ga, ep, grid, st); else g8_pick<2>(ga, ep, grid, st);
+    if (fp8) { if (bn == 192) g8_pick_fp8<1>(ga, ep, grid, st); else g8_pick_fp8<2>(ga, ep, grid, st); }
+    else if (bn == 192) g8_pick<1>(ga, ep, grid, st); else g8_pick<2>(ga, ep, grid, st);
     return ap_check_launch();
 }
 
@@ -909,10 +929,20 @@ int ap_gemm_nt_fp8(const unsigned char* A, int lda, const unsigned char* B, int 
         ep.row_scale = epi->row_scale; ep.rows_per_scale = epi->rows_per_scale > 0 ? epi->rows_per_scale : 1;
         ep.residual = epi->residual; ep.ldr = epi->ldr;
         if (ep.residual && ep.ldr < N) return AP_ERR_SHAPE;
+        if (ep.gelu < 0 || ep.gelu > 2 || (ep.gelu && !ep.preact && ep.gelu == 2)) return AP_ERR_SHAPE;
+        ep.q8 = epi->q8_out; ep.q8_scale = epi->q8_scale; ep.q8_amax = epi->q8_amax;
+        if (ep.q8 && (!ep.q8_scale || !ep.gelu)) return AP_ERR_SHAPE;
     }
     (void)hipGetLastError();
+    // byte pairs: the kernels' element is 2 bytes.  The persistent 8-phase kernel where the bf16 launch of these dimensions would take it
+    // (K % 128 == 0 here: whole 128-byte K-tiles), the 128 x 128-tile kernel otherwise
+    if ((K & 127) == 0 && !ep.dgelu_of) {
+        const int bn8 = use_8p(M, N, K / 2, ldc, ep);
+        if (bn8) return g8_launch(bn8, reinterpret_cast<const bf16_t*>(A), lda / 2, reinterpret_cast<const bf16_t*>(B), ldb / 2, C, ldc, M, N, K / 2, ep,
+                                  (hipStream_t)stream, true);
+    }
+    if (ep.q8) return AP_ERR_UNSUPPORTED;            // the e4m3 side output exists in the 8-phase kernel's row phase only
     const int tm = (M + 127) / 128, tn = (N + 127) / 128, nt = tm * tn;
-    // byte pairs: the kernel's element is 2 bytes
     hipLaunchKernelGGL((k_gemm_nt<128, 128, 2, 2, false, 1, false, 0, true>), dim3(nt), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const bf16_t*>(A), lda / 2, reinterpret_cast<const bf16_t*>(B), ldb / 2, C, ldc, M, N, K / 2, tn, nt, ep);
     return ap_check_launch();

@@ -132,7 +132,21 @@ __host__ __device__ inline int g8_flavour(const EpiArgs& ep) {
 }
 
 // NT1: B part 1 holds NT1 16-column tiles per wave (1: 256 x 192 block tile, 2: 256 x 256).
-template <int NT1, int EF>
+// FP8: A and B hold OCP e4m3 bytes (configs[4]: "mixed MFMA fp8 GEMM"); the kernel is launched on byte PAIRS (lda, ldb, K in 2-byte units:
+// a K-tile is 128 bytes of a row either way), the two 16-byte fragments of a row feed one K = 128 MFMA (the same K set on both
+// operands), and the accumulators are multiplied by dq_a[0] * dq_b[0] before the epilogue.  Half the operand bytes per FLOP.
+// (one v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales on the two 16-byte fragments of a row's 128-byte K-tile: the double-rate
+// fp8 instruction of gfx950; the pair of v_mfma_f32_16x16x32_fp8_fp8 per fragment of the first version ran at the bf16 rate)
+typedef int __attribute__((ext_vector_type(8))) g8_i32x8;
+__device__ __forceinline__ f32x4 g8_mma_bf16(const u32x4& b, const u32x4& a, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(b), as_bf16x8(a), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 g8_mma_fp8(const u32x4& b0, const u32x4& b1, const u32x4& a0, const u32x4& a1, f32x4 c) {
+    const g8_i32x8 b = __builtin_bit_cast(g8_i32x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+    const g8_i32x8 a = __builtin_bit_cast(g8_i32x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b, a, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+template <int NT1, int EF, bool FP8 = false>
 __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     const bool has_bias = EF < 0 ? ep.bias != nullptr : (EF & G8_BIAS) != 0;
     const bool has_gelu = EF < 0 ? ep.gelu != 0 : (EF & G8_GELU) != 0;
@@ -140,6 +154,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     const bool has_rs = EF < 0 ? ep.row_scale != nullptr : (EF & G8_RS) != 0;
     const bool has_res = EF < 0 ? ep.residual != nullptr : (EF & G8_RES) != 0;
     const bool has_mul = EF < 0 ? ep.mul_by != nullptr : (EF & G8_MUL) != 0;
+    float qmx = 0.f;                              // FP8 with ep.q8: running max |output| of this lane, and the quantisation scale
+    const float qsc = (FP8 && ep.q8) ? ep.q8_scale[0] : 1.f;
     constexpr int WN = 32 + 16 * NT1, BN = 4 * WN;
     constexpr int VMN = 4 + NT1;                 // DMA instructions of the three parts in flight behind a counted wait
     constexpr int KS = 49152 + 8192 * NT1;       // bytes of a K-tile buffer (A h0 | A h1 | B part 0 | B part 1); the two buffers are adjacent
@@ -264,24 +280,40 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     };
     auto mma0_of = [&](int mh, const u32x4 (&a)[4][2]) {
         if (!(G8_ABL & 1)) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            if constexpr (FP8) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        acc0[mh][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(bf0[nt][kb]), as_bf16x8(a[mt][kb]), acc0[mh][mt][nt], 0, 0, 0);
+                        acc0[mh][mt][nt] = g8_mma_fp8(bf0[nt][0], bf0[nt][1], a[mt][0], a[mt][1], acc0[mh][mt][nt]);
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc0[mh][mt][nt] = g8_mma_bf16(bf0[nt][kb], a[mt][kb], acc0[mh][mt][nt]);
+            }
         }
     };
     auto mma1_of = [&](int mh, const u32x4 (&a)[4][2]) {
         if (!(G8_ABL & 1)) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            if constexpr (FP8) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT1; ++nt)
-                        acc1[mh][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(bf1[nt][kb]), as_bf16x8(a[mt][kb]), acc1[mh][mt][nt], 0, 0, 0);
+                        acc1[mh][mt][nt] = g8_mma_fp8(bf1[nt][0], bf1[nt][1], a[mt][0], a[mt][1], acc1[mh][mt][nt]);
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT1; ++nt)
+                            acc1[mh][mt][nt] = g8_mma_bf16(bf1[nt][kb], a[mt][kb], acc1[mh][mt][nt]);
+            }
         }
     };
     auto mma0 = [&](int mh) { __builtin_amdgcn_s_setprio(1); mma0_of(mh, af); __builtin_amdgcn_s_setprio(0); };
@@ -472,6 +504,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) { asm volatile("" : "+v"(in0[mh][mt])); asm volatile("" : "+v"(in1[mh][mt])); }
             }
+            const float dq = FP8 ? ep.dq_a[0] * ep.dq_b[0] : 1.f;
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int mh = pass / (NPASS / 2), mtb = (pass % (NPASS / 2)) * PASS_MT;    // this pass: tiles mt = mtb .. mtb + PASS_MT - 1 of half mh
@@ -489,6 +522,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                     for (int d = 0; d < NT1; ++d)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) w[4 * d + r] = acc1[mh][mt][d][r];
+                    if constexpr (FP8) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] *= dq;
+#pragma unroll
+                        for (int q = 0; q < 4 * NT1; ++q) w[q] *= dq;
+                    }
                     if (has_bias) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) v[q] += bias0[q];
@@ -549,6 +588,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                     const int id = it * 256 + wc * 64 + lane, row = id / CPR, p = id % CPR;
                     const int m = rbase + row, n = n0 + ((p ^ (row & 7)) << 3);
                     u32x4 x = xs[it];
+                    u32x2 q8v = {0u, 0u}; bool q8ok = false;
                     if (m < ga.M && n < ga.N) {
                         if (rowgelu) {
                             // x = the bf16-rounded pre-activation (bias included): the activation is applied to the rounded value; what is stored
@@ -571,9 +611,41 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                                 for (int q = 0; q < 8; ++q) f[q] = gelu_erf(f[q]) * rs;
                             }
                             x = pack8(f);
+                            if constexpr (FP8) {
+                                if (ep.q8) {           // the operand of the fp8 GEMM that consumes this activation (fc2), without a pass of its own
+                                    float r8[8];
+                                    unpack8(x, r8);
+                                    u32x2 o;
+#pragma unroll
+                                    for (int h2 = 0; h2 < 2; ++h2) {
+                                        float c4[4];
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) { qmx = fmaxf(qmx, fabsf(r8[4 * h2 + e])); c4[e] = fminf(fmaxf(r8[4 * h2 + e] * qsc, -448.f), 448.f); }
+                                        int w = 0;
+                                        w = __builtin_amdgcn_cvt_pk_fp8_f32(c4[0], c4[1], w, false);
+                                        w = __builtin_amdgcn_cvt_pk_fp8_f32(c4[2], c4[3], w, true);
+                                        o[h2] = (unsigned)w;
+                                    }
+                                    q8v = o; q8ok = true;
+                                }
+                            }
                         }
                         if (!(G8_ABL & 32)) st16(ga.C + (int64_t)m * ga.ldc + n, x);
                         else asm volatile("" :: "v"(x));
+                    }
+                    if constexpr (FP8) {
+                        if (ep.q8) {
+                            // 8 bytes per lane would leave as half lines: the lane with the even chunk of a pair takes its neighbour's 8 bytes
+                            // (the XOR swizzle keeps chunk pairs on lane pairs) and stores 16
+                            const unsigned n0lo = (unsigned)__shfl_xor((int)q8v[0], 1, 64), n0hi = (unsigned)__shfl_xor((int)q8v[1], 1, 64);
+                            const bool nok = __shfl_xor((int)q8ok, 1, 64) != 0;
+                            if (q8ok) {
+                                unsigned char* qp = ep.q8 + (int64_t)m * ga.ldc + n;
+                                if (nok && !(ga.ldc & 15)) {
+                                    if (!((n >> 3) & 1)) { u32x4 o4; o4[0] = q8v[0]; o4[1] = q8v[1]; o4[2] = n0lo; o4[3] = n0hi; st16(qp, o4); }
+                                } else *reinterpret_cast<u32x2*>(qp) = q8v;
+                            }
+                        }
                     }
                 }
                 if (pass + 1 < NPASS) G8_BAR();        // (the row reads were retired above)
@@ -582,4 +654,10 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
         }
     }
     G8_VM(0);
+    if constexpr (FP8) {
+        if (ep.q8 && ep.q8_amax) {
+            qmx = group_max<64>(qmx);
+            if (lane == 0 && __float_as_int(qmx) > *reinterpret_cast<volatile int*>(ep.q8_amax)) atomicMax(reinterpret_cast<int*>(ep.q8_amax), __float_as_int(qmx));
+        }
+    }
 }

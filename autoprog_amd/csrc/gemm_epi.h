@@ -30,6 +30,8 @@ struct EpiArgs {
     PatchMap pm;                // used by the PATCH instantiations of k_gemm_nt only
     const float* dq_a; const float* dq_b;     // fp8 instantiation: device scalars, accumulators are multiplied by dq_a[0] * dq_b[0] first
     const bf16_t* mul_by;       // out = v * mul_by[m,n] (ld = ldc): the stored activation derivative of a gelu = 2 forward
+    unsigned char* q8; const float* q8_scale; float* q8_amax;     // fp8 GELU launches of the 8-phase kernel: the output a second time as e4m3
+                                                                  // bytes [M, ldc], q8 = sat(out * q8_scale[0]), q8_amax[0] raised to max |out|
 };
 
 // epilogue of 8 consecutive output columns [n, n+8) of row m held in v[] (fp32 accumulators):

@@ -13,7 +13,12 @@ template <int V, int U>
 __global__ void __launch_bounds__(256)
 k_ln_fwd(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
          bf16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
-         int64_t rows, int C, int G, float eps) {
+         int64_t rows, int C, int G, float eps,
+         unsigned char* __restrict__ y8 = nullptr, const float* __restrict__ q_scale = nullptr, float* __restrict__ q_amax = nullptr) {
+    // y8 (nullable): the same output a second time as OCP e4m3 bytes, y8 = sat(bf16(y) * q_scale[0]), and q_amax[0] = max(q_amax[0],
+    // max |bf16(y)|) -- the operand of an fp8 GEMM without a quantisation pass of its own (ap_layernorm_fwd_fp8)
+    const float qs = y8 ? q_scale[0] : 1.f;
+    float qmx = 0.f;
     // U row-iterations are loaded before any is reduced (the per-row chain load -> shuffles -> store is latency bound)
     const int lane_in_group = threadIdx.x & (G - 1);
     const int groups_per_block = 256 / G;
@@ -84,10 +89,37 @@ k_ln_fwd(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const fl
                     float o8[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) o8[k] = (v[i][k] - mu) * rs * gam[i][k] + bet[i][k];
-                    st16(y + row * C + 8 * ch, pack8(o8));
+                    const u32x4 ob = pack8(o8);
+                    st16(y + row * C + 8 * ch, ob);
+                    if (y8) {
+                        float r8[8];
+                        unpack8(ob, r8);
+                        u32x2 o;
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            float c4[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { qmx = fmaxf(qmx, fabsf(r8[4 * h2 + e])); c4[e] = fminf(fmaxf(r8[4 * h2 + e] * qs, -448.f), 448.f); }
+                            int w = 0;
+                            w = __builtin_amdgcn_cvt_pk_fp8_f32(c4[0], c4[1], w, false);
+                            w = __builtin_amdgcn_cvt_pk_fp8_f32(c4[2], c4[3], w, true);
+                            o[h2] = (unsigned)w;
+                        }
+                        *reinterpret_cast<u32x2*>(y8 + row * C + 8 * ch) = o;
+                    }
                 }
             }
             if (lane_in_group == 0) { mean[row] = mu; rstd[row] = rs; }
+        }
+    }
+    if (y8 && q_amax) {                       // one atomic per workgroup, and only when it raises the value (see k_quantize_fp8)
+        __syncthreads();
+        qmx = group_max<64>(qmx);
+        if ((threadIdx.x & 63) == 0) sgb[threadIdx.x >> 6] = qmx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(sgb[0], sgb[1]), fmaxf(sgb[2], sgb[3]));
+            if (__float_as_int(m) > *reinterpret_cast<volatile int*>(q_amax)) atomicMax(reinterpret_cast<int*>(q_amax), __float_as_int(m));
         }
     }
 }
@@ -265,7 +297,13 @@ extern "C" {
 
 int ap_layernorm_fwd(const ap_bf16* x, const float* gamma, const float* beta, ap_bf16* y, float* mean, float* rstd,
                      int64_t rows, int C, float eps, ap_stream_t stream) {
+    return ap_layernorm_fwd_fp8(x, gamma, beta, y, nullptr, nullptr, nullptr, mean, rstd, rows, C, eps, stream);
+}
+
+int ap_layernorm_fwd_fp8(const ap_bf16* x, const float* gamma, const float* beta, ap_bf16* y, unsigned char* y8, const float* q_scale,
+                         float* q_amax, float* mean, float* rstd, int64_t rows, int C, float eps, ap_stream_t stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd) return AP_ERR_NULL;
+    if (y8 && !q_scale) return AP_ERR_NULL;
     if (C <= 0 || (C & 7)) return AP_ERR_SHAPE;
     if (C > 2048) return AP_ERR_UNSUPPORTED;
     if (rows <= 0) return AP_OK;
@@ -277,10 +315,10 @@ int ap_layernorm_fwd(const ap_bf16* x, const float* gamma, const float* beta, ap
     const size_t lds = (size_t)2 * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
-    if (V == 1) hipLaunchKernelGGL((k_ln_fwd<1, 4>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
-    else if (V == 2) hipLaunchKernelGGL((k_ln_fwd<2, 4>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
-    else if (V == 3) hipLaunchKernelGGL((k_ln_fwd<3, 2>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
-    else hipLaunchKernelGGL((k_ln_fwd<4, 2>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
+    if (V == 1) hipLaunchKernelGGL((k_ln_fwd<1, 4>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps, y8, q_scale, q_amax);
+    else if (V == 2) hipLaunchKernelGGL((k_ln_fwd<2, 4>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps, y8, q_scale, q_amax);
+    else if (V == 3) hipLaunchKernelGGL((k_ln_fwd<3, 2>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps, y8, q_scale, q_amax);
+    else hipLaunchKernelGGL((k_ln_fwd<4, 2>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps, y8, q_scale, q_amax);
     return ap_check_launch();
 }
 

@@ -313,6 +313,167 @@ def token_mask(keep01, n_tokens):
     return torch.cat([m, m.new_zeros(pad)]) if pad else m.contiguous()
 
 
+# ---------------------------------------------------------------- fp8 forward GEMMs (BASELINE configs[4]: "mixed MFMA fp8 GEMM")
+# With FP8_LINEAR (AP_FP8=1, bench.py --fp8) the four Linear layers of a transformer block run their FORWARD product on OCP e4m3
+# operands (ap_gemm_nt_fp8: the fp8 instantiation of the 8-phase kernel, fp32 accumulation, the usual fused epilogue); the backward
+# stays bf16 on the bf16 activations the block saves anyway.  Scaling is per tensor and DELAYED: an activation is quantised with
+# the scale derived from the amax its site saw in the previous step (ap_quantize_fp8 records the new amax while it quantises: one
+# pass, no reduction in front of it); a site's first use scales by its current amax.  Weights are quantised once per optimizer
+# step from their bf16 copies.  All scales live in three device vectors; nothing is read back to the host.
+FP8_LINEAR = os.environ.get("AP_FP8", "0") == "1"
+
+
+class _Fp8Scales:
+    CAP = 4096
+
+    def __init__(self):
+        self.amax = None
+        self.slots = {}
+        self.generation = None
+
+    def _init(self, device):
+        self.amax = torch.zeros(self.CAP, dtype=torch.float32, device=device)
+        self.scale = torch.ones(self.CAP, dtype=torch.float32, device=device)
+        self.dq = torch.ones(self.CAP, dtype=torch.float32, device=device)
+        self.slots = {}
+
+    def roll(self):
+        """scales of the coming step from the amax recorded since the last roll (sites that saw nothing keep theirs)"""
+        if self.amax is None:
+            return
+        seen = self.amax > 0
+        self.scale.copy_(torch.where(seen, ops.FP8_MAX / self.amax.clamp_min(1e-30), self.scale))
+        self.dq.copy_(1.0 / self.scale)
+        self.amax.zero_()
+
+    def site(self, key, x):
+        """-> slot index of the (per-tensor) quantisation site; a new site is scaled by the tensor in front of it"""
+        if self.amax is None or self.amax.device != x.device:
+            self._init(x.device)
+        if self.generation != _WeightBank.generation:          # an optimizer step has passed
+            self.generation = _WeightBank.generation
+            self.roll()
+        i = self.slots.get(key)
+        if i is None:
+            i = len(self.slots)
+            if i >= self.CAP:
+                raise AutoProgHipError("fp8: more than %d quantisation sites" % self.CAP)
+            self.slots[key] = i
+            amax = x.detach().abs().amax().float().clamp_min(1e-12)
+            self.scale[i:i + 1].copy_((ops.FP8_MAX / amax).reshape(1))
+            self.dq[i:i + 1].copy_((amax / ops.FP8_MAX).reshape(1))
+        return i
+
+    def quantize(self, key, x):
+        i = self.site(key, x)
+        return ops.quantize_fp8(x, self.scale[i:i + 1], self.amax[i:i + 1]), self.dq[i:i + 1]
+
+    def producer(self, key, device):
+        """(scale, amax, dq) of a site whose PRODUCER quantises (ops.layernorm_fwd(fp8=...)); None on the site's first use -- the
+        tensor to scale by does not exist yet, the caller quantises it afterwards through quantize()"""
+        if self.amax is None or self.amax.device != device or key not in self.slots:
+            return None
+        if self.generation != _WeightBank.generation:
+            self.generation = _WeightBank.generation
+            self.roll()
+        i = self.slots[key]
+        return self.scale[i:i + 1], self.amax[i:i + 1], self.dq[i:i + 1]
+
+
+fp8_scales = _Fp8Scales()
+
+
+class _Fp8Weights:
+    """e4m3 copies of the Linear weights.  A weight is registered (and scaled by its current amax) at its first use; after that all
+    registered weights are re-quantised together, once per optimizer step, in ONE launch (ops.quantize_fp8_multi) from the bf16
+    copies the weight bank holds, with delayed scales like the activations."""
+
+    def __init__(self):
+        self.items = []               # (parameter, slot, persistent e4m3 buffer)
+        self.table = None             # device job table + the source pointers it was built from
+        self.table_src = None
+
+    def get(self, w):
+        key = (w.data_ptr(), w._version, _WeightBank.generation)
+        ent = w.__dict__.get("_ap_fp8")
+        if ent is not None and ent[0] == key:
+            return ent[1], ent[2]
+        if ent is None or ent[3] is not self:
+            wb = bank.get(w)
+            w8, dq = fp8_scales.quantize(("w", id(w)), wb)
+            self.items.append((w, fp8_scales.slots[("w", id(w))], w8))
+            w._ap_fp8 = (key, w8, dq, self)
+            return w8, dq
+        self.requantize()
+        ent = w._ap_fp8
+        return ent[1], ent[2]
+
+    def requantize(self):
+        import numpy as np
+        if not self.items:
+            return
+        sc = fp8_scales
+        sc.site(("w", id(self.items[0][0])), bank.get(self.items[0][0]))          # rolls the scales when an optimizer step has passed
+        srcs = [bank.get(w) for (w, _, _) in self.items]
+        ptrs = tuple(t.data_ptr() for t in srcs)
+        if self.table is None or self.table_src != ptrs:
+            tab = np.zeros((len(self.items), 4), dtype=np.int64)                   # ap_fp8_job: x, y, n, (slot, pad)
+            for r, ((w, slot, w8), t) in enumerate(zip(self.items, srcs)):
+                tab[r] = (t.data_ptr(), w8.data_ptr(), t.numel(), slot)
+            self.table = torch.from_numpy(tab).to(srcs[0].device)
+            self.table_src = ptrs
+        ops.quantize_fp8_multi(self.table, len(self.items), sc.scale, sc.amax)
+        for (w, slot, w8) in self.items:
+            w._ap_fp8 = ((w.data_ptr(), w._version, _WeightBank.generation), w8, sc.dq[slot:slot + 1], self)
+
+
+fp8_weights = _Fp8Weights()
+
+
+def _fp8_weight(w):
+    return fp8_weights.get(w)
+
+
+def reset_fp8_state():
+    """forget every quantisation site and weight copy (another model in the same process)"""
+    global fp8_scales, fp8_weights
+    fp8_scales = _Fp8Scales()
+    fp8_weights = _Fp8Weights()
+
+
+def _fp8_ok(x, w):
+    return FP8_LINEAR and x.shape[1] % 16 == 0 and w.shape[1] == x.shape[1]
+
+
+def _linear_fwd(x, w, x8=None, emit_for=None, **kw):
+    """y = epilogue(x W^T): bf16, or e4m3 operands under FP8_LINEAR (the K of every VOLO / DeiT Linear is a multiple of 16);
+    x8 = (bytes, dq): the producer of x has quantised it already.  emit_for = the weight of the Linear that consumes y (GELU launches):
+    -> (y, (y8, dq) or None), the e4m3 operand of that Linear from this launch's epilogue where the kernel can"""
+    if _fp8_ok(x, w):
+        x8, dq_x = x8 if x8 is not None else fp8_scales.quantize(("x", id(w)), x)
+        w8, dq_w = _fp8_weight(w)
+        if emit_for is not None:
+            site = fp8_scales.producer(("x", id(emit_for)), x.device)
+            if site is not None and kw.get("gelu") and ops.gemm_nt_fp8_emits(x.shape[0], w.shape[0], x.shape[1]):
+                y, y8 = ops.gemm_nt_fp8(x8, w8, dq_x, dq_w, q8=(site[0], site[1]), **kw)
+                return y, (y8, site[2])
+            return ops.gemm_nt_fp8(x8, w8, dq_x, dq_w, **kw), None
+        return ops.gemm_nt_fp8(x8, w8, dq_x, dq_w, **kw)
+    y = ops.gemm_nt(x, bank.get(w), **kw)
+    return (y, None) if emit_for is not None else y
+
+
+def _ln_fwd_for(x, gw, gb, eps, w):
+    """LayerNorm whose output feeds the Linear with weight w: under FP8_LINEAR the kernel also emits the e4m3 operand"""
+    if _fp8_ok(x, w):
+        site = fp8_scales.producer(("x", id(w)), x.device)
+        if site is not None:
+            y, m, r, y8 = ops.layernorm_fwd(x, gw, gb, eps, fp8=(site[0], site[1]))
+            return y, m, r, (y8, site[2])
+    y, m, r = ops.layernorm_fwd(x, gw, gb, eps)
+    return y, m, r, None
+
+
 # ----------------------------------------------------------------------- transformer block
 class TransformerBlockFn(torch.autograd.Function):
     """x -> x + rs1*(proj(mhsa(qkv(LN1 x)))) -> + rs2*(fc2(gelu(fc1(LN2 .))))
@@ -341,14 +502,14 @@ class TransformerBlockFn(torch.autograd.Function):
             k1 = (rs1 != 0).float()
         if rs2 is not None and k2 is None:
             k2 = (rs2 != 0).float()
-        xn1, m1, r1 = ops.layernorm_fwd(x2, n1w, n1b, eps)
-        qkv = ops.gemm_nt(xn1, bank.get(qkv_w), bias=qkv_b)
+        xn1, m1, r1, xq = _ln_fwd_for(x2, n1w, n1b, eps, qkv_w)
+        qkv = _linear_fwd(xn1, qkv_w, x8=xq, bias=qkv_b)
         o, lse = ops.mhsa_fwd(qkv, B, N, heads, scale, out_row_scale=k1)                       # rows of dropped samples: zeros
-        x1 = ops.gemm_nt(o, bank.get(proj_w), bias=proj_b, row_scale=rs1, rows_per_scale=N, residual=x2)
-        xn2, m2, r2 = ops.layernorm_fwd(x1, n2w, n2b, eps)
+        x1 = _linear_fwd(o, proj_w, bias=proj_b, row_scale=rs1, rows_per_scale=N, residual=x2)
+        xn2, m2, r2, xq = _ln_fwd_for(x1, n2w, n2b, eps, fc1_w)
         h = torch.empty((B * N, fc1_w.shape[0]), dtype=BF16, device=x.device)
-        a = ops.gemm_nt(xn2, bank.get(fc1_w), bias=fc1_b, gelu=True, preact_out=h, preact_grad=STORE_GELU_GRAD, row_scale=k2, rows_per_scale=N)
-        y = ops.gemm_nt(a, bank.get(fc2_w), bias=fc2_b, row_scale=rs2, rows_per_scale=N, residual=x1)
+        a, aq = _linear_fwd(xn2, fc1_w, x8=xq, emit_for=fc2_w, bias=fc1_b, gelu=True, preact_out=h, preact_grad=STORE_GELU_GRAD, row_scale=k2, rows_per_scale=N)
+        y = _linear_fwd(a, fc2_w, x8=aq, bias=fc2_b, row_scale=rs2, rows_per_scale=N, residual=x1)
         if rs1 is not None and tm1 is None:
             tm1 = token_mask(k1, N)
         if rs2 is not None and tm2 is None:

@@ -82,13 +82,22 @@ def droppath_masks(uniform, keep, tokens=0):
 
 
 # -------------------------------------------------------------------------------- layernorm
-def layernorm_fwd(x, gamma, beta, eps):
+def layernorm_fwd(x, gamma, beta, eps, fp8=None):
+    """-> (y, mean, rstd); fp8 = (scale, amax) device scalars: -> (y, mean, rstd, y8) with y8 = e4m3 bytes of y * scale[0] and
+    amax[0] raised to max |y| (what quantize_fp8(y, scale, amax) returns, without its pass over y)"""
     _req(x, BF16, "x"); _req(gamma, torch.float32, "gamma"); _req(beta, torch.float32, "beta")
     C = x.shape[-1]
     rows = x.numel() // C
     y = torch.empty_like(x)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    if fp8 is not None:
+        scale, amax = fp8
+        y8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        check(lib.ap_layernorm_fwd_fp8(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), y8.data_ptr(), scale.data_ptr(),
+                                       amax.data_ptr() if amax is not None else None, mean.data_ptr(), rstd.data_ptr(),
+                                       rows, C, float(eps), _stream()), "ap_layernorm_fwd_fp8")
+        return y, mean, rstd, y8
     check(lib.ap_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                rows, C, float(eps), _stream()), "ap_layernorm_fwd")
     return y, mean, rstd
@@ -169,14 +178,28 @@ def quantize_fp8(x, scale, amax=None):
     return y
 
 
+def quantize_fp8_multi(table, njobs, scales, amax):
+    """table: int64 [njobs, 4] device tensor of ap_fp8_job records (x pointer, y pointer, n, slot); one launch for all of them"""
+    _req(table, torch.int64, "table"); _req(scales, torch.float32, "scales")
+    check(lib.ap_quantize_fp8_multi(table.data_ptr(), int(njobs), scales.data_ptr(), amax.data_ptr() if amax is not None else None, _stream()),
+          "ap_quantize_fp8_multi")
+
+
 def quantize_fp8_now(x):
     """current scaling (one extra pass for the amax): -> (bytes, dequantisation factor as a device scalar)"""
     amax = x.abs().amax().float().clamp_min(1e-12).reshape(1)
     return quantize_fp8(x, (FP8_MAX / amax).contiguous()), (amax / FP8_MAX).contiguous()
 
 
-def gemm_nt_fp8(a8, b8, dq_a, dq_b, n=None, bias=None, gelu=False, preact_out=None, residual=None, row_scale=None, rows_per_scale=1):
-    """out[M, :n] = epilogue(dq_a * dq_b * a8 @ b8[:n]^T): a8 [M,K], b8 [>=n,K] uint8 e4m3 bytes (K % 16 == 0), bf16 output"""
+def gemm_nt_fp8_emits(M, N, K):
+    """can this launch also emit its GELU output as e4m3 (q8)?  -- the 8-phase kernel's launches: see use_8p() in csrc/gemm.hip"""
+    return K % 128 == 0 and M >= 4096 and N % 8 == 0 and (N >= 1024 or N % 192 == 0 or (N % 256 == 0 and N >= 192)) and os.environ.get("AP_GEMM_8P", "1") != "0"
+
+
+def gemm_nt_fp8(a8, b8, dq_a, dq_b, n=None, bias=None, gelu=False, preact_out=None, residual=None, row_scale=None, rows_per_scale=1,
+                preact_grad=False, q8=None):
+    """out[M, :n] = epilogue(dq_a * dq_b * a8 @ b8[:n]^T): a8 [M,K], b8 [>=n,K] uint8 e4m3 bytes (K % 16 == 0), bf16 output;
+    the epilogue arguments as for gemm_nt.  q8 = (scale, amax) with gelu: -> (out, out8), out8 the e4m3 bytes of out * scale[0]"""
     _req(a8, torch.uint8, "a8"); _req(b8, torch.uint8, "b8")
     M, K = a8.shape
     n = b8.shape[0] if n is None else n
@@ -184,7 +207,7 @@ def gemm_nt_fp8(a8, b8, dq_a, dq_b, n=None, bias=None, gelu=False, preact_out=No
     out = torch.empty((M, ldc), dtype=BF16, device=a8.device)
     epi = GemmEpilogue()
     epi.bias = bias.data_ptr() if bias is not None else None
-    epi.gelu = 1 if gelu else 0
+    epi.gelu = (2 if preact_grad else 1) if gelu else 0
     epi.preact_out = preact_out.data_ptr() if preact_out is not None else None
     epi.dgelu_of = None
     epi.mul_by = None
@@ -192,9 +215,13 @@ def gemm_nt_fp8(a8, b8, dq_a, dq_b, n=None, bias=None, gelu=False, preact_out=No
     epi.rows_per_scale = int(rows_per_scale)
     epi.residual = residual.data_ptr() if residual is not None else None
     epi.ldr = residual.shape[1] if residual is not None else 0
+    out8 = None
+    if q8 is not None:
+        out8 = torch.empty((M, ldc), dtype=torch.uint8, device=a8.device)
+        epi.q8_out, epi.q8_scale, epi.q8_amax = out8.data_ptr(), q8[0].data_ptr(), (q8[1].data_ptr() if q8[1] is not None else None)
     check(lib.ap_gemm_nt_fp8(a8.data_ptr(), K, b8.data_ptr(), b8.shape[1], out.data_ptr(), ldc, M, n, K, dq_a.data_ptr(), dq_b.data_ptr(),
                              ctypes.byref(epi), _stream()), "ap_gemm_nt_fp8")
-    return out
+    return out if q8 is None else (out, out8)
 
 
 def gemm_tn_acc(a, b, c, n1=None, n2=None, colsum=None):

@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--variant", default="volo_h12_l18")
     ap.add_argument("--workload", default="d1", choices=["d1", "stages", "d5", "deit_base"],
                     help="d5: BASELINE configs[4] in bf16 -- VOLO-D5 at 448 px (use --batch 8..16); not the default line")
+    ap.add_argument("--fp8", action="store_true",
+                    help="d5 workload: the forward Linear GEMMs of the transformer blocks on e4m3 operands (configs[4] 'mixed MFMA fp8 GEMM'); "
+                         "delayed per-tensor scaling, bf16 backward.  Never the default line: the headline metric is bf16")
     ap.add_argument("--search-mix", action="store_true", help="stages workload: uniform random (l, r) per step (supernet search)")
     ap.add_argument("--dense-target", action="store_true",
                     help="feed the token-label target as the dense fp32 [B,1000,2+N] tensor (default: the top-5 label maps it is built from; the CE "
@@ -278,6 +281,9 @@ def main():
         args.variant, args.res = "deit_h12_l12", 224
         model = create_model("model_variant", variant="deit_h12_l12", drop_path_rate=0.1).to(dev).train()
     elif args.workload == "d5":
+        if args.fp8:
+            from autoprog_amd import functional as AF
+            AF.FP8_LINEAR = True
         args.variant, args.res = "volo_d5", 448
         if args.batch == 128:
             args.batch = 16
@@ -465,14 +471,17 @@ def main():
             wl = ("BASELINE.json configs[2]: %s supernet over the AutoProg stages (l,r) = %s, %s, batch %d, on-device resize from %d px"
                   % (args.variant, [(s[0], s[1]) for s in STAGES], "uniform random (l,r) per step" if args.search_mix else "a quarter of the steps each", B, res))
         else:
-            wl = ("BASELINE.json configs[4] in bf16 (no fp8): volo_d5 448px token-label training step, batch %d" % B if args.workload == "d5"
+            wl = (("BASELINE.json configs[4]: volo_d5 448px token-label training step, batch %d; " % B) +
+                  ("forward Linear GEMMs of the transformer blocks on e4m3 operands (fp32 accumulate, delayed per-tensor scaling), everything else bf16"
+                   if args.fp8 else "in bf16 (no fp8)") if args.workload == "d5"
                   else "BASELINE.json configs[1]: %s (VOLO-D1) %dpx token-label training step" % (args.variant, res))
         metric = ("images/sec/GPU (fwd+bwd) VOLO-D5 448px token-label step" if args.workload == "d5"
                   else "images/sec/GPU (fwd+bwd) DeiT-Base AutoProg search-mix step" if args.workload == "deit_base"
                   else "images/sec/GPU (fwd+bwd) VOLO-D1 224px AutoProg step")
         line = {"metric": metric, "value": round(value, 2), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "fp8 (e4m3 forward GEMMs) / bf16" if (args.fp8 and args.workload == "d5") else "bf16", "data": "synthetic",
                 "value_semantics": "whole-job aggregate over n_gpus (per-GPU rate in images_per_sec_per_gpu)",
                 "images_per_sec_per_gpu": round(value / world, 2),
                 "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "allreduce_ms_standalone": None if allreduce_ms is None else round(allreduce_ms, 3),

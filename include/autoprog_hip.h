@@ -60,6 +60,10 @@ int ap_droppath_masks(const float* uniform, const float* keep, float* factor, fl
 /* ---- LayerNorm (nn.LayerNorm: models/volo.py:122,131,213,221,290,297,550) ------------- */
 int ap_layernorm_fwd(const ap_bf16* x, const float* gamma, const float* beta, ap_bf16* y,
                      float* mean, float* rstd, int64_t rows, int C, float eps, ap_stream_t stream);
+/* the same with a second copy of the output as OCP e4m3 bytes for an fp8 GEMM (configs[4]): y8 = sat(y * q_scale[0]),
+ * q_amax[0] = max(q_amax[0], max |y|) (nullable) -- what ap_quantize_fp8 would produce from y, without its pass over y */
+int ap_layernorm_fwd_fp8(const ap_bf16* x, const float* gamma, const float* beta, ap_bf16* y, unsigned char* y8, const float* q_scale,
+                         float* q_amax, float* mean, float* rstd, int64_t rows, int C, float eps, ap_stream_t stream);
 /* dx = dres + d(LN)/dx ; dgamma/dbeta are ACCUMULATED (+=).  `workspace` (device, caller-owned,
  * >= ap_layernorm_bwd_workspace() bytes) holds per-workgroup partial sums for the deterministic
  * two-pass column reduction. */
@@ -104,12 +108,20 @@ typedef struct ap_gemm_epilogue {
     const ap_bf16* mul_by;      /* out = v * mul_by[m,n] (ld = ldc), applied where dgelu_of is: the backward of gelu = 2, whose forward stored
                                  * gelu'(h) -- the only thing the backward needs of h (autograd of models/volo.py:157) -- so that it is a
                                  * multiplication instead of ~18 instructions per element; not together with dgelu_of.  (ABI version 3) */
+    unsigned char* q8_out;      /* ap_gemm_nt_fp8 with gelu only (ABI version 4): the output a second time as OCP e4m3 bytes [M, ldc] --     */
+    const float* q8_scale;      /* q8_out = sat(out * q8_scale[0]), q8_amax[0] = max(q8_amax[0], max |out|) (nullable) -- the operand of the */
+    float* q8_amax;             /* fp8 GEMM that consumes this activation, without a quantisation pass.  Launches of the 8-phase kernel only */
+                                /* (M >= 4096, K % 128 == 0, N as for ap_gemm_nt): AP_ERR_UNSUPPORTED otherwise; ap_gemm_nt ignores them.   */
 } ap_gemm_epilogue;
 int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C, int ldc,
                int M, int N, int K, const ap_gemm_epilogue* epi, ap_stream_t stream);
 /* ---- fp8 forward GEMM (BASELINE configs[4] "mixed MFMA fp8 GEMM"): OCP e4m3 operands, fp32 accumulation, bf16 output.
  * y = sat(x * scale[0]) -> e4m3, n % 16 == 0; amax (nullable): amax[0] = max(amax[0], max |x|) for the next step's scale */
 int ap_quantize_fp8(const ap_bf16* x, unsigned char* y, int64_t n, const float* scale, float* amax, ap_stream_t stream);
+/* the same for several tensors in ONE launch (the Linear weights of a model, once per optimizer step): `jobs_device` is a DEVICE array;
+ * job j is scaled by scales[slot] and raises amax[slot] (n % 16 == 0) */
+typedef struct ap_fp8_job { const ap_bf16* x; unsigned char* y; int64_t n; int slot; int pad_; } ap_fp8_job;
+int ap_quantize_fp8_multi(const ap_fp8_job* jobs_device, int njobs, const float* scales, float* amax, ap_stream_t stream);
 /* C = epi(dq_a[0] * dq_b[0] * A8 . B8^T): A8 [M,K], B8 [N,K] e4m3 bytes (K, lda, ldb multiples of 16), dq_* device scalars (1/scale);
  * same epilogue as ap_gemm_nt */
 int ap_gemm_nt_fp8(const unsigned char* A, int lda, const unsigned char* B, int ldb, ap_bf16* C, int ldc, int M, int N, int K,

@@ -44,7 +44,7 @@ def dev(t):
 # ------------------------------------------------------------------------------------------
 def test_abi_loaded(ops):
     from autoprog_amd._lib import lib, LIB_PATH
-    assert lib.ap_abi_version() == 3
+    assert lib.ap_abi_version() == 4
     assert LIB_PATH.endswith("libautoprog_hip.so")
 
 
@@ -769,12 +769,13 @@ def test_conv7_s2d_fwd_wgrad_vs_torch_fp32(B, R, src):
     assert rel(dw - 0.25, refdw) < 1e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 384, 1152), (4096, 1152, 384), (300, 200, 192)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 384, 1152), (4096, 1152, 384), (300, 200, 192), (4352, 384, 1152), (4200, 768, 768), (4100, 3072, 768)])
 def test_gemm_nt_fp8_vs_dequantised_reference(M, N, K):
     """ap_quantize_fp8 + ap_gemm_nt_fp8 (BASELINE configs[4] 'mixed MFMA fp8 GEMM'): (a) the quantiser against torch's e4m3 cast of the
     clamped, scaled input (bit exact) and its amax; (b) the GEMM against an fp32 matmul of the SAME dequantised bytes (the only
     differences left are the fp32 summation order and the bf16 store: 4e-3 rel-L2), with bias + GELU + stored pre-activation and
-    with a residual; (c) against the un-quantised fp32 product: 6e-2 (e4m3 keeps 3 mantissa bits)."""
+    with a residual; (c) against the un-quantised fp32 product: 6e-2 (e4m3 keeps 3 mantissa bits).  M >= 4096 with K % 128 == 0: the
+    fp8 instantiations of the persistent 8-phase kernel (256 x 192 / 256 x 256 tiles), the flavours of a transformer block's forward."""
     import torch.nn.functional as F
     from autoprog_amd import ops
     torch.manual_seed(M + N)
@@ -800,3 +801,49 @@ def test_gemm_nt_fp8_vs_dequantised_reference(M, N, K):
     y2 = ops.gemm_nt_fp8(a8, w8, dq_a, dq_w, residual=res)[:, :N]
     assert rel(y2, a_dq @ w_dq.t() + res[:, :N].float()) < 4e-3
     assert rel(ops.gemm_nt_fp8(a8, w8, dq_a, dq_w)[:, :N], a.float() @ w.float().t()) < 6e-2
+    # bias + DropPath row scale + residual (proj / fc2), and GELU with the stored derivative + row scale (fc1)
+    rps = max(1, M // 2)
+    rs = torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9], device="cuda")
+    y3 = ops.gemm_nt_fp8(a8, w8, dq_a, dq_w, bias=bias, row_scale=rs, rows_per_scale=rps, residual=res)[:, :N]
+    assert rel(y3, pre * rs.repeat_interleave(rps)[:M, None] + res[:, :N].float()) < 4e-3
+    gp = torch.empty_like(h)
+    y4 = ops.gemm_nt_fp8(a8, w8, dq_a, dq_w, bias=bias, gelu=True, preact_out=gp, preact_grad=True, row_scale=rs, rows_per_scale=rps)[:, :N]
+    hb = pre.to(torch.bfloat16).float().requires_grad_(True)
+    F.gelu(hb).sum().backward()
+    assert rel(gp[:, :N], hb.grad) < 4e-3
+    assert rel(y4, F.gelu(hb.detach()) * rs.repeat_interleave(rps)[:M, None]) < 4e-3
+    if ops.gemm_nt_fp8_emits(M, N, K):
+        # the GELU output a second time as e4m3 (the operand of the next fp8 GEMM): bit-equal to the quantiser run on the bf16 output
+        qs, qa, qa_ref = torch.tensor([93.0], device="cuda"), torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+        y5, y5_8 = ops.gemm_nt_fp8(a8, w8, dq_a, dq_w, bias=bias, gelu=True, preact_out=gp, preact_grad=True, row_scale=rs, rows_per_scale=rps, q8=(qs, qa))
+        assert torch.equal(y5[:, :N], y4)
+        assert torch.equal(y5_8[:, :N], ops.quantize_fp8(y5, qs, qa_ref)[:, :N]) and float(qa) == float(y5[:, :N].float().abs().max())
+
+
+def test_fp8_producers_match_the_quantiser(ops):
+    """the two ways an fp8 operand is made without a pass of its own: (a) ap_layernorm_fwd_fp8 -- the LayerNorm's e4m3 copy and amax are
+    bit-equal to ap_quantize_fp8 of its bf16 output; (b) ap_quantize_fp8_multi -- several tensors (the Linear weights of a model) in one
+    launch, each with its own scale / amax slot, bit-equal to one ap_quantize_fp8 per tensor"""
+    for rows, C in [(777, 384), (300, 768), (64, 192)]:
+        x = dev(rnd(rows, C, scale=2.0, seed=rows))
+        g = dev(torch.randn(C, generator=torch.Generator().manual_seed(1)) * 0.3 + 1)
+        b = dev(torch.randn(C, generator=torch.Generator().manual_seed(2)) * 0.3)
+        scale = torch.tensor([37.5], device="cuda")
+        amax = torch.zeros(1, device="cuda")
+        y, mean, rstd, y8 = ops.layernorm_fwd(x, g, b, 1e-5, fp8=(scale, amax))
+        y0, mean0, rstd0 = ops.layernorm_fwd(x, g, b, 1e-5)
+        assert torch.equal(y, y0) and torch.equal(mean, mean0) and torch.equal(rstd, rstd0)
+        amax_ref = torch.zeros(1, device="cuda")
+        assert torch.equal(y8, ops.quantize_fp8(y0, scale, amax_ref)) and float(amax) == float(amax_ref) == float(y0.float().abs().max())
+    sizes = [(1152, 384), (384, 384), (64, 16), (3072, 768)]
+    ws = [dev(rnd(n, k, scale=0.05 * (i + 1), seed=10 + i)) for i, (n, k) in enumerate(sizes)]
+    scales = torch.tensor([100.0, 300.0, 50.0, 1000.0, 7.0], device="cuda")
+    amax = torch.zeros(5, device="cuda")
+    outs = [torch.empty(w.shape, dtype=torch.uint8, device="cuda") for w in ws]
+    slots = [3, 0, 4, 1]
+    table = torch.tensor([[w.data_ptr(), o.data_ptr(), w.numel(), s] for w, o, s in zip(ws, outs, slots)], dtype=torch.int64, device="cuda")
+    ops.quantize_fp8_multi(table, len(ws), scales, amax)
+    for w, o, s in zip(ws, outs, slots):
+        a1 = torch.zeros(1, device="cuda")
+        assert torch.equal(o, ops.quantize_fp8(w, scales[s:s + 1].contiguous(), a1)) and float(amax[s]) == float(a1)
+    assert float(amax[2]) == 0.0

@@ -12,8 +12,8 @@ def timeit(fns, n=40):
     for i in range(n): fns[i % len(fns)]()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
-R = 12                                                   # operand copies: > 600 MB in rotation
-for (M, N, K, what) in [(25088, 1152, 384, "qkv"), (25088, 1152, 384, "fc1+gelu"), (25088, 384, 1152, "fc2+res"), (25088, 384, 384, "proj+res"), (100352, 576, 192, "o.fc1+gelu")]:
+R = 6                                                   # operand copies: > 600 MB in rotation
+for (M, N, K, what) in [(12544, 2304, 768, "d5 qkv"), (12544, 3072, 768, "d5 fc1+gelu"), (12544, 768, 3072, "d5 fc2+res"), (12544, 768, 768, "d5 proj+res"), (25088, 1152, 384, "qkv"), (25088, 1152, 384, "fc1+gelu"), (25088, 384, 1152, "fc2+res"), (25088, 384, 384, "proj+res"), (100352, 576, 192, "o.fc1+gelu")]:
     a = [torch.randn(M, K, device="cuda").to(torch.bfloat16) for _ in range(R)]
     w = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
     res = torch.randn(M, N, device="cuda").to(torch.bfloat16)
