@@ -89,6 +89,7 @@ _SIGNATURES["ap_layernorm_bwd_partial"] = (_I, [_P, _P, _P, _P, _P, _P, _P, _L, 
 _SIGNATURES["ap_layernorm_bwd_reduce_batched"] = (_I, [_P, _I, _P])
 _SIGNATURES["ap_quantize_fp8"] = (_I, [_P, _P, _L, _P, _P, _P])
 _SIGNATURES["ap_quantize_fp8_multi"] = (_I, [_P, _I, _P, _P, _P])
+_SIGNATURES["ap_mhsa_fwd_fp8"] = (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P])
 _SIGNATURES["ap_gemm_nt_fp8"] = (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, POINTER(GemmEpilogue), _P])
 _SIGNATURES["ap_gemm_nt_patch"] = (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, POINTER(PatchMap), _I, _P])
 _SIGNATURES["ap_bn_relu_fwd_partials"] = (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P])

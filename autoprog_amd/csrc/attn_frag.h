@@ -66,7 +66,7 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
 
 // key/query-blocked kernels for long sequences and head_dim 48 (mhsa_flash.hip)
 int ap_mhsa_flash_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N, int heads, int hd, float scale, const float* out_row_scale,
-                      hipStream_t s);
+                      hipStream_t s, unsigned char* out8 = nullptr, const float* q_scale = nullptr, float* q_amax = nullptr);
 size_t ap_mhsa_flash_bwd_ws(int B, int N, int heads);
 int ap_mhsa_flash_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, int B, int N, int heads, int hd,
                       float scale, float* delta, hipStream_t s);

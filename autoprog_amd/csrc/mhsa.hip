@@ -842,6 +842,15 @@ static bool mhsa_use_flash(int N, int hd) {
 
 extern "C" {
 
+int ap_mhsa_fwd_fp8(const ap_bf16* qkv, ap_bf16* out, unsigned char* out8, const float* q_scale, float* q_amax, float* lse, int B, int N,
+                    int heads, int hd, float scale, const float* out_row_scale, ap_stream_t stream) {
+    if (!qkv || !out || !lse || !out8 || !q_scale) return AP_ERR_NULL;
+    if (B <= 0 || N <= 0 || heads <= 0) return AP_ERR_SHAPE;
+    if (hd != 32 && hd != 48 && hd != 64) return AP_ERR_UNSUPPORTED;
+    if (!mhsa_use_flash(N, hd)) return AP_ERR_UNSUPPORTED;          // the e4m3 side output exists in the blocked kernel only
+    return ap_mhsa_flash_fwd(qkv, out, lse, B, N, heads, hd, scale, out_row_scale, (hipStream_t)stream, out8, q_scale, q_amax);
+}
+
 int ap_mhsa_fwd(const ap_bf16* qkv, ap_bf16* out, float* lse, int B, int N, int heads, int hd, float scale, const float* out_row_scale,
                 ap_stream_t stream) {
     if (!qkv || !out || !lse) return AP_ERR_NULL;

@@ -65,7 +65,10 @@ __device__ __forceinline__ void own_frag(bf16x8* f, const bf16_t* base, int64_t 
 template <int HDP, int DT>
 __global__ void __launch_bounds__(512)
 k_mhsa_flash_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int heads, int hd, float scale, int nqb,
-                 const float* __restrict__ out_row_scale) {
+                 const float* __restrict__ out_row_scale, unsigned char* __restrict__ out8 = nullptr, const float* __restrict__ q_scale = nullptr,
+                 float* __restrict__ q_amax = nullptr) {
+    // out8 (nullable): the output a second time as OCP e4m3 bytes, out8 = sat(bf16(out) * q_scale[0]), q_amax[0] raised to max |bf16(out)|:
+    // the operand of the fp8 output projection without a quantisation pass (ap_mhsa_fwd_fp8)
     extern __shared__ __attribute__((aligned(16))) bf16_t fsm[];
     constexpr int KC = HDP / 32;
     const int wg = blockIdx.x;
@@ -145,6 +148,8 @@ k_mhsa_flash_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float
     l += __shfl_xor(l, 32, 64);
     const float inv = (out_row_scale ? out_row_scale[b] : 1.0f) / l;
     if (g == 0 && q0 + fr < N) lse[((int64_t)b * heads + h) * N + q0 + fr] = (m * c2 + log2f(l)) * 0.6931471805599453f;
+    const float qs = out8 ? q_scale[0] : 1.f;
+    float qmx = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float ir = __shfl(inv, 4 * g + r, 64);
@@ -152,8 +157,22 @@ k_mhsa_flash_fwd(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float
         if (q < N) {
             bf16_t* op = out + ((int64_t)b * N + q) * C + h * hd + fr;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) op[dt * 16] = f2bf(o[dt][r] * ir);
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16_t ob = f2bf(o[dt][r] * ir);
+                op[dt * 16] = ob;
+                if (out8) {
+                    const float v = bf2f(ob);
+                    qmx = fmaxf(qmx, fabsf(v));
+                    const float c = fminf(fmaxf(v * qs, -448.f), 448.f);
+                    out8[((int64_t)b * N + q) * C + h * hd + fr + dt * 16] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(c, c, 0, false) & 0xff);
+                }
+            }
         }
+    }
+    if (out8 && q_amax) {
+        qmx = group_max<64>(qmx);
+        if ((threadIdx.x & 63) == 0 && __float_as_int(qmx) > *reinterpret_cast<volatile int*>(q_amax))
+            atomicMax(reinterpret_cast<int*>(q_amax), __float_as_int(qmx));
     }
 }
 
@@ -364,13 +383,13 @@ k_mhsa_flash_bwd_q(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ do
     else hipLaunchKernelGGL((KERNEL<64, 4>), grid, dim3(512), lds, s, __VA_ARGS__);
 
 int ap_mhsa_flash_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N, int heads, int hd, float scale, const float* out_row_scale,
-                      hipStream_t s) {
+                      hipStream_t s, unsigned char* out8, const float* q_scale, float* q_amax) {
     const int nqb = (N + FW - 1) / FW;
     const int hdp = hd == 32 ? 32 : 64;
     const dim3 grid((unsigned)((int64_t)B * heads * nqb));
     const size_t lds = (size_t)4 * FB * hdp * sizeof(bf16_t);
     (void)hipGetLastError();
-    FLASH_DISPATCH(k_mhsa_flash_fwd, qkv, out, lse, N, heads, hd, scale, nqb, out_row_scale)
+    FLASH_DISPATCH(k_mhsa_flash_fwd, qkv, out, lse, N, heads, hd, scale, nqb, out_row_scale, out8, q_scale, q_amax)
     return ap_check_launch();
 }
 

@@ -504,8 +504,14 @@ class TransformerBlockFn(torch.autograd.Function):
             k2 = (rs2 != 0).float()
         xn1, m1, r1, xq = _ln_fwd_for(x2, n1w, n1b, eps, qkv_w)
         qkv = _linear_fwd(xn1, qkv_w, x8=xq, bias=qkv_b)
-        o, lse = ops.mhsa_fwd(qkv, B, N, heads, scale, out_row_scale=k1)                       # rows of dropped samples: zeros
-        x1 = _linear_fwd(o, proj_w, bias=proj_b, row_scale=rs1, rows_per_scale=N, residual=x2)
+        oq = None
+        site = fp8_scales.producer(("x", id(proj_w)), x.device) if (FP8_LINEAR and ops.mhsa_emits_fp8(N, C // heads)) else None
+        if site is not None:          # the attention kernel emits the e4m3 operand of the output projection
+            o, lse, o8 = ops.mhsa_fwd(qkv, B, N, heads, scale, out_row_scale=k1, fp8=(site[0], site[1]))
+            oq = (o8, site[2])
+        else:
+            o, lse = ops.mhsa_fwd(qkv, B, N, heads, scale, out_row_scale=k1)                   # rows of dropped samples: zeros
+        x1 = _linear_fwd(o, proj_w, x8=oq, bias=proj_b, row_scale=rs1, rows_per_scale=N, residual=x2)
         xn2, m2, r2, xq = _ln_fwd_for(x1, n2w, n2b, eps, fc1_w)
         h = torch.empty((B * N, fc1_w.shape[0]), dtype=BF16, device=x.device)
         a, aq = _linear_fwd(xn2, fc1_w, x8=xq, emit_for=fc2_w, bias=fc1_b, gelu=True, preact_out=h, preact_grad=STORE_GELU_GRAD, row_scale=k2, rows_per_scale=N)

@@ -372,12 +372,25 @@ def avgpool2_bwd_acc(dpooled, dx):
 
 
 # ------------------------------------------------------------------------------------- mhsa
-def mhsa_fwd(qkv, B, N, heads, scale, out_row_scale=None):
-    """out_row_scale: fp32 [B] factors (0/1 DropPath keep mask) folded into the stored output (see include/autoprog_hip.h)"""
+def mhsa_emits_fp8(N, hd):
+    """does mhsa_fwd(fp8=...) have the e4m3 side output for this shape?  (the key/query-blocked kernel: mhsa_use_flash in csrc/mhsa.hip)"""
+    e = os.environ.get("AP_MHSA_FLASH")
+    return (e == "1") if e is not None else (N > 256 or hd == 48)
+
+
+def mhsa_fwd(qkv, B, N, heads, scale, out_row_scale=None, fp8=None):
+    """out_row_scale: fp32 [B] factors (0/1 DropPath keep mask) folded into the stored output (see include/autoprog_hip.h).
+    fp8 = (scale, amax) device scalars: -> (out, lse, out8), out8 the e4m3 bytes of out * scale[0] (mhsa_emits_fp8 shapes only)"""
     _req(qkv, BF16, "qkv")
     C = qkv.shape[-1] // 3
     out = torch.empty((B * N, C), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+    if fp8 is not None:
+        out8 = torch.empty((B * N, C), dtype=torch.uint8, device=qkv.device)
+        check(lib.ap_mhsa_fwd_fp8(qkv.data_ptr(), out.data_ptr(), out8.data_ptr(), fp8[0].data_ptr(), fp8[1].data_ptr() if fp8[1] is not None else None,
+                                  lse.data_ptr(), B, N, heads, C // heads, float(scale),
+                                  out_row_scale.data_ptr() if out_row_scale is not None else None, _stream()), "ap_mhsa_fwd_fp8")
+        return out, lse, out8
     check(lib.ap_mhsa_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, heads, C // heads, float(scale),
                           out_row_scale.data_ptr() if out_row_scale is not None else None, _stream()), "ap_mhsa_fwd")
     return out, lse

@@ -185,6 +185,10 @@ int ap_avgpool2_bwd_acc(const ap_bf16* dpooled, ap_bf16* dx, int B, int H, int W
  * (models/volo.py:230-234).  The backward needs nothing extra: a dropped sample arrives with dout = 0. */
 int ap_mhsa_fwd(const ap_bf16* qkv, ap_bf16* out, float* lse, int B, int N, int heads, int hd,
                 float scale, const float* out_row_scale, ap_stream_t stream);
+/* the same with the output a second time as OCP e4m3 bytes (out8 = sat(out * q_scale[0]), q_amax[0] raised to max |out|, nullable): the
+ * operand of an fp8 output projection (configs[4]).  The key/query-blocked kernel only (N > 256 or head_dim 48): AP_ERR_UNSUPPORTED else */
+int ap_mhsa_fwd_fp8(const ap_bf16* qkv, ap_bf16* out, unsigned char* out8, const float* q_scale, float* q_amax, float* lse, int B, int N,
+                    int heads, int hd, float scale, const float* out_row_scale, ap_stream_t stream);
 size_t ap_mhsa_bwd_workspace(int B, int N, int heads, int hd);
 int ap_mhsa_bwd(const ap_bf16* qkv, const ap_bf16* out, const ap_bf16* dout, const float* lse,
                 ap_bf16* dqkv, int B, int N, int heads, int hd, float scale,

@@ -823,7 +823,7 @@ def test_gemm_nt_fp8_vs_dequantised_reference(M, N, K):
 def test_fp8_producers_match_the_quantiser(ops):
     """the two ways an fp8 operand is made without a pass of its own: (a) ap_layernorm_fwd_fp8 -- the LayerNorm's e4m3 copy and amax are
     bit-equal to ap_quantize_fp8 of its bf16 output; (b) ap_quantize_fp8_multi -- several tensors (the Linear weights of a model) in one
-    launch, each with its own scale / amax slot, bit-equal to one ap_quantize_fp8 per tensor"""
+    launch, each with its own scale / amax slot, bit-equal to one ap_quantize_fp8 per tensor; (c) the attention kernel's side output"""
     for rows, C in [(777, 384), (300, 768), (64, 192)]:
         x = dev(rnd(rows, C, scale=2.0, seed=rows))
         g = dev(torch.randn(C, generator=torch.Generator().manual_seed(1)) * 0.3 + 1)
@@ -835,6 +835,15 @@ def test_fp8_producers_match_the_quantiser(ops):
         assert torch.equal(y, y0) and torch.equal(mean, mean0) and torch.equal(rstd, rstd0)
         amax_ref = torch.zeros(1, device="cuda")
         assert torch.equal(y8, ops.quantize_fp8(y0, scale, amax_ref)) and float(amax) == float(amax_ref) == float(y0.float().abs().max())
+    # (c) ap_mhsa_fwd_fp8: the blocked attention kernel's e4m3 copy of its output (with the DropPath keep mask folded in)
+    B, N, heads, hd = 3, 300, 2, 48
+    qkv = dev(rnd(B * N, 3 * heads * hd, seed=7))
+    keep = torch.tensor([1.0, 0.0, 1.0], device="cuda")
+    scale, amax, amax_ref = torch.tensor([55.0], device="cuda"), torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    o, lse, o8 = ops.mhsa_fwd(qkv, B, N, heads, hd ** -0.5, out_row_scale=keep, fp8=(scale, amax))
+    o0, lse0 = ops.mhsa_fwd(qkv, B, N, heads, hd ** -0.5, out_row_scale=keep)
+    assert torch.equal(o, o0) and torch.equal(lse, lse0)
+    assert torch.equal(o8, ops.quantize_fp8(o0, scale, amax_ref)) and float(amax) == float(amax_ref) > 0
     sizes = [(1152, 384), (384, 384), (64, 16), (3072, 768)]
     ws = [dev(rnd(n, k, scale=0.05 * (i + 1), seed=10 + i)) for i, (n, k) in enumerate(sizes)]
     scales = torch.tensor([100.0, 300.0, 50.0, 1000.0, 7.0], device="cuda")
