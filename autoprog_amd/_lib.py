@@ -25,6 +25,11 @@ class TnProblem(Structure):
                 ("M", c_int), ("N1", c_int), ("N2", c_int), ("alpha", c_float), ("colsum_A", c_void_p), ("colsum_weight", c_void_p), ("colsum_scale", c_float), ("b_patch", c_void_p)]
 
 
+class BnInput(Structure):
+    """ap_bn_input (include/autoprog_hip.h)"""
+    _fields_ = [("mean", c_void_p), ("rstd", c_void_p), ("gamma", c_void_p), ("beta", c_void_p)]
+
+
 class LnReduce(Structure):
     """ap_ln_reduce (include/autoprog_hip.h)"""
     _fields_ = [("partial", c_void_p), ("n_partial", c_int), ("C", c_int), ("dgamma", c_void_p), ("dbeta", c_void_p)]
@@ -89,6 +94,8 @@ _SIGNATURES["ap_layernorm_bwd_partial"] = (_I, [_P, _P, _P, _P, _P, _P, _P, _L, 
 _SIGNATURES["ap_layernorm_bwd_reduce_batched"] = (_I, [_P, _I, _P])
 _SIGNATURES["ap_quantize_fp8"] = (_I, [_P, _P, _L, _P, _P, _P])
 _SIGNATURES["ap_quantize_fp8_multi"] = (_I, [_P, _I, _P, _P, _P])
+_SIGNATURES["ap_conv3x3_c64_bn"] = (_I, [_P, POINTER(BnInput), _P, _P, _I, _I, _I, _P, _P])
+_SIGNATURES["ap_conv3x3_c64_wgrad_bn"] = (_I, [_P, POINTER(BnInput), _P, _P, _I, _I, _I, _P, ctypes.c_size_t, _P])
 _SIGNATURES["ap_mhsa_fwd_fp8"] = (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P])
 _SIGNATURES["ap_gemm_nt_fp8"] = (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, POINTER(GemmEpilogue), _P])
 _SIGNATURES["ap_gemm_nt_patch"] = (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, POINTER(PatchMap), _I, _P])

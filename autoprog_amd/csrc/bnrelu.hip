@@ -223,12 +223,12 @@ int ap_bn_relu_fwd(const ap_bf16* x, const float* gamma, const float* beta, floa
 int ap_bn_relu_fwd_partials(const ap_bf16* x, const float* partial, int n_partial, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, ap_bf16* y, float* mean, float* rstd,
                             int64_t T, int C, ap_stream_t stream) {
-    if (!x || !partial || !gamma || !beta || !y || !mean || !rstd) return AP_ERR_NULL;
+    if (!partial || !mean || !rstd || (y && (!x || !gamma || !beta))) return AP_ERR_NULL;
     if (!bn_shape_ok(C) || T <= 0 || n_partial <= 0) return AP_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_bn_finalize, dim3(C), dim3(BN_BLOCK), 0, s, partial, n_partial, T, C, eps, momentum, mean, rstd, running_mean, running_var);
-    hipLaunchKernelGGL(k_bn_relu_apply, dim3(bn_grid(T, C)), dim3(BN_BLOCK), 0, s, x, mean, rstd, gamma, beta, y, T, C);
+    if (y) hipLaunchKernelGGL(k_bn_relu_apply, dim3(bn_grid(T, C)), dim3(BN_BLOCK), 0, s, x, mean, rstd, gamma, beta, y, T, C);
     return ap_check_launch();
 }
 

@@ -48,6 +48,26 @@ k_conv3x3_pack(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __r
     wb[((8 - tap) * CV_C + ci) * CV_C + co] = v;
 }
 
+// Input transform (PRE_BN): the kernel reads the PRE-BatchNorm output z of the previous convolution and applies
+// relu((z - mean) * rstd * gamma + beta) -- in the arithmetic of k_bn_relu_apply, rounded to bf16 -- to every chunk on its way from the
+// staging registers to LDS; pixels outside the image stay zero (the padding is of the ACTIVATION).  The activation tensor between two
+// convolutions of the stem is then never written or read (models/volo.py:355-366): 2 x 411 MB per step and the pass that made them.
+struct BnIn { const float* mean; const float* rstd; const float* gamma; const float* beta; };
+__device__ __forceinline__ void bn_in_consts(const BnIn& bn, int c8, float* sc, float* sh) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = bn.rstd[c8 + k] * bn.gamma[c8 + k];
+        sh[k] = bn.beta[c8 + k] - bn.mean[c8 + k] * sc[k];
+    }
+}
+__device__ __forceinline__ u32x4 bn_in_apply(const u32x4& v, const float* sc, const float* sh) {
+    float f[8];
+    unpack8(v, f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = fmaxf(fmaf(f[k], sc[k], sh[k]), 0.f);
+    return pack8(f);
+}
+
 // STATS: every workgroup also stores the per-channel sum / sum of squares of its (bf16-rounded) outputs to stats[blockIdx.x][2][64]
 // -- the partial sums of the BatchNorm that follows (models/volo.py:356-366), in the layout k_bn_finalize reads.
 //
@@ -56,10 +76,10 @@ k_conv3x3_pack(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __r
 // and stores chunk s of the PREVIOUS tile's output (16 chunks per thread, kept packed in registers) -- with one workgroup per
 // CU, a load phase, a compute phase and a store phase of their own would run one after the other on every CU at once
 // (measured: 151 us with the phases apart, 84 us for the MFMAs alone).
-template <bool STATS, int ABL = 0>
+template <bool STATS, int ABL = 0, bool PRE_BN = false>
 __global__ void __launch_bounds__(256)
 k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_t* __restrict__ y, int H, int W,
-              int tiles_x, int tiles_y, int ntiles, float* __restrict__ stats) {
+              int tiles_x, int tiles_y, int ntiles, float* __restrict__ stats, BnIn bn = BnIn{nullptr, nullptr, nullptr, nullptr}) {
     extern __shared__ __attribute__((aligned(16))) bf16_t cv_smem[];
     bf16_t* Wl = cv_smem;                       // [9][64 co][64 ci], chunk ^ key_b(co)
     bf16_t* P = cv_smem + CV_WELEMS;            // [612 px][64 ci + 8 pad]
@@ -87,6 +107,8 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
     // tile: one packed (py, px) word per chunk
     u32x4 pre[CV_NPRE];
     const int c8 = (tid & 7) * 8;
+    float bsc[8], bsh[8];                        // PRE_BN: scale / shift of this thread's 8 channels (its chunk index is the same for every chunk)
+    if constexpr (PRE_BN) bn_in_consts(bn, c8, bsc, bsh);
     int tl = tid >> 3;                           // laundered once per tile: keeps the 20 per-chunk offsets from being hoisted out of the
                                                  // tile loop into 20 registers held for the whole kernel (they are 3 VALU each)
     // The load is UNCONDITIONAL (halo pixels outside the image read a clamped, valid address) and the zero padding is applied
@@ -137,7 +159,7 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
         for (int i = 0; i < CV_NPRE; ++i) {
             const int idx = tid + 256 * i;
             if (idx < CV_NCHUNK && (!(ABL & 2) || t == (int)blockIdx.x))
-                st16(P + ((tid >> 3) + 32 * i) * CV_PSTR + c8, pvalid(i, ty0c, tx0c) ? pre[i] : zero4);
+                st16(P + ((tid >> 3) + 32 * i) * CV_PSTR + c8, pvalid(i, ty0c, tx0c) ? (PRE_BN ? bn_in_apply(pre[i], bsc, bsh) : pre[i]) : zero4);
         }
         __syncthreads();
         asm volatile("" : "+v"(tl));
@@ -391,10 +413,10 @@ k_conv3x3_c64_wgrad(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
 // and the fragments of K step k+1 are read from LDS while the MFMAs of step k issue.  The two-workgroup kernel cannot afford either
 // next to its 144 accumulators and spends 74 % of its wave time waiting.  208 -> 151 us at B = 128, 112 x 112 (16-row tiles; 32-row
 // tiles spill and take 177); half the slabs, too.
-template <int TR>
+template <int TR, bool PRE_BN = false>
 __global__ void __launch_bounds__(256)
 k_conv3x3_c64_wgrad_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ slab, int H, int W,
-                      int tiles_x, int tiles_y, int ntiles) {
+                      int tiles_x, int tiles_y, int ntiles, BnIn bn = BnIn{nullptr, nullptr, nullptr, nullptr}) {
     constexpr int DPIX = TR * CW_T, APIX = (TR + 2) * CW_PW;
     constexpr int ND = DPIX * 8 / 256, NA = (APIX * 8 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) bf16_t cw_smem[];
@@ -403,6 +425,8 @@ k_conv3x3_c64_wgrad_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ d
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4, q = fr >> 2, p = fr & 3;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const int c8 = (tid & 7) * 8, cidx = tid & 7;
+    float bsc[8], bsh[8];                       // PRE_BN: x is the pre-BatchNorm tensor, the operand is relu(bn(x)) (see BnIn)
+    if constexpr (PRE_BN) bn_in_consts(bn, c8, bsc, bsh);
     int dbase[4][2], abase[3][2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -466,7 +490,7 @@ k_conv3x3_c64_wgrad_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ d
         for (int i = 0; i < NA; ++i) {
             const int px = (tid >> 3) + 32 * i, r = (px * 3641) >> 16, c = px - r * CW_PW;
             const unsigned gy = (unsigned)(ty0 - 1 + r), gx = (unsigned)(tx0 - 1 + c);
-            if (px < APIX) st16(A + px * CV_C + ((cidx ^ cw_key(c)) << 3), (gy < (unsigned)H && gx < (unsigned)W) ? ra[i] : zero4);
+            if (px < APIX) st16(A + px * CV_C + ((cidx ^ cw_key(c)) << 3), (gy < (unsigned)H && gx < (unsigned)W) ? (PRE_BN ? bn_in_apply(ra[i], bsc, bsh) : ra[i]) : zero4);
         }
         __syncthreads();
         asm volatile("" : "+v"(tl));
@@ -561,7 +585,13 @@ int ap_conv3x3_c64_stat_rows(int B, int H, int W) {
 }
 
 int ap_conv3x3_c64(const ap_bf16* x, const ap_bf16* w_packed, ap_bf16* y, int B, int H, int W, float* stats, ap_stream_t stream) {
+    return ap_conv3x3_c64_bn(x, nullptr, w_packed, y, B, H, W, stats, stream);
+}
+
+int ap_conv3x3_c64_bn(const ap_bf16* x, const ap_bn_input* bn_in, const ap_bf16* w_packed, ap_bf16* y, int B, int H, int W, float* stats,
+                      ap_stream_t stream) {
     if (!x || !w_packed || !y) return AP_ERR_NULL;
+    if (bn_in && (!bn_in->mean || !bn_in->rstd || !bn_in->gamma || !bn_in->beta)) return AP_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0) return AP_ERR_SHAPE;
     const int tiles_x = (W + CV_TW - 1) / CV_TW, tiles_y = (H + CV_TR - 1) / CV_TR;
     const int64_t nt64 = (int64_t)B * tiles_x * tiles_y;
@@ -572,9 +602,17 @@ int ap_conv3x3_c64(const ap_bf16* x, const ap_bf16* w_packed, ap_bf16* y, int B,
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES) != hipSuccess) return AP_ERR_LAUNCH;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES) != hipSuccess) return AP_ERR_LAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES) != hipSuccess) return AP_ERR_LAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64<true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES) != hipSuccess) return AP_ERR_LAUNCH;
         attr_done = 1;
     }
     const int grid = cv_grid(ntiles);
+    if (bn_in) {
+        const BnIn bn = {bn_in->mean, bn_in->rstd, bn_in->gamma, bn_in->beta};
+        if (stats) hipLaunchKernelGGL((k_conv3x3_c64<true, 0, true>), dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats, bn);
+        else hipLaunchKernelGGL((k_conv3x3_c64<false, 0, true>), dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats, bn);
+        return ap_check_launch();
+    }
 #if AP_EXPERIMENTS             // ablation instantiations (DESIGN.md "Convolution kernels, by ablation"): make EXTRA=-DAP_EXPERIMENTS=1, AP_CONV_ABL=bits
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("AP_CONV_ABL"); abl = e ? atoi(e) : 0; }
@@ -601,7 +639,13 @@ size_t ap_conv3x3_c64_wgrad_workspace(int B, int H, int W) {
 
 int ap_conv3x3_c64_wgrad(const ap_bf16* x, const ap_bf16* dy, float* dw_oihw, int B, int H, int W, void* workspace, size_t ws_bytes,
                          ap_stream_t stream) {
+    return ap_conv3x3_c64_wgrad_bn(x, nullptr, dy, dw_oihw, B, H, W, workspace, ws_bytes, stream);
+}
+
+int ap_conv3x3_c64_wgrad_bn(const ap_bf16* x, const ap_bn_input* bn_in, const ap_bf16* dy, float* dw_oihw, int B, int H, int W, void* workspace,
+                            size_t ws_bytes, ap_stream_t stream) {
     if (!x || !dy || !dw_oihw || !workspace) return AP_ERR_NULL;
+    if (bn_in && (!bn_in->mean || !bn_in->rstd || !bn_in->gamma || !bn_in->beta)) return AP_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0) return AP_ERR_SHAPE;
     const int tiles_x = (W + CW_T - 1) / CW_T, tiles_y = (H + CW_T - 1) / CW_T;
     const int64_t nt64 = (int64_t)B * tiles_x * tiles_y;
@@ -615,17 +659,22 @@ int ap_conv3x3_c64_wgrad(const ap_bf16* x, const ap_bf16* dy, float* dw_oihw, in
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64_wgrad), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES) != hipSuccess) return AP_ERR_LAUNCH;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64_wgrad_p<PTR>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS) != hipSuccess) return AP_ERR_LAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64_wgrad_p<PTR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS) != hipSuccess) return AP_ERR_LAUNCH;
         attr_done = 1;
     }
     static int use_p = -1;
     if (use_p < 0) { const char* e = getenv("AP_CONV_WGRAD_P"); use_p = e ? atoi(e) : 1; }
-    if (use_p) {                // one prefetching workgroup per CU, 32 x 16 tiles
+    if (use_p || bn_in) {       // one prefetching workgroup per CU, 32 x 16 tiles (the only kernel with the BatchNorm input transform)
         const int tyy = (H + PTR - 1) / PTR;
         const int64_t np = (int64_t)B * tiles_x * tyy;
         ntiles = (int)np;
         const int gp = ntiles < 256 ? ntiles : 256;
         if ((size_t)gp * CV_WELEMS * sizeof(float) > ws_bytes) return AP_ERR_SHAPE;
         grid = gp;
+        if (bn_in) {
+            const BnIn bn = {bn_in->mean, bn_in->rstd, bn_in->gamma, bn_in->beta};
+            hipLaunchKernelGGL((k_conv3x3_c64_wgrad_p<PTR, true>), dim3(grid), dim3(256), P_LDS, (hipStream_t)stream, x, dy, static_cast<float*>(workspace), H, W, tiles_x, tyy, ntiles, bn);
+        } else
         hipLaunchKernelGGL((k_conv3x3_c64_wgrad_p<PTR>), dim3(grid), dim3(256), P_LDS, (hipStream_t)stream, x, dy, static_cast<float*>(workspace), H, W, tiles_x, tyy, ntiles);
     } else
     hipLaunchKernelGGL(k_conv3x3_c64_wgrad, dim3(grid), dim3(256), CW_LDS_BYTES, (hipStream_t)stream, x, dy, static_cast<float*>(workspace), H, W, tiles_x, tiles_y, ntiles);

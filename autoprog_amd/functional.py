@@ -1067,6 +1067,62 @@ class Conv3x3BNReLUFn(torch.autograd.Function):
         return dx, dw, dg, db, None, None, None, None, None
 
 
+class Stem64Fn(torch.autograd.Function):
+    """The whole 64-wide stem in front of the patch projection (models/volo.py:355-366): conv7x7/s2 -> BN -> ReLU -> conv3x3 -> BN -> ReLU
+    -> conv3x3 -> BN -> ReLU on the space-to-depth image, as ONE autograd node so that the two activations between the convolutions
+    never exist: a 3x3 convolution (forward and weight gradient) reads the PRE-BatchNorm output of the layer before it and applies
+    relu(bn(.)) while it stages its input (csrc/conv.hip PRE_BN) -- the arithmetic of the stand-alone BatchNorm + ReLU pass, rounded
+    to bf16 at the same place, so the result is bit-identical to the chain Conv7BNReLUFn -> Conv3x3BNReLUFn -> Conv3x3BNReLUFn.
+    Saves two passes of 411 MB per step at B = 128, 224 px.  AP_STEM_FUSE_BN=0 keeps the chain."""
+
+    @staticmethod
+    def forward(ctx, xs, w7, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3, training, momentum, eps):
+        wp7 = ops.conv7_pack(w7.detach().float().contiguous())
+        wf2, wb2 = ops.conv3x3_pack(w2.detach().float().contiguous())
+        wf3, wb3 = ops.conv3x3_pack(w3.detach().float().contiguous())
+        mom1, mom2, mom3 = momentum
+        eps1, eps2, eps3 = eps
+        if training:
+            z1, p1 = ops.conv7_s2d(xs, wp7, True)
+            _, mean1, rstd1 = ops.bn_relu_fwd(z1, g1, b1, rm1, rv1, True, mom1, eps1, partials=p1, apply=False)
+            z2, p2 = ops.conv3x3_c64(z1, wf2, True, bn_in=(mean1, rstd1, g1, b1))
+            _, mean2, rstd2 = ops.bn_relu_fwd(z2, g2, b2, rm2, rv2, True, mom2, eps2, partials=p2, apply=False)
+            z3, p3 = ops.conv3x3_c64(z2, wf3, True, bn_in=(mean2, rstd2, g2, b2))
+            y, mean3, rstd3 = ops.bn_relu_fwd(z3, g3, b3, rm3, rv3, True, mom3, eps3, partials=p3)
+        else:
+            z1 = ops.conv7_s2d(xs, wp7)
+            _, mean1, rstd1 = ops.bn_relu_fwd(z1, g1, b1, rm1, rv1, False, mom1, eps1, apply=False)
+            z2 = ops.conv3x3_c64(z1, wf2, bn_in=(mean1, rstd1, g1, b1))
+            _, mean2, rstd2 = ops.bn_relu_fwd(z2, g2, b2, rm2, rv2, False, mom2, eps2, apply=False)
+            z3 = ops.conv3x3_c64(z2, wf3, bn_in=(mean2, rstd2, g2, b2))
+            y, mean3, rstd3 = ops.bn_relu_fwd(z3, g3, b3, rm3, rv3, False, mom3, eps3)
+        ctx.save_for_backward(xs, z1, z2, z3, wb2, wb3, w7, g1, b1, w2, g2, b2, w3, g3, b3, mean1, rstd1, mean2, rstd2, mean3, rstd3)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xs, z1, z2, z3, wb2, wb3, w7, g1, b1, w2, g2, b2, w3, g3, b3, mean1, rstd1, mean2, rstd2, mean3, rstd3) = ctx.saved_tensors
+        if not ctx.training:
+            raise AutoProgHipError("Stem64Fn backward is implemented for training mode (batch statistics) only")
+        params = (w7, g1, b1, w2, g2, b2, w3, g3, b3)
+        bufs, sunk = _param_grad_buffers(params)
+        dw7, dg1, db1, dw2, dg2, db2, dw3, dg3, db3 = bufs
+        dz3 = ops.bn_relu_bwd(dy.contiguous(), z3, g3, b3, mean3, rstd3, dg3, db3)
+        da2 = ops.conv3x3_c64(dz3, wb3)
+        ops.conv3x3_c64_wgrad(z2, dz3, dw3, bn_in=(mean2, rstd2, g2, b2))
+        dz2 = ops.bn_relu_bwd(da2, z2, g2, b2, mean2, rstd2, dg2, db2)
+        da1 = ops.conv3x3_c64(dz2, wb2)
+        ops.conv3x3_c64_wgrad(z1, dz2, dw2, bn_in=(mean1, rstd1, g1, b1))
+        dz1 = ops.bn_relu_bwd(da1, z1, g1, b1, mean1, rstd1, dg1, db1)
+        ops.conv7_s2d_wgrad(xs, dz1, dw7)
+        gr = _finish_param_grads(params, bufs, sunk)
+        return (None, gr[0], gr[1], gr[2], None, None, gr[3], gr[4], gr[5], None, None, gr[6], gr[7], gr[8], None, None, None, None, None)
+
+
+STEM_FUSE_BN = os.environ.get("AP_STEM_FUSE_BN", "1") != "0"
+
+
 def to_bf16(x):
     """fp32/bf16 torch tensor -> contiguous bf16 (autograd-aware torch cast: stem boundary)"""
     return x.to(BF16).contiguous()

@@ -341,7 +341,19 @@ class PatchEmbed(nn.Module):
             # resize + space-to-depth in one kernel, then the 7x7 / stride 2 convolution of csrc/conv7.hip with its BatchNorm + ReLU
             from .. import ops
             bn = self.conv[1]
-            first = AF.Conv7BNReLUFn.apply(ops.resize_bilinear_s2d16(x.contiguous(), size), self.conv[0].weight, bn.weight, bn.bias,
+            xs = ops.resize_bilinear_s2d16(x.contiguous(), size)
+            if (AF.STEM_FUSE_BN and all(tuple(self.conv[i].weight.shape) == (64, 64, 3, 3) for i in (3, 6))
+                    and all(self.conv[i].running_mean is not None for i in (1, 4, 7))):
+                # the three convolutions as one node: the activations between them are applied inside the next convolution's staging
+                c = self.conv
+                whole = AF.Stem64Fn.apply(xs, c[0].weight, c[1].weight, c[1].bias, c[1].running_mean, c[1].running_var,
+                                          c[3].weight, c[4].weight, c[4].bias, c[4].running_mean, c[4].running_var,
+                                          c[6].weight, c[7].weight, c[7].bias, c[7].running_mean, c[7].running_var,
+                                          self.training, (c[1].momentum, c[4].momentum, c[7].momentum), (c[1].eps, c[4].eps, c[7].eps))
+                if self.training:
+                    torch._foreach_add_([c[i].num_batches_tracked for i in (1, 4, 7) if c[i].num_batches_tracked is not None], 1)
+                return self._project(whole.permute(0, 3, 1, 2), fused)
+            first = AF.Conv7BNReLUFn.apply(xs, self.conv[0].weight, bn.weight, bn.bias,
                                            bn.running_mean, bn.running_var, self.training, bn.momentum, bn.eps)
             x = first.permute(0, 3, 1, 2)
         elif fused and x.dtype == torch.float32 and x.shape[-1] == x.shape[-2] and not x.requires_grad:
@@ -379,6 +391,10 @@ class PatchEmbed(nn.Module):
                         torch._foreach_add_(counters, 1)                                # one launch for the three counters
                 else:
                     x = self.conv(x)
+        return self._project(x, fused)
+
+    def _project(self, x, fused):
+        with torch.autocast("cuda", dtype=BF16, enabled=fused):
             k = self.proj.kernel_size[0]
             nhwc = x.permute(0, 2, 3, 1)
             if fused and self.hip_conv and self.proj.stride[0] == k and nhwc.is_contiguous() and AF.patch_conv_ok(nhwc, self.proj.weight, k):

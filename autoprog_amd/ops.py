@@ -500,13 +500,18 @@ def sum_reps_acc(x, out, reps):
 
 
 # ---------------------------------------------------------------------------- stem BN + ReLU
-def bn_relu_fwd(x, gamma, beta, running_mean, running_var, training, momentum, eps, partials=None):
+def bn_relu_fwd(x, gamma, beta, running_mean, running_var, training, momentum, eps, partials=None, apply=True):
     """x: bf16 [..., C] NHWC rows.  returns (y, mean, rstd).  partials (training only): fp32 [rows,2,C] partial sums / sums of squares
-    of x from the kernel that produced it (conv3x3_c64 want_stats) -- the statistics pass over x is skipped"""
+    of x from the kernel that produced it (conv3x3_c64 want_stats) -- the statistics pass over x is skipped.  apply=False (with
+    partials, or in eval mode): statistics only, y is None -- the consumer normalises while it loads (conv3x3_c64(bn_in=...))"""
     _req(x, BF16, "x")
     C = x.shape[-1]
     T = x.numel() // C
-    y = torch.empty_like(x)
+    if not apply and not training:
+        return None, running_mean.float().contiguous(), torch.rsqrt(running_var.float() + eps).contiguous()
+    if not apply and partials is None:
+        raise AutoProgHipError("bn_relu_fwd(apply=False) needs the producer's partial statistics")
+    y = torch.empty_like(x) if apply else None
     if training and partials is not None:
         _req(partials, torch.float32, "partials")
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -514,7 +519,7 @@ def bn_relu_fwd(x, gamma, beta, running_mean, running_var, training, momentum, e
         check(lib.ap_bn_relu_fwd_partials(x.data_ptr(), partials.data_ptr(), partials.shape[0], gamma.data_ptr(), beta.data_ptr(),
                                           running_mean.data_ptr() if running_mean is not None else None,
                                           running_var.data_ptr() if running_var is not None else None,
-                                          float(momentum), float(eps), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), T, C, _stream()),
+                                          float(momentum), float(eps), y.data_ptr() if y is not None else None, mean.data_ptr(), rstd.data_ptr(), T, C, _stream()),
               "ap_bn_relu_fwd_partials")
         return y, mean, rstd
     if training:
@@ -557,28 +562,50 @@ def conv3x3_pack(weight):
     return wf, wb
 
 
-def conv3x3_c64(x, w_packed, want_stats=False):
+def _bn_input(bn_in):
+    from ._lib import BnInput
+    mean, rstd, gamma, beta = bn_in
+    for t, n in ((mean, "mean"), (rstd, "rstd"), (gamma, "gamma"), (beta, "beta")):
+        _req(t, torch.float32, n)
+    b = BnInput()
+    b.mean, b.rstd, b.gamma, b.beta = mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    return b
+
+
+def conv3x3_c64(x, w_packed, want_stats=False, bn_in=None):
     """x [B,H,W,64] bf16 (NHWC, contiguous) -> conv3x3 / stride 1 / pad 1.  want_stats: also return the partial BatchNorm
-    statistics of the output (fp32 [rows,2,64], for bn_relu_fwd(..., partials=))"""
+    statistics of the output (fp32 [rows,2,64], for bn_relu_fwd(..., partials=)).  bn_in = (mean, rstd, gamma, beta): x is the
+    PRE-BatchNorm output of the previous convolution and the kernel applies relu(bn(x)) while it stages its input"""
     _req(x, BF16, "x"); _req(w_packed, BF16, "w_packed")
     B, H, W, C = x.shape
     if C != 64:
         raise AutoProgHipError("conv3x3_c64: 64 channels (got %d)" % C)
     y = torch.empty_like(x)
     stats = torch.empty((lib.ap_conv3x3_c64_stat_rows(B, H, W), 2, 64), dtype=torch.float32, device=x.device) if want_stats else None
-    check(lib.ap_conv3x3_c64(x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), B, H, W,
-                             stats.data_ptr() if want_stats else None, _stream()), "ap_conv3x3_c64")
+    if bn_in is not None:
+        b = _bn_input(bn_in)
+        check(lib.ap_conv3x3_c64_bn(x.data_ptr(), ctypes.byref(b), w_packed.data_ptr(), y.data_ptr(), B, H, W,
+                                    stats.data_ptr() if want_stats else None, _stream()), "ap_conv3x3_c64_bn")
+    else:
+        check(lib.ap_conv3x3_c64(x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), B, H, W,
+                                 stats.data_ptr() if want_stats else None, _stream()), "ap_conv3x3_c64")
     return (y, stats) if want_stats else y
 
 
-def conv3x3_c64_wgrad(x, dy, dw):
-    """dw (fp32 [64,64,3,3], contiguous) += weight gradient of conv3x3_c64 for input x and output gradient dy"""
+def conv3x3_c64_wgrad(x, dy, dw, bn_in=None):
+    """dw (fp32 [64,64,3,3], contiguous) += weight gradient of conv3x3_c64 for input x and output gradient dy; bn_in as for conv3x3_c64
+    (the layer's input was relu(bn(x)))"""
     _req(x, BF16, "x"); _req(dy, BF16, "dy"); _req(dw, torch.float32, "dw")
     B, H, W, C = x.shape
     if C != 64 or tuple(dy.shape) != tuple(x.shape) or tuple(dw.shape) != (64, 64, 3, 3):
         raise AutoProgHipError("conv3x3_c64_wgrad: shapes %s %s %s" % (tuple(x.shape), tuple(dy.shape), tuple(dw.shape)))
     ws_bytes = lib.ap_conv3x3_c64_wgrad_workspace(B, H, W)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    if bn_in is not None:
+        b = _bn_input(bn_in)
+        check(lib.ap_conv3x3_c64_wgrad_bn(x.data_ptr(), ctypes.byref(b), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), ws_bytes, _stream()),
+              "ap_conv3x3_c64_wgrad_bn")
+        return dw
     check(lib.ap_conv3x3_c64_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), ws_bytes, _stream()), "ap_conv3x3_c64_wgrad")
     return dw
 

@@ -252,7 +252,8 @@ int ap_bn_relu_fwd(const ap_bf16* x, const float* gamma, const float* beta, floa
                    int training, float momentum, float eps, ap_bf16* y, float* mean, float* rstd, int64_t T, int C,
                    void* workspace, size_t ws_bytes, ap_stream_t stream);
 /* training-mode ap_bn_relu_fwd whose batch statistics come from `partial`: n_partial rows [2][C] of per-channel sums and sums
- * of squares of x, produced by the kernel that wrote x (ap_conv3x3_c64 with stats != NULL) -- saves the pass over x */
+ * of squares of x, produced by the kernel that wrote x (ap_conv3x3_c64 with stats != NULL) -- saves the pass over x.
+ * y NULL: statistics only (mean, rstd, running statistics); the consumer applies the normalisation itself (ap_conv3x3_c64_bn) */
 int ap_bn_relu_fwd_partials(const ap_bf16* x, const float* partial, int n_partial, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, ap_bf16* y, float* mean, float* rstd,
                             int64_t T, int C, ap_stream_t stream);
@@ -271,12 +272,21 @@ int ap_conv3x3_c64_pack(const float* w_oihw, ap_bf16* w_fwd, ap_bf16* w_bwd, ap_
  * squares of its bf16 outputs to its row (the partial batch statistics of the BatchNorm that follows: ap_bn_relu_fwd_partials) */
 int ap_conv3x3_c64_stat_rows(int B, int H, int W);
 int ap_conv3x3_c64(const ap_bf16* x, const ap_bf16* w_packed, ap_bf16* y, int B, int H, int W, float* stats, ap_stream_t stream);
+/* the same on the PRE-BatchNorm output of the previous stem convolution: the kernel applies relu((x - mean) * rstd * gamma + beta) (the
+ * arithmetic of ap_bn_relu_fwd, rounded to bf16) to its input while staging it, pixels outside the image stay zero -- the activation
+ * between the two convolutions (models/volo.py:358-359, 361-362) is never materialised.  bn_in NULL: plain ap_conv3x3_c64. */
+typedef struct ap_bn_input { const float* mean; const float* rstd; const float* gamma; const float* beta; } ap_bn_input;   /* [64] each */
+int ap_conv3x3_c64_bn(const ap_bf16* x, const ap_bn_input* bn_in, const ap_bf16* w_packed, ap_bf16* y, int B, int H, int W, float* stats,
+                      ap_stream_t stream);
 
 /* dw_oihw[64][64][3][3] (fp32) += weight gradient of ap_conv3x3_c64: x the layer input, dy the output gradient (both
  * [B,H,W,64] NHWC bf16).  Per-workgroup partial sums go to `workspace` and are added in a fixed order: no atomics. */
 size_t ap_conv3x3_c64_wgrad_workspace(int B, int H, int W);
 int ap_conv3x3_c64_wgrad(const ap_bf16* x, const ap_bf16* dy, float* dw_oihw, int B, int H, int W, void* workspace, size_t ws_bytes,
                          ap_stream_t stream);
+/* the same for a layer whose input was relu(bn(x)) of ap_conv3x3_c64_bn: x is the pre-BatchNorm tensor */
+int ap_conv3x3_c64_wgrad_bn(const ap_bf16* x, const ap_bn_input* bn_in, const ap_bf16* dy, float* dw_oihw, int B, int H, int W, void* workspace,
+                            size_t ws_bytes, ap_stream_t stream);
 
 /* ---- first stem convolution in HIP: 7x7 / stride 2 / pad 3, 3 -> 64, no bias (models/volo.py:355-357) on the space-to-depth input
  * xs[B, H, W, 16] (bf16; H, W = half the image size; channel (sy*2+sx)*3+c = pixel (2Y+sy, 2X+sx) channel c, 12..15 zero) */

@@ -191,3 +191,51 @@ def test_hip_stem64_vs_reference_golden(monkeypatch):
     print("stem64 vs oracle (3 x 48 x 48) gradient errors:", {k: round(v, 4) for k, v in sorted(errs2.items(), key=lambda kv: -kv[1])})
     bad = {k: v for k, v in errs2.items() if v > (1.5e-2 if k.startswith("proj") else 1.3 * max(base.values()))}
     assert not bad, bad
+
+
+def test_stem64_fused_batchnorm_input_is_bit_identical_to_the_chain(monkeypatch):
+    """functional.Stem64Fn (the 3x3 convolutions read the PRE-BatchNorm tensor of the layer before them and apply relu(bn(.)) while they
+    stage it: csrc/conv.hip PRE_BN, forward and weight gradient) against the chain of per-layer nodes with materialised activations
+    (AP_STEM_FUSE_BN=0): the same bits -- train output, every parameter gradient, running statistics, eval output -- on an odd batch and
+    a feature map that does not divide the convolution tiles; and the two kernels on their own against apply-then-convolve."""
+    from autoprog_amd import functional as AF, ops
+    from autoprog_amd.models.volo import PatchEmbed
+    torch.manual_seed(3)
+    x = torch.randn(3, 3, 80, 80, device="cuda")
+    res = {}
+    for fuse in (False, True):
+        monkeypatch.setattr(AF, "STEM_FUSE_BN", fuse)
+        torch.manual_seed(11)
+        pe = PatchEmbed(stem_conv=True, stem_stride=2, patch_size=8, in_chans=3, hidden_dim=64, embed_dim=192).cuda().train()
+        y = pe(x)
+        torch.manual_seed(12)
+        y.backward(torch.randn_like(y))
+        out = {"y": y.detach().clone()}
+        out.update({"g." + n: p.grad.detach().clone() for n, p in pe.named_parameters()})
+        out.update({"b." + n: b.detach().clone() for n, b in pe.named_buffers()})
+        pe.eval()
+        with torch.no_grad():
+            out["eval"] = pe(x).clone()
+        res[fuse] = out
+    assert set(res[True]) == set(res[False]) and len(res[True]) > 15
+    for k in res[True]:
+        assert torch.equal(res[True][k], res[False][k]), k
+    assert float(res[True]["g.conv.3.weight"].abs().max()) > 0 and float(res[True]["b.conv.4.running_mean"].abs().max()) > 0
+    # kernel level
+    g = torch.Generator(device="cuda").manual_seed(5)
+    z = torch.randn(2, 37, 21, 64, device="cuda", generator=g).to(torch.bfloat16)
+    dy = torch.randn(2, 37, 21, 64, device="cuda", generator=g).to(torch.bfloat16)
+    mean, rstd = torch.randn(64, device="cuda", generator=g) * 0.3, torch.rand(64, device="cuda", generator=g) + 0.5
+    gam, bet = torch.randn(64, device="cuda", generator=g) * 0.3 + 1, torch.randn(64, device="cuda", generator=g) * 0.3
+    w = torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05
+    wf, wb = ops.conv3x3_pack(w)
+    a = torch.relu((z.float() - mean) * (rstd * gam) + bet)            # same association as k_bn_relu_apply: x * (rstd * gamma) + (beta - mean * rstd * gamma)
+    sc = rstd * gam
+    a = torch.clamp_min(torch.addcmul(bet - mean * sc, z.float(), sc), 0).to(torch.bfloat16)
+    y0, s0 = ops.conv3x3_c64(a, wf, True)
+    y1, s1 = ops.conv3x3_c64(z, wf, True, bn_in=(mean, rstd, gam, bet))
+    assert float((y1.float() - y0.float()).abs().max()) <= 2 ** -6 * float(y0.float().abs().max())     # (fma vs mul + add inside the transform: <= 1 bf16 ulp of an input)
+    dw0, dw1 = torch.zeros(64, 64, 3, 3, device="cuda"), torch.zeros(64, 64, 3, 3, device="cuda")
+    ops.conv3x3_c64_wgrad(a, dy, dw0)
+    ops.conv3x3_c64_wgrad(z, dy, dw1, bn_in=(mean, rstd, gam, bet))
+    assert float((dw1 - dw0).norm() / dw0.norm()) < 2e-3
