@@ -307,9 +307,12 @@ int ap_layernorm_fwd_fp8(const ap_bf16* x, const float* gamma, const float* beta
     if (C <= 0 || (C & 7)) return AP_ERR_SHAPE;
     if (C > 2048) return AP_ERR_UNSUPPORTED;
     if (rows <= 0) return AP_OK;
-    int V; const int G = pick_group(C, &V);
+    static int rpg = 0, wide = -1;
+    if (rpg == 0) { const char* e = getenv("AP_LN_FWD_RPG"); rpg = e ? atoi(e) : 1; if (rpg < 1) rpg = 1;       // one row per lane group and workgroup: 10.3 vs 10.7 us at 25088 x 384 (4: 11.4, 8: 15.3)
+                    const char* w = getenv("AP_LN_FWD_WIDE"); wide = w ? atoi(w) : 0; }
+    int V; const int G = wide ? pick_group_wide(C, &V) : pick_group(C, &V);
     const int gpb = 256 / G;
-    int64_t grid = ceil_div64(rows, (int64_t)gpb * 2);
+    int64_t grid = ceil_div64(rows, (int64_t)gpb * rpg);
     if (grid > 256 * 8) grid = 256 * 8;
     if (grid < 1) grid = 1;
     const size_t lds = (size_t)2 * C * sizeof(float);
@@ -378,6 +381,7 @@ int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, co
     static int grid_cap = 0;
     if (grid_cap == 0) { const char* e = getenv("AP_LN_BWD_GRID"); grid_cap = e ? atoi(e) : 768; if (grid_cap < 1 || grid_cap > 1024) grid_cap = 768; }   // 3 blocks per CU measured best (20.7 vs 23.5 us at 1024)
     if (grid > grid_cap) grid = grid_cap;   // bounds the dgamma/dbeta partial rows (workspace holds 1024)
+    if (V >= 2 && grid > 512 && !getenv("AP_LN_BWD_GRID")) grid = 512;      // 768-wide rows (DeiT-Base, VOLO-D5): 19.6 us at two workgroups per CU, 24.3 at three
     const size_t lds = (size_t)2 * 4 * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
