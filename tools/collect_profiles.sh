@@ -12,7 +12,7 @@ if [ -z "$PMC_ONLY" ]; then
 python3 bench.py 2> gpurun_out/${ROUND}_bench.err | tail -1 > gpurun_out/${ROUND}_bench_n1.json
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/_kt -o run -- python3 bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/_kt.log 2>&1
 f=$(find gpurun_out/_kt -name "*kernel_trace.csv" | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-roofline ; dispatches after the 6th k_soft_ce (3 warm-up steps dropped; kept: the 7 timed steps + the 6 forward+backward-only probe steps behind `fwd_loss_bwd_only_ms_per_step`)"; python3 tools/prof_summary.py $f --after k_soft_ce 6; } > gpurun_out/${ROUND}_kernel_stats.txt
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-roofline ; dispatches after the 6th k_soft_ce (3 warm-up steps dropped; kept: the 7 timed steps + the 6 forward+backward-only probe steps behind fwd_loss_bwd_only_ms_per_step)"; python3 tools/prof_summary.py $f --after k_soft_ce 6; } > gpurun_out/${ROUND}_kernel_stats.txt
 rm -rf gpurun_out/_kt
 fi
 i=0
