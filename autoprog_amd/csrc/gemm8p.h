@@ -71,57 +71,6 @@ struct G8Args {
     int tiles_n, ntiles;
 };
 
-// epilogue of W (8 or 4) consecutive output columns [n, n+W) of row m, all inside the matrix; every leading dimension a multiple
-// of 8 elements.  Same operations, same order and same rounding points as epi_chunk (gemm_epi.h).
-template <int W>
-__device__ __forceinline__ void g8_epi(float* v, int m, int n, int ldc, const EpiArgs& ep, bf16_t* __restrict__ C) {
-    typedef typename std::conditional<W == 8, u32x4, u32x2>::type pk_t;
-    auto unpack = [](const pk_t& x, float* f) {
-#pragma unroll
-        for (int i = 0; i < W / 2; ++i) { f[2 * i] = bf_lo(x[i]); f[2 * i + 1] = bf_hi(x[i]); }
-    };
-    auto pack = [](const float* f) {
-        pk_t x;
-#pragma unroll
-        for (int i = 0; i < W / 2; ++i) x[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
-        return x;
-    };
-    if (ep.bias) {
-#pragma unroll
-        for (int q = 0; q < W; q += 4) {
-            const float4 b = *reinterpret_cast<const float4*>(ep.bias + n + q);
-            v[q] += b.x; v[q + 1] += b.y; v[q + 2] += b.z; v[q + 3] += b.w;
-        }
-    }
-    if (ep.gelu) {
-        if (ep.preact) {
-            const pk_t h = pack(v);
-            *reinterpret_cast<pk_t*>(ep.preact + (int64_t)m * ldc + n) = h;
-            unpack(h, v);
-        }
-#pragma unroll
-        for (int q = 0; q < W; ++q) v[q] = gelu_erf(v[q]);
-    }
-    if (ep.dgelu_of) {
-        float h[W];
-        unpack(*reinterpret_cast<const pk_t*>(ep.dgelu_of + (int64_t)m * ldc + n), h);
-#pragma unroll
-        for (int q = 0; q < W; ++q) v[q] *= gelu_erf_grad(h[q]);
-    }
-    if (ep.row_scale) {
-        const float rs = ep.row_scale[m / ep.rows_per_scale];
-#pragma unroll
-        for (int q = 0; q < W; ++q) v[q] *= rs;
-    }
-    if (ep.residual) {
-        float h[W];
-        unpack(*reinterpret_cast<const pk_t*>(ep.residual + (int64_t)m * ep.ldr + n), h);
-#pragma unroll
-        for (int q = 0; q < W; ++q) v[q] += h[q];
-    }
-    *reinterpret_cast<pk_t*>(C + (int64_t)m * ldc + n) = pack(v);
-}
-
 // epilogue flavour of an instantiation (EF >= 0: bits known at compile time; EF < 0: read from the arguments at run time).  The
 // generic epilogue is ~25 KB of code that a CU runs once or twice per launch, cold: an instantiation per flavour of the training
 // step keeps what is fetched to what is used (2.8 us -> see DESIGN.md on the 25088 x 384 x 1152 launch).

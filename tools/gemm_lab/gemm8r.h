@@ -19,9 +19,9 @@
 // with row & 7) behind one barrier; row phase: 16 lanes own a row (3 chunks of 8 columns each), four rows of a wave in flight, four
 // steps; row statistics by shuffles inside the 16 lanes; the outputs leave as whole lines.
 #pragma once
-#include "common.h"
-#include "gemm_epi.h"
-#include "gemm8p.h"
+#include "../../autoprog_amd/csrc/common.h"
+#include "../../autoprog_amd/csrc/gemm_epi.h"
+#include "../../autoprog_amd/csrc/gemm8p.h"
 
 #ifndef G8R_ABL
 #define G8R_ABL 0           // lab ablations: 1 no MFMA, 2 no fragment reads, 4 no DMA

@@ -10,7 +10,7 @@
 #include <algorithm>
 #include <type_traits>
 #define k_gemm_nt_8r k_gemm_nt_8r_lab
-#include "../../autoprog_amd/csrc/gemm8r.h"
+#include "gemm8r.h"
 #include "../../include/autoprog_hip.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
