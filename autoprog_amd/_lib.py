@@ -94,6 +94,7 @@ _SIGNATURES["ap_layernorm_bwd_partial"] = (_I, [_P, _P, _P, _P, _P, _P, _P, _L, 
 _SIGNATURES["ap_layernorm_bwd_reduce_batched"] = (_I, [_P, _I, _P])
 _SIGNATURES["ap_quantize_fp8"] = (_I, [_P, _P, _L, _P, _P, _P])
 _SIGNATURES["ap_quantize_fp8_multi"] = (_I, [_P, _I, _P, _P, _P])
+_SIGNATURES["ap_debug_poison_lds"] = (_I, [ctypes.c_uint, _P, _P])
 _SIGNATURES["ap_conv3x3_c64_bn"] = (_I, [_P, POINTER(BnInput), _P, _P, _I, _I, _I, _P, _P])
 _SIGNATURES["ap_conv3x3_c64_wgrad_bn"] = (_I, [_P, POINTER(BnInput), _P, _P, _I, _I, _I, _P, ctypes.c_size_t, _P])
 _SIGNATURES["ap_mhsa_fwd_fp8"] = (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P])

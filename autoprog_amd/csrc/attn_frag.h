@@ -2,6 +2,12 @@
 // workgroup's LDS; mhsa_flash.hip: key/query-blocked kernels for long sequences and head_dim 48).
 // Tiles are [tokens][HD] bf16 with HD = 32 (64-byte rows) or 64 (128-byte rows).
 #pragma once
+// Backward: p = exp2(s * c2 - lse * log2 e) is recomputed per (query, key).  A PADDED key (zero K row, s = 0) gets p = exp(-lse), which
+// is harmless -- its dS meets zero K rows, its dK / dV rows are not stored -- until every real logit of the row is so negative that
+// lse < -88: then exp(-lse) is inf and inf * 0 = NaN lands in dQ (seen at step ~150-250 of a run on one synthetic batch, once a head's
+// logits had drifted to -100).  The exponent is clamped instead of masking by key index: real keys have s * c2 - lse * log2 e <= ~0.
+#define ATT_PCAP 64.0f
+
 #include "common.h"
 
 // element offset of 16-B chunk `chunk` of row `row` in a [tokens][HD] LDS tile.

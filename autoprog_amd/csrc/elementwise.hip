@@ -333,6 +333,23 @@ k_quantize_fp8_multi(const ap_fp8_job* __restrict__ jobs, const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------- test aid: poison the LDS of every CU
+// every workgroup fills all 160 KB of its CU's LDS with `pattern` (e.g. 0x7FC07FC0 = bf16 NaN pairs, 0xFFFFFFFF = fp32 NaN) and spins
+// until `min_wgs` workgroups have arrived, so that the fill lands on many CUs: a kernel that reads LDS words it never wrote (padded
+// rows of a tile, a tail chunk) then computes on NaNs instead of on whatever the previous kernel left there
+__global__ void __launch_bounds__(1024)
+k_poison_lds(unsigned pattern, unsigned* counter, int min_wgs) {
+    extern __shared__ unsigned lds_all[];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 1024) lds_all[i] = pattern;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(counter, 1u);
+        for (int spin = 0; spin < 20000 && atomicAdd(counter, 0u) < (unsigned)min_wgs; ++spin) __builtin_amdgcn_s_sleep(20);
+    }
+    __syncthreads();
+    if (lds_all[threadIdx.x] != pattern) counter[1] = 1;        // (keeps the fill alive)
+}
+
 // ---------------------------------------------------------------------------- DropPath masks
 // timm DropPath: mask = floor(keep + U[0,1)), factor = mask / keep.  One launch produces, for every DropPath site of
 // a forward pass: the per-sample factors, the 0/1 masks and the per-token bf16 masks the bias gradients read (16-byte aligned rows).
@@ -421,6 +438,20 @@ int ap_quantize_fp8_multi(const ap_fp8_job* jobs_device, int njobs, const float*
     if (njobs == 0) return AP_OK;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_quantize_fp8_multi, dim3(32, njobs), dim3(256), 0, (hipStream_t)stream, jobs_device, scales, amax);
+    return ap_check_launch();
+}
+
+int ap_debug_poison_lds(unsigned pattern, unsigned* scratch2, ap_stream_t stream) {
+    if (!scratch2) return AP_ERR_NULL;
+    int dev = 0, ncu = 256;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_poison_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    (void)hipGetLastError();
+    if (hipMemsetAsync(scratch2, 0, 8, (hipStream_t)stream) != hipSuccess) return AP_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_poison_lds, dim3(ncu), dim3(1024), 160 * 1024, (hipStream_t)stream, pattern, scratch2, ncu);
     return ap_check_launch();
 }
 

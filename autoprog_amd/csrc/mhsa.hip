@@ -385,7 +385,7 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
                 const f32x4 fd4 = *reinterpret_cast<const f32x4*>(fd + q0 + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -fl4[r]));
+                    const float pv = __builtin_amdgcn_exp2f(fminf(fmaf(sc[r], c2, -fl4[r]), ATT_PCAP));
                     p[hf][r] = pv;
                     ds[hf][r] = pv * (dp[r] - fd4[r]);                // the softmax scale is applied once to dK / dQ
                 }
@@ -431,8 +431,8 @@ k_mhsa_bwd(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    // padded keys need no mask here: their K rows are zero, so they add nothing to dQ
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -flq));
+                    // padded keys: their K rows are zero, so they add nothing to dQ -- as long as p stays finite (ATT_PCAP, attn_frag.h)
+                    const float pv = __builtin_amdgcn_exp2f(fminf(fmaf(sc[r], c2, -flq), ATT_PCAP));
                     ds[hf][r] = pv * (dp[r] - fdq);
                 }
             }
@@ -623,7 +623,7 @@ k_mhsa_bwd_ds(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, co
                     const f32x4 fl4 = *reinterpret_cast<const f32x4*>(fl + q0 + 4 * g);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -fl4[r]));
+                        const float pv = __builtin_amdgcn_exp2f(fminf(fmaf(sc[r], c2, -fl4[r]), ATT_PCAP));
                         p[hf][r] = pv;
                         ds[hf][r] = pv * dp[r];                                   // the softmax scale is applied once to dK / dQ
                     }

@@ -268,7 +268,7 @@ k_mhsa_flash_bwd_kv(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d
                 const f32x4 fd4 = *reinterpret_cast<const f32x4*>(fdb + q0 + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -fl4[r]));
+                    const float pv = __builtin_amdgcn_exp2f(fminf(fmaf(sc[r], c2, -fl4[r]), ATT_PCAP));
                     p[hf][r] = pv;
                     ds[hf][r] = pv * (dp[r] - fd4[r]);
                 }
@@ -354,7 +354,7 @@ k_mhsa_flash_bwd_q(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ do
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // padded keys need no mask: their K rows are zero in LDS, so they add nothing to dQ
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, -flq));
+                    const float pv = __builtin_amdgcn_exp2f(fminf(fmaf(sc[r], c2, -flq), ATT_PCAP));
                     ds[hf][r] = pv * (dp[r] - fdq);
                 }
             }

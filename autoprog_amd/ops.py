@@ -185,6 +185,13 @@ def quantize_fp8_multi(table, njobs, scales, amax):
           "ap_quantize_fp8_multi")
 
 
+def poison_lds(pattern=0x7FC07FC0):
+    """test aid: every CU's LDS filled with `pattern` (default: bf16 NaN pairs)"""
+    scratch = torch.zeros(2, dtype=torch.int32, device="cuda")
+    check(lib.ap_debug_poison_lds(int(pattern) & 0xFFFFFFFF, scratch.data_ptr(), _stream()), "ap_debug_poison_lds")
+    return scratch
+
+
 def quantize_fp8_now(x):
     """current scaling (one extra pass for the amax): -> (bytes, dequantisation factor as a device scalar)"""
     amax = x.abs().amax().float().clamp_min(1e-12).reshape(1)

@@ -122,6 +122,10 @@ int ap_quantize_fp8(const ap_bf16* x, unsigned char* y, int64_t n, const float* 
  * job j is scaled by scales[slot] and raises amax[slot] (n % 16 == 0) */
 typedef struct ap_fp8_job { const ap_bf16* x; unsigned char* y; int64_t n; int slot; int pad_; } ap_fp8_job;
 int ap_quantize_fp8_multi(const ap_fp8_job* jobs_device, int njobs, const float* scales, float* amax, ap_stream_t stream);
+
+/* ---- test aid: fill all 160 KB of LDS of every CU with `pattern` (one workgroup per CU; scratch2: 8 bytes of device memory).  A kernel
+ * that reads LDS it never wrote (padded rows of a tile) then sees NaNs instead of the previous kernel's leftovers: tests/test_gpu_kernels.py */
+int ap_debug_poison_lds(unsigned pattern, unsigned* scratch2, ap_stream_t stream);
 /* C = epi(dq_a[0] * dq_b[0] * A8 . B8^T): A8 [M,K], B8 [N,K] e4m3 bytes (K, lda, ldb multiples of 16), dq_* device scalars (1/scale);
  * same epilogue as ap_gemm_nt */
 int ap_gemm_nt_fp8(const unsigned char* A, int lda, const unsigned char* B, int ldb, ap_bf16* C, int ldc, int M, int N, int K,

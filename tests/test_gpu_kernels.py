@@ -856,3 +856,72 @@ def test_fp8_producers_match_the_quantiser(ops):
         a1 = torch.zeros(1, device="cuda")
         assert torch.equal(o, ops.quantize_fp8(w, scales[s:s + 1].contiguous(), a1)) and float(amax[s]) == float(a1)
     assert float(amax[2]) == 0.0
+
+
+@pytest.mark.parametrize("B,N,heads,hd", [(4, 196, 3, 32), (2, 100, 2, 32), (2, 196, 2, 64), (2, 300, 2, 32), (2, 300, 2, 48), (2, 49, 2, 32), (2, 256, 2, 32)])
+def test_mhsa_backward_with_very_negative_logits(ops, B, N, heads, hd):
+    """every logit of every row ~ -110, so lse < -88: a padded key (zero K row, s = 0) of the last key tile then has exp(-lse) = inf in
+    fp32, and inf times its zero K row put NaN into dQ -- in all three backward kernels, found by a 300-step run on one batch
+    (tools/soak.py) once a head's logits had drifted there.  The kernels clamp the exponent (ATT_PCAP); result against fp32 autograd."""
+    C = heads * hd
+    g = torch.Generator(device="cuda").manual_seed(N + hd)
+    w = torch.nn.functional.normalize(torch.randn(1, 1, heads, hd, device="cuda", generator=g), dim=-1) * hd ** 0.5
+    c = (110.0 / hd ** 0.5) ** 0.5
+    q = c * w + 0.2 * torch.randn(B, N, heads, hd, device="cuda", generator=g)
+    k = -c * w + 0.2 * torch.randn(B, N, heads, hd, device="cuda", generator=g)
+    v = torch.randn(B, N, heads, hd, device="cuda", generator=g)
+    qkv = torch.stack([q, k, v], dim=2).reshape(B * N, 3 * C).to(torch.bfloat16)
+    do = (torch.randn(B * N, C, device="cuda", generator=g) * 0.01).to(torch.bfloat16)
+    scale = hd ** -0.5
+    o, lse = ops.mhsa_fwd(qkv, B, N, heads, scale)
+    assert float(lse.max()) < -88.0
+    d = ops.mhsa_bwd(qkv, o, do, lse, B, N, heads, scale)
+    qf = qkv.float().reshape(B, N, 3, heads, hd).requires_grad_(True)
+    S = torch.einsum("bnhd,bmhd->bhnm", qf[:, :, 0], qf[:, :, 1]) * scale
+    oref = torch.einsum("bhnm,bmhd->bnhd", torch.softmax(S, -1), qf[:, :, 2]).reshape(B * N, C)
+    oref.backward(do.float())
+    assert rel(o, oref) < TOL_BF16
+    assert bool(torch.isfinite(d.float()).all())
+    assert rel(d, qf.grad.reshape(B * N, 3 * C)) < TOL_BF16
+
+
+def test_kernels_do_not_depend_on_what_lds_held_before(ops):
+    """ap_debug_poison_lds fills every CU's LDS with NaN patterns; kernels with padded tiles (196 tokens in 16-row tiles, ragged GEMM
+    edges, odd feature maps) must give the same, finite results as on a clean LDS"""
+    torch.manual_seed(0)
+    cases = {}
+    B, N, heads, hd = 4, 196, 6, 32
+    qkv = torch.randn(B * N, 3 * heads * hd, device="cuda").to(torch.bfloat16)
+    do = torch.randn(B * N, heads * hd, device="cuda").to(torch.bfloat16)
+    o, lse = ops.mhsa_fwd(qkv, B, N, heads, hd ** -0.5)
+    cases["mhsa_fwd"] = lambda: ops.mhsa_fwd(qkv, B, N, heads, hd ** -0.5)
+    cases["mhsa_bwd"] = lambda: (ops.mhsa_bwd(qkv, o, do, lse, B, N, heads, hd ** -0.5),)
+    q2 = torch.randn(2 * 300, 3 * 2 * 48, device="cuda").to(torch.bfloat16); d2 = torch.randn(2 * 300, 96, device="cuda").to(torch.bfloat16)
+    o2, l2 = ops.mhsa_fwd(q2, 2, 300, 2, 48 ** -0.5)
+    cases["flash_fwd"] = lambda: ops.mhsa_fwd(q2, 2, 300, 2, 48 ** -0.5)
+    cases["flash_bwd"] = lambda: (ops.mhsa_bwd(q2, o2, d2, l2, 2, 300, 2, 48 ** -0.5),)
+    a = torch.randn(4100, 384, device="cuda").to(torch.bfloat16); w = (torch.randn(1152, 384, device="cuda") * 0.05).to(torch.bfloat16)
+    cases["gemm_nt_8p"] = lambda: (ops.gemm_nt(a, w),)
+    cases["gemm_nt_small"] = lambda: (ops.gemm_nt(a[:300].contiguous(), w),)
+    g = torch.randn(4160, 384, device="cuda").to(torch.bfloat16); x = torch.randn(4160, 576, device="cuda").to(torch.bfloat16)
+    def tn(gg, xx):
+        c = torch.zeros(384, 576, device="cuda"); ops.gemm_tn_acc(gg, xx, c); return (c,)
+    cases["gemm_tn_8p"] = lambda: tn(g, x)
+    cases["gemm_tn_128"] = lambda: tn(g[:1000].contiguous(), x[:1000].contiguous())
+    v = torch.randn(2, 27, 25, 64, device="cuda").to(torch.bfloat16); lg = torch.randn(2 * 14 * 13, 168, device="cuda").to(torch.bfloat16)
+    dyo = torch.randn(2, 27, 25, 64, device="cuda").to(torch.bfloat16)
+    cases["outlook_fwd"] = lambda: (ops.outlook_fwd(v, lg, 2, 32 ** -0.5),)
+    cases["outlook_bwd"] = lambda: ops.outlook_bwd(v, lg, dyo, 2, 32 ** -0.5)
+    xc = torch.randn(2, 37, 21, 64, device="cuda").to(torch.bfloat16)
+    wf, wb = ops.conv3x3_pack(torch.randn(64, 64, 3, 3, device="cuda") * 0.05)
+    cases["conv3x3"] = lambda: (ops.conv3x3_c64(xc, wf),)
+    xl = torch.randn(777, 384, device="cuda").to(torch.bfloat16); gl, bl = torch.randn(384, device="cuda"), torch.randn(384, device="cuda")
+    cases["layernorm_fwd"] = lambda: ops.layernorm_fwd(xl, gl, bl, 1e-5)
+    for name, fn in cases.items():
+        ref = fn()
+        for pat in (0x7FC07FC0, 0xFFFFFFFF, 0x7F807F80):
+            ops.poison_lds(pat)
+            out = fn()
+            for a_, b_ in zip(out, ref):
+                assert bool(torch.isfinite(a_.float()).all()), (name, hex(pat))
+                assert torch.allclose(a_.float(), b_.float(), rtol=1e-2, atol=1e-2), (name, hex(pat))
