@@ -1027,7 +1027,7 @@ static int tn_plan(const ap_tn_problem* problems, int count, TnGroup& grp, int& 
     if (capacity == 0) {
         const char* e = getenv("AP_GEMM_TN_GROUP_BLOCKS");
         if (e) capacity = atoi(e);
-        else { int dev = 0; hipGetDevice(&dev); hipDeviceProp_t pr; capacity = 2 * ((hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256); }
+        else { int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr; capacity = 2 * ((hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256); }
     }
     int max_steps = 1;
     for (int i = 0; i < count; ++i) {
@@ -1291,7 +1291,7 @@ static int tn_grouped_128(const ap_tn_problem* problems, int count, const ap_ln_
         static int place = -1, cap = 0;
         if (place < 0) {
             const char* e = getenv("AP_GEMM_TN_PLACE"); place = e ? atoi(e) : 1;
-            int dev = 0; hipGetDevice(&dev); hipDeviceProp_t pr;
+            int dev = 0; (void)hipGetDevice(&dev); hipDeviceProp_t pr;
             cap = 2 * ((hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256) / 8;     // resident workgroups per XCD
         }
         TnMap map; int mblocks = 0;

@@ -78,5 +78,6 @@ for i in range(steps):
     opt.step()
     if i % 25 == 0 or i == steps - 1:
         gn = float(red.flat.norm()) * red.grad_scale
-        out.append("%d:%.4f(g%.2e)" % (i, float(loss), gn))
+        out.append("%d:%.4f(g%.2e,%.2fGB)" % (i, float(loss), gn, torch.cuda.memory_allocated() / 2 ** 30))
 print(" ".join(out))
+print("peak allocated %.2f GB, reserved %.2f GB" % (torch.cuda.max_memory_allocated() / 2 ** 30, torch.cuda.memory_reserved() / 2 ** 30))
