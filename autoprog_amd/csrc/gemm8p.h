@@ -45,6 +45,9 @@
 #include "gemm_epi.h"
 #include <type_traits>
 
+#ifndef G8_NT_STORE
+#define G8_NT_STORE 1          // the epilogue's row stores bypass L2 allocation (nontemporal): the outputs are read by the NEXT kernel, behind an L2 write-back anyway
+#endif
 #define G8_LDS_BYTES 163840                    // all of the CU's LDS: two K-tile buffers + the epilogue staging region
 
 #define G8_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -86,6 +89,9 @@ __host__ __device__ inline int g8_flavour(const EpiArgs& ep) {
 // operands), and the accumulators are multiplied by dq_a[0] * dq_b[0] before the epilogue.  Half the operand bytes per FLOP.
 // (one v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales on the two 16-byte fragments of a row's 128-byte K-tile: the double-rate
 // fp8 instruction of gfx950; the pair of v_mfma_f32_16x16x32_fp8_fp8 per fragment of the first version ran at the bf16 rate)
+__device__ __forceinline__ void g8_store(bf16_t* p, const u32x4& v) {
+    if (G8_NT_STORE) st16_nt(p, v); else st16(p, v);
+}
 typedef int __attribute__((ext_vector_type(8))) g8_i32x8;
 __device__ __forceinline__ f32x4 g8_mma_bf16(const u32x4& b, const u32x4& a, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(b), as_bf16x8(a), c, 0, 0, 0);
@@ -553,9 +559,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                                     gp[q] = fmaf(f[q] * 0.39894228040143268f, e, c);
                                     f[q] = f[q] * c * rs;
                                 }
-                                st16(ep.preact + (int64_t)m * ga.ldc + n, pack8(gp));
+                                g8_store(ep.preact + (int64_t)m * ga.ldc + n, pack8(gp));
                             } else {
-                                if (ep.preact) st16(ep.preact + (int64_t)m * ga.ldc + n, x);
+                                if (ep.preact) g8_store(ep.preact + (int64_t)m * ga.ldc + n, x);
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) f[q] = gelu_erf(f[q]) * rs;
                             }
@@ -579,7 +585,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                                 }
                             }
                         }
-                        if (!(G8_ABL & 32)) st16(ga.C + (int64_t)m * ga.ldc + n, x);
+                        if (!(G8_ABL & 32)) g8_store(ga.C + (int64_t)m * ga.ldc + n, x);
                         else asm volatile("" :: "v"(x));
                     }
                     if constexpr (FP8) {

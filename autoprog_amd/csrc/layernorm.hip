@@ -90,7 +90,7 @@ k_ln_fwd(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const fl
 #pragma unroll
                     for (int k = 0; k < 8; ++k) o8[k] = (v[i][k] - mu) * rs * gam[i][k] + bet[i][k];
                     const u32x4 ob = pack8(o8);
-                    st16(y + row * C + 8 * ch, ob);
+                    st16_nt(y + row * C + 8 * ch, ob);
                     if (y8) {
                         float r8[8];
                         unpack8(ob, r8);
@@ -202,7 +202,7 @@ k_ln_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const floa
                     unpack8(rres[u][i], o8);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) o8[k] += rs[u] * (g[i][k] - s1 - xh[i][k] * s2);
-                    st16(dx + row * C + 8 * ch, pack8(o8));
+                    st16_nt(dx + row * C + 8 * ch, pack8(o8));
                 }
             }
         }
