@@ -245,7 +245,7 @@ __device__ __forceinline__ void t8_item(const T8Item& it, int tile, int split, u
 #pragma unroll
             for (int b = 0; b < 3; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) crow[(int64_t)(a * 16 + r) * it.ldc + b * 16] = fmaf(acc[a][b][r], it.alpha, old[b][r]);
+                for (int r = 0; r < 4; ++r) __builtin_nontemporal_store(fmaf(acc[a][b][r], it.alpha, old[b][r]), crow + (int64_t)(a * 16 + r) * it.ldc + b * 16);
         }
         if (cs_wave && fr == 0) {
 #pragma unroll
