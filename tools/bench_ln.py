@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from autoprog_amd import ops
 from autoprog_amd._lib import lib
-for T, C in [(25088, 384), (100352, 192), (12544, 768)]:
+for T, C in [(25088, 384), (100352, 384), (401408, 384), (100352, 192), (12544, 768)]:
     n = max(2, int(400e6 / (T * C * 2 * 4)))
     xs = [torch.randn(T, C, device="cuda").bfloat16() for _ in range(n)]
     dys = [torch.randn(T, C, device="cuda").bfloat16() for _ in range(n)]
