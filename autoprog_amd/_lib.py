@@ -110,6 +110,7 @@ _SIGNATURES["ap_conv3x3_c64_wgrad"] = (_I, [_P, _P, _P, _I, _I, _I, _P, ctypes.c
 _SIGNATURES["ap_sum_reps_acc"] = (_I, [_P, _P, _L, _I, _P])
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+EXPECTED_ABI = 4                     # ap_abi_version() of the library these ctypes Structures mirror (include/autoprog_hip.h)
 
 
 class AutoProgHipError(RuntimeError):
@@ -122,6 +123,11 @@ def _load():
             "libautoprog_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C autoprog_amd/csrc`; there is no CPU/PyTorch fallback." % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    lib.ap_abi_version.restype = ctypes.c_int
+    got = lib.ap_abi_version()
+    if got != EXPECTED_ABI:          # (a stale or ablation .so with every symbol but older structs would read garbage past their end)
+        raise AutoProgHipError("%s has ABI version %d, these bindings were written for %d: rebuild it (make -C autoprog_amd/csrc)"
+                               % (LIB_PATH, got, EXPECTED_ABI))
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
         fn.restype = res

@@ -14,6 +14,7 @@
 // dA = s*P*(dP - sum_q P*dP).
 #include "common.h"
 #include <cstdlib>
+#include <algorithm>
 
 // acc += a.lo*b.lo + a.hi*b.hi on packed bf16 pairs, fp32 accumulate.  Inline asm: hipcc (ROCm 7.2) miscompiles
 // __builtin_amdgcn_fdot2_f32_bf16 on elements of a 4 x u32 vector (every call reads element 0; tools/probe/dot2.hip)
@@ -21,6 +22,10 @@ __device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float acc) {
     asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
     return acc;
 }
+// hipcc's hazard recognizer does not look inside inline asm: a DOT result read by another VALU instruction needs 3 wait states on
+// gfx940+ and gets none (seen in round 4: a v_pk_mul_f32 scheduled right behind the last v_dot2c of a chain read the accumulator
+// one term short -- dlogits 4.5 % off).  Close every chain with this before its sum is used.
+__device__ __forceinline__ void dot2_done(float& acc) { asm volatile("s_nop 2" : "+v"(acc)); }
 #define OHD 32          // head dim handled by these kernels
 #define OKK 9           // 3x3 slots
 #define OPP 81
@@ -209,6 +214,7 @@ k_outlook_dlogits(const bf16_t* __restrict__ v, const bf16_t* __restrict__ dy, c
 #pragma unroll
                 for (int k = 0; k < 4; ++k) s = dot2_bf16(g[c][k], f[k], s);
             }
+            dot2_done(s);
             dP[q] = s;
             pr[q] = Prow[q];
             dot += pr[q] * s;
@@ -409,6 +415,311 @@ k_outlook_gather_mfma(const bf16_t* __restrict__ in, const bf16_t* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ persistent kernels (round 4)
+// The kernels above run one (image, strip, head) per workgroup: global loads -> LDS -> barrier -> MFMA -> barrier -> fold, three
+// workgroups per CU, ~15 workgroups per CU one after the other -- every one of them exposes a memory latency, and every one of them
+// derives its indices (five non-constant integer divisions per thread and phase) again.  Here a workgroup is PERSISTENT: it walks items
+// it = first + k * grid, keeps the index tables of its threads in registers (they depend on the thread, not on the item), and requests
+// item k+1's pixels and logits into registers right after it has dropped item k's into LDS -- the loads land under the MFMA and fold
+// phases of item k behind LDS-only barriers (nobody waits for them or for the result stores).
+//   BWD = false:  Y = fold(softmax(A) V)                                   (models/volo.py:83-98)
+//   BWD = true :  dV = fold'(softmax(A)^T dY)  AND  dA = s P (dP - <P, dP>), dP = <dY[src p], V[src q]>  in ONE kernel: dY, the logits and
+//                 the softmax are read / computed once for both (two launches before: 227 MB -> 165 MB of traffic per call)
+// P goes to LDS row-major as bf16 rows of 16 (slots 9..15 zero) for both directions; the transposed operand of the backward fold is read
+// with ds_read_b64_tr_b16 (rows 9..15 of the transposed matrix come from a zeroed row behind the nine).
+#ifndef OLK_ABL
+#define OLK_ABL 0      // timing-only ablations (tools/abl.sh outlook OLK_ABL n; results WRONG): 1 no MFMA phase, 2 no fold, 4 no output stores, 8 no
+#endif                 // loads after the first item, 16 no softmax, 32 no dlogits rows, 64 no patch stores to LDS
+#define OLK_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+struct OlkArgs {
+    const bf16_t* v; const bf16_t* dy; const bf16_t* logits; bf16_t* out; bf16_t* dlogits;
+    int ldl, B, H, W, heads, SR, nstrips, nitems, wp_shift;
+    float scale;
+};
+
+template <int T, int NSU, int NPU, bool BWD>
+__global__ void __launch_bounds__(T, (BWD ? 2 : 3) * T / 256)          // waves per SIMD: three (forward) / two (backward) workgroups per CU
+k_outlook_p(OlkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int H = a.H, W = a.W, heads = a.heads, SR = a.SR, ldl = a.ldl;
+    const int h = (H + 1) >> 1, w = (W + 1) >> 1, C = heads * OHD, pw = 2 * w + 1;
+    const int PH = 2 * SR + 3, npix = PH * pw, NWR = SR + 1;
+    const int npixc = pad_npix(npix);
+    bf16_t* const pm = reinterpret_cast<bf16_t*>(smem_raw);           // pixel-major patch [npix][32]: V (forward) / dY (backward): the MFMA operand
+    bf16_t* const pvc = pm + (size_t)npix * OHD;                        // BWD: chunk-major V patch [4][npixc][8] (16-byte reads of neighbouring pixels)
+    bf16_t* const PZ = BWD ? pvc + (size_t)npixc * OHD : pvc;           // [NWR * w][9][32]: P rows (16 used per row, + a zero row), then Z
+    bf16_t* const dA = PZ + (size_t)NWR * w * OPZ;                      // BWD: [SR * w][81] bf16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    // ---- per-thread tables (functions of the thread, not of the item)
+    int s_goff[NSU], s_pr[NSU];                  // patch chunk u of this thread: element offset from (row y0, column 0, this head); patch row (or -1)
+    bool s_xok[NSU];
+#pragma unroll
+    for (int u = 0; u < NSU; ++u) {
+        const int idx = tid + u * T;
+        const int c = idx & 3, pix = idx >> 2;
+        const int pr = pix / pw, pc = pix - pr * pw, x = pc - 1;
+        s_pr[u] = idx < npix * 4 ? pr : -1;
+        s_xok[u] = x >= 0 && x < W;
+        s_goff[u] = (pr * W + x) * C + c * 8;
+    }
+    int r_loff[NPU], r_wl[NPU], r_p[NPU], r_pix[NPU];   // softmax row u: logits offset from the strip's first window, local window, row p, patch pixel of slot (0,0)
+#pragma unroll
+    for (int u = 0; u < NPU; ++u) {
+        const int r = tid + u * T;
+        const int wl = r / OKK, p = r - wl * OKK;
+        const int wi = wl / w, wj = wl - wi * w;
+        r_wl[u] = wl; r_p[u] = p;
+        r_loff[u] = wl * ldl + p * OKK;
+        r_pix[u] = (2 * wi) * pw + 2 * wj;
+    }
+
+    // ---- item walk: workgroups of one XCD (blockIdx % 8) take neighbouring items in every round, so the heads of an (image, strip)
+    // -- which share cache lines -- meet in one L2
+    const int G = gridDim.x;
+    int item = xcd_remap(blockIdx.x, G);
+    u32x4 fm[NSU], fv[BWD ? NSU : 1];
+    unsigned lg[NPU][5];
+    int I0, nq, nwr, head, b;
+    auto decode = [&](int it, int& b_, int& head_, int& I0_, int& nq_, int& nwr_) {
+        head_ = it % heads; it /= heads;
+        const int strip = it % a.nstrips;
+        b_ = it / a.nstrips;
+        I0_ = strip * SR; nq_ = min(SR, h - I0_); nwr_ = min(nq_ + 1, h - I0_);
+    };
+    auto request = [&](int it) {                 // global -> registers
+        int b_, head_, I0_, nq_, nwr_;
+        decode(it, b_, head_, I0_, nq_, nwr_);
+        const int y0 = 2 * I0_ - 1, ph = 2 * nq_ + 3;
+        const int64_t base = ((int64_t)b_ * H + y0) * W * C + head_ * OHD;
+#pragma unroll
+        for (int u = 0; u < NSU; ++u) {
+            const int y = y0 + s_pr[u];
+            const bool ok = s_pr[u] >= 0 && s_pr[u] < ph && s_xok[u] && y >= 0 && y < H;
+            fm[u] = ok ? ld16((BWD ? a.dy : a.v) + base + s_goff[u]) : zero4;
+            if constexpr (BWD) fv[u] = ok ? ld16(a.v + base + s_goff[u]) : zero4;
+        }
+        const bf16_t* lbase = a.logits + ((int64_t)b_ * h + I0_) * w * ldl + head_ * OPP;
+        const int nrows = nwr_ * w * OKK;
+#pragma unroll
+        for (int u = 0; u < NPU; ++u) {
+            // the row's 9 bf16 (18 bytes, 2-byte aligned) as five aligned dwords; the halfword in front of / behind the row lies inside the matrix
+            const int r = tid + u * T;
+            const int off = r < nrows ? r_loff[u] : 0;
+            const int odd = (head_ + (r < nrows ? r_p[u] : 0)) & 1;
+            const unsigned* a4 = reinterpret_cast<const unsigned*>(lbase + off - odd);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) lg[u][k] = a4[k];
+        }
+    };
+    if (item < a.nitems) request(item);
+    while (item < a.nitems) {
+        decode(item, b, head, I0, nq, nwr);
+        const int nwin = nwr * w;
+        // ---- (A) registers -> LDS: patches; softmax rows -> P
+#pragma unroll
+        for (int u = 0; u < NSU; ++u) {
+            const int idx = tid + u * T;
+            if (s_pr[u] >= 0 && !(OLK_ABL & 64)) {
+                st16(pm + (size_t)idx * 8, fm[u]);
+                if constexpr (BWD) st16(pvc + ((size_t)(idx & 3) * npixc + (idx >> 2)) * 8, fv[u]);
+            }
+        }
+        float prow[NPU][OKK];
+#pragma unroll
+        for (int u = 0; u < NPU; ++u) {
+            if (OLK_ABL & 16) {
+#pragma unroll
+                for (int q = 0; q < OKK; ++q) prow[u][q] = __uint_as_float(lg[u][q >> 1]);
+                continue;
+            }
+            const int r = tid + u * T;
+            const int p = r_p[u];
+            const unsigned sh = ((head + p) & 1) << 4;         // the row starts at the high half of its first dword
+            unsigned al[5];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) al[k] = __builtin_amdgcn_alignbit(lg[u][k + 1], lg[u][k], sh);
+            al[4] = lg[u][4] >> sh;
+            float sv[OKK];
+#pragma unroll
+            for (int q = 0; q < OKK; ++q) sv[q] = (q & 1) ? bf_hi(al[q >> 1]) : bf_lo(al[q >> 1]);
+            float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(fmaxf(sv[6], sv[7]), sv[8])));
+            // softmax(s x): exp2((x - max x) s log2 e)  (s > 0), one fma per element in front of the v_exp
+            const float c2 = a.scale * 1.4426950408889634f, nm = -mx * c2;
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < OKK; ++q) { sv[q] = __builtin_amdgcn_exp2f(fmaf(sv[q], c2, nm)); sum += sv[q]; }
+            const float inv = __builtin_amdgcn_rcpf(sum);
+            float o8[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o8[q] = q < OKK ? sv[q] * inv : 0.f;
+#pragma unroll
+            for (int q = 0; q < OKK; ++q) prow[u][q] = o8[q];
+            if (r < nwin * OKK) {
+                bf16_t* slot = PZ + (size_t)r_wl[u] * OPZ;
+                st16(slot + p * 16, pack8(o8));
+                st16(slot + p * 16 + 8, pack8(o8 + 8));
+                if (BWD && p == 0) { st16(slot + 144, zero4); st16(slot + 152, zero4); }      // the zero row of the transposed read
+            }
+        }
+        const int next = item + G;
+        if (next < a.nitems && !(OLK_ABL & 8)) request(next);
+        OLK_BAR();
+        // ---- (B) Z_w = P_w (or its transpose) x pixels of the window, on the matrix pipe; wave-uniform window walk
+        {
+            const int fr = lane & 15, g = lane >> 4, q4 = fr >> 2, p4 = fr & 3;
+            int wi = 0, wj = wave;
+            while (wj >= w) { wj -= w; ++wi; }
+            for (int wl = wave; wl < ((OLK_ABL & 1) ? 0 : nwin); wl += T / 64) {
+                bf16_t* slot = PZ + (size_t)wl * OPZ;
+                s16x4_t pfrag;
+                if constexpr (BWD) pfrag = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(slot + min(4 * g + q4, OKK) * 16 + p4 * 4));
+                else pfrag = *reinterpret_cast<const s16x4_t*>(slot + min(fr, OKK - 1) * 16 + g * 4);
+                const int kq = min(4 * g + q4, OKK - 1);
+                const int kr = (kq * 11) >> 5;                            // kq / 3 for kq < 9
+                const bf16_t* vpix = pm + ((2 * wi + kr) * pw + 2 * wj + (kq - 3 * kr)) * OHD + p4 * 4;
+                f32x4 z[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const s16x4_t vfrag = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(vpix + t * 16));
+                    z[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vfrag, pfrag, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                }
+                if (fr < OKK) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        u32x2 pk;
+                        pk[0] = pack_bf2(z[t][0], z[t][1]); pk[1] = pack_bf2(z[t][2], z[t][3]);
+                        *reinterpret_cast<u32x2*>(slot + fr * OHD + 16 * t + 4 * g) = pk;
+                    }
+                }
+                wj += T / 64;
+                while (wj >= w) { wj -= w; ++wi; }
+            }
+        }
+        if constexpr (BWD) {
+            // dA rows of the windows this strip owns: one lane per (window, row p) -- the lane that holds the row's probabilities
+#pragma unroll
+            for (int u = 0; u < NPU; ++u) {
+                const int r = tid + u * T;
+                if (r < nq * w * OKK && !(OLK_ABL & 32)) {
+                    const int p = r_p[u];
+                    const int pr3 = (p * 11) >> 5, pc3 = p - 3 * pr3;
+                    u32x4 gch[4];
+                    const bf16_t* gp = pm + (size_t)(r_pix[u] + pr3 * pw + pc3) * OHD;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gch[c] = ld16(gp + c * 8);
+                    float dP[OKK];
+                    float dot = 0.f;
+#pragma unroll
+                    for (int q = 0; q < OKK; ++q) {
+                        const bf16_t* vp = pvc + (size_t)(r_pix[u] + (q / 3) * pw + (q % 3)) * 8;
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const u32x4 f = ld16(vp + (size_t)c * npixc * 8);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) sacc = dot2_bf16(gch[c][k], f[k], sacc);
+                        }
+                        dot2_done(sacc);
+                        dP[q] = sacc;
+                        dot += prow[u][q] * sacc;
+                    }
+                    bf16_t* drow = dA + (size_t)r_wl[u] * OPP + p * OKK;
+#pragma unroll
+                    for (int q = 0; q < OKK; ++q) drow[q] = f2bf(a.scale * prow[u][q] * (dP[q] - dot));
+                }
+            }
+        }
+        OLK_BAR();
+        // ---- (C) fold: one lane per (output pixel, 8-channel chunk); a group of 16 lanes-pixels shares (row, column parity), so no wave diverges
+        {
+            const int wp = 1 << a.wp_shift;
+            const int nfold = 4 * nq * wp * 4;                     // 2 nq pixel rows x 2 column parities x wp columns x 4 chunks
+            for (int id = tid; id < ((OLK_ABL & 2) ? 0 : nfold); id += T) {
+                const int c = id & 3, pid = id >> 2;
+                const int jj = pid & (wp - 1), t = pid >> a.wp_shift;
+                const int dx = t & 1, yy = t >> 1;
+                const int dy = yy & 1, wi0 = yy >> 1;
+                const int y = 2 * I0 + yy, x = 2 * jj + dx;
+                if (x >= W || y >= H) continue;
+                float acc[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+                auto add = [&](int wi, int wj, int slot9) {
+                    float f[8];
+                    unpack8(ld16(PZ + ((size_t)(wi * w + wj)) * OPZ + slot9 * OHD + c * 8), f);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[k] += f[k];
+                };
+                const bool row2 = dy && (I0 + wi0 + 1 < h), col2 = dx && (jj + 1 < w);
+                const int ar = dy ? 2 : 1, ac = dx ? 2 : 1;
+                add(wi0, jj, ar * 3 + ac);
+                if (col2) add(wi0, jj + 1, ar * 3);
+                if (row2) {
+                    add(wi0 + 1, jj, ac);
+                    if (col2) add(wi0 + 1, jj + 1, 0);
+                }
+                if (!(OLK_ABL & 4)) st16(a.out + (((int64_t)b * H + y) * W + x) * C + head * OHD + c * 8, pack8(acc));
+                else asm volatile("" :: "v"(acc[0]), "v"(acc[7]));
+            }
+        }
+        if constexpr (BWD) {
+            const int64_t win_base = ((int64_t)b * h + I0) * w;
+            const int nown = nq * w;
+            for (int r = tid; r < nown * OPP; r += T) {
+                const int wl2 = r / OPP, e = r - wl2 * OPP;
+                a.dlogits[(win_base + wl2) * ldl + head * OPP + e] = dA[r];
+            }
+            if (head == 0) {                                 // zero the padding columns once per window
+                const int padc = ldl - heads * OPP;
+                for (int r = tid; r < nown * padc; r += T) {
+                    const int wl2 = r / padc, e = r - wl2 * padc;
+                    a.dlogits[(win_base + wl2) * ldl + heads * OPP + e] = 0;
+                }
+            }
+        }
+        OLK_BAR();
+        item = next;
+    }
+}
+
+// geometry of a persistent launch: the tallest strip (<= 3 window rows) whose tables fit the instantiation and whose LDS image leaves
+// `wgs` workgroups per CU; -> SR (0: this shape stays on the one-item-per-workgroup kernels)
+static int olk_pick(int H, int W, bool bwd, int T, int NSU, int NPU, size_t& lds) {
+    const int h = (H + 1) / 2, w = (W + 1) / 2, pw = 2 * w + 1;
+    if (w > 32) return 0;
+    static int sr_env = -1;
+    if (sr_env < 0) { const char* e = getenv("AP_OUTLOOK_SR"); sr_env = e ? atoi(e) : 0; }
+    for (int SR = std::min(sr_env > 0 ? sr_env : 3, h); SR >= 1; --SR) {
+        const int npix = (2 * SR + 3) * pw;
+        if (npix * 4 > NSU * T || (SR + 1) * w * OKK > NPU * T) continue;
+        lds = (size_t)npix * OHD * 2 + (size_t)(SR + 1) * w * OPZ * 2;
+        if (bwd) lds += (size_t)pad_npix(npix) * OHD * 2 + (((size_t)SR * w * OPP * 2 + 15) & ~(size_t)15);
+        if (lds <= 80 * 1024) return SR;
+    }
+    return 0;
+}
+
+template <int T, int NSU, int NPU, bool BWD>
+static int olk_launch(const OlkArgs& a0, int SR, size_t lds, hipStream_t s) {
+    OlkArgs a = a0;
+    const int h = (a.H + 1) / 2, w = (a.W + 1) / 2;
+    a.SR = SR; a.nstrips = (h + SR - 1) / SR; a.nitems = a.B * a.nstrips * a.heads;
+    a.wp_shift = w <= 16 ? 4 : 5;
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k_outlook_p<T, NSU, NPU, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; (void)hipGetLastError(); }
+    const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / T));
+    int grid = std::min(a.nitems, ncu * per_cu);
+    grid = std::max(8, grid & ~7);                      // a multiple of 8: the XCD-contiguous item walk
+    if (grid > a.nitems) grid = a.nitems;
+    hipLaunchKernelGGL((k_outlook_p<T, NSU, NPU, BWD>), dim3((unsigned)grid), dim3(T), lds, s, a);
+    return ap_check_launch();
+}
+
 static int gather_launch(bool tp, const bf16_t* in, const bf16_t* logits, int ldl, bf16_t* out, int B, int H, int W, int heads,
                          float scale, hipStream_t s) {
     const int h = (H + 1) / 2, w = (W + 1) / 2;
@@ -449,6 +760,14 @@ static int gather_launch(bool tp, const bf16_t* in, const bf16_t* logits, int ld
     return ap_check_launch();
 }
 
+// AP_OUTLOOK_P: 1 (default) the persistent kernels with 512-thread workgroups (256 where a shape's tables do not fit 512 threads);
+// 2 the 256-thread instantiations; 0 the one-item-per-workgroup kernels of rounds 1-3
+static int olk_mode() {
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("AP_OUTLOOK_P"); m = e ? atoi(e) : 1; }
+    return m;
+}
+
 extern "C" {
 
 int ap_outlook_fwd(const ap_bf16* v, const ap_bf16* logits, int ldl, ap_bf16* y, int B, int H, int W, int heads, int hd,
@@ -456,6 +775,12 @@ int ap_outlook_fwd(const ap_bf16* v, const ap_bf16* logits, int ldl, ap_bf16* y,
     if (!v || !logits || !y) return AP_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || heads <= 0 || ldl < heads * OPP) return AP_ERR_SHAPE;
     if (hd != OHD) return AP_ERR_UNSUPPORTED;
+    if (olk_mode()) {
+        size_t lds = 0;
+        OlkArgs a = {v, nullptr, logits, y, nullptr, ldl, B, H, W, heads, 0, 0, 0, 0, scale};
+        if (olk_mode() == 1) { if (const int SR = olk_pick(H, W, false, 512, 3, 1, lds)) return olk_launch<512, 3, 1, false>(a, SR, lds, (hipStream_t)stream); }
+        if (const int SR = olk_pick(H, W, false, 256, 5, 2, lds)) return olk_launch<256, 5, 2, false>(a, SR, lds, (hipStream_t)stream);
+    }
     return gather_launch(false, v, logits, ldl, y, B, H, W, heads, scale, (hipStream_t)stream);
 }
 
@@ -464,6 +789,12 @@ int ap_outlook_bwd(const ap_bf16* v, const ap_bf16* logits, int ldl, const ap_bf
     if (!v || !logits || !dy || !dv || !dlogits) return AP_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || heads <= 0 || ldl < heads * OPP) return AP_ERR_SHAPE;
     if (hd != OHD) return AP_ERR_UNSUPPORTED;
+    if (olk_mode()) {
+        size_t lds = 0;
+        OlkArgs a = {v, dy, logits, dv, dlogits, ldl, B, H, W, heads, 0, 0, 0, 0, scale};
+        if (olk_mode() == 1) { if (const int SR = olk_pick(H, W, true, 512, 3, 1, lds)) return olk_launch<512, 3, 1, true>(a, SR, lds, (hipStream_t)stream); }
+        if (const int SR = olk_pick(H, W, true, 256, 5, 2, lds)) return olk_launch<256, 5, 2, true>(a, SR, lds, (hipStream_t)stream);
+    }
     int rc = gather_launch(true, dy, logits, ldl, dv, B, H, W, heads, scale, (hipStream_t)stream);
     if (rc != AP_OK) return rc;
     const int h = (H + 1) / 2, w = (W + 1) / 2;

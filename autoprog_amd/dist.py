@@ -17,8 +17,15 @@ import torch.distributed as dist
 
 
 class GradientBucketReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, world_size=None, defer_mean=False, comm_dtype=None):
-        """defer_mean: finish() leaves the all-reduced SUM in the slab and the consumer applies 1/world itself
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, world_size=None, defer_mean=False, comm_dtype=None,
+                 accumulate_steps=1):
+        """accumulate_steps: micro-batches per optimizer update (the reference's --batch-splits: main_prog.py:567-574 picks the split
+        count per stage, :971 `update = (batch_idx + 1) % batch_splits == 0`, :1019-1027 / prog/scaler.py:60-68 run backward on
+        loss / batch_splits every micro-batch and step the optimizer only on the update one).  Gradients of the first k - 1
+        micro-batches only accumulate in the slab (every kernel adds in place): no parameter is counted ready, no bucket leaves;
+        the k-th backward pass drives the bucketed exchange as usual.  finish() closes a micro-batch; `is_update_step` says whether
+        the one just closed was the k-th.  zero_grad() starts a new update.
+        defer_mean: finish() leaves the all-reduced SUM in the slab and the consumer applies 1/world itself
         (optim.FlatAdamWEma folds it into the fused update kernel via take_pending_scale(): no extra pass over the slab).
         comm_dtype: torch.bfloat16 (or AP_GRAD_COMM_DTYPE=bf16) sends every bucket as bf16 -- half the bytes per xGMI link; the slab
         and the sum stay fp32 on each rank (the bucket is rounded once before the exchange, the exchanged sum is written back as fp32).
@@ -28,6 +35,10 @@ class GradientBucketReducer:
             comm_dtype = torch.bfloat16
         self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
         self._staged = []                  # (bucket range, bf16 copy) of the buckets in flight
+        self.accumulate_steps = max(1, int(accumulate_steps))
+        self._micro = 0                    # micro-batches of the current update already closed by finish()
+        self.is_update_step = True
+        self.launch_log = []               # (bucket, parameters already delivered when it left) -- tests read the overlap from it
         self.defer_mean = defer_mean
         self._pending_scale = 1.0
         self.params = [p for p in params if p.requires_grad]
@@ -83,6 +94,29 @@ class GradientBucketReducer:
         if self.world > 1:
             self._on_grad(p)
 
+    def set_accumulate_steps(self, k):
+        """between updates only (the driver changes the split count with the stage, main_prog.py:842)"""
+        assert self._micro == 0 or self._micro >= self.accumulate_steps, "set_accumulate_steps() inside an update"
+        self.accumulate_steps = max(1, int(k))
+        self._micro = 0
+
+    def _accumulating(self):
+        """True while the running micro-batch is not the last of its update: its gradients only add up in the slab"""
+        return self._micro < self.accumulate_steps - 1
+
+    def completes_a_bucket(self, held_params):
+        """would releasing these held parameters complete a bucket that has not left yet?  (functional's weight-gradient window asks
+        before it decides to launch early)"""
+        if self.world <= 1 or self._accumulating():
+            return False
+        waiting = {}
+        for p in held_params:
+            if id(p) in self._held and id(p) not in self._seen:
+                b = self._bucket_of.get(id(p))
+                if b is not None:
+                    waiting[b] = waiting.get(b, 0) + 1
+        return any(not self._launched[b] and self._pending[b] == n for b, n in waiting.items())
+
     def hold(self, params):
         """the gradients of these parameters are still to be written (functional's weight-gradient window holds their problems): autograd
         runs their AccumulateGrad nodes -- and the post-accumulate hook -- when the block's backward returns, with nothing to accumulate;
@@ -106,7 +140,7 @@ class GradientBucketReducer:
     def _on_grad(self, p):
         # idempotent per step: autograd may still run the AccumulateGrad node (and this hook) of a parameter
         # whose gradient the fused backward already delivered through param_ready()
-        if id(p) in self._seen or id(p) in self._held:
+        if id(p) in self._seen or id(p) in self._held or self._accumulating():
             return
         self._seen.add(id(p))
         b = self._bucket_of[id(p)]
@@ -117,6 +151,7 @@ class GradientBucketReducer:
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
+        self.launch_log.append((b, len(self._seen)))
         buf = self.flat[s:e]
         if self.comm_dtype is not None:
             buf = buf.to(self.comm_dtype)
@@ -136,6 +171,8 @@ class GradientBucketReducer:
         self._staged = []
         self._seen = set()
         self._held = set()
+        self._micro = 0
+        self.launch_log = []
 
     def finish(self):
         """call after backward(): reduce buckets whose hooks did not all fire (skipped layers), wait
@@ -143,6 +180,13 @@ class GradientBucketReducer:
         from . import functional
         functional.flush_wgrad_window()         # (empty after a backward pass: the autograd engine's final callback has flushed it)
         functional.join_wgrad_stream()          # side-stream weight gradients land before anyone reads the slab
+        if self._accumulating():                # a micro-batch that only accumulates: nothing is exchanged, nothing was marked ready
+            self._micro += 1
+            self._held = set()
+            self.is_update_step = False
+            return
+        self._micro = 0 if self.accumulate_steps == 1 else self.accumulate_steps     # (closed: zero_grad() opens the next update)
+        self.is_update_step = True
         if self.world <= 1:
             return
         for b in range(len(self.buckets)):

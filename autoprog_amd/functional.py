@@ -198,7 +198,14 @@ class wgrad_batch:
 # param.grad in place, and the sink hears param_ready() at the flush instead of at the end of the block.
 # AP_WGRAD_WINDOW: tiles per launch (0 = one launch per block, the behaviour before).
 WGRAD_WINDOW = int(os.environ.get("AP_WGRAD_WINDOW", "256"))
-_window = {"problems": [], "ln": [], "params": [], "tiles": 0, "armed": False}
+_window = {"problems": [], "ln": [], "params": [], "tiles": 0, "armed": None, "outs": set()}
+
+# Two private hooks of the autograd engine make the window self-flushing: queue_callback (run at the end of the backward pass the
+# caller is inside) and _current_graph_task_id (which backward pass that is).  Both are probed once; without them the window still
+# works and is flushed by GradientBucketReducer.finish() -- the sink's contract is "call finish() after backward()" either way.
+_ENGINE = getattr(getattr(torch.autograd, "Variable", None), "_execution_engine", None)
+_HAS_ENGINE_CALLBACK = hasattr(_ENGINE, "queue_callback")
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
 
 
 def _tiles_192(prob):
@@ -210,6 +217,19 @@ def _tiles_192(prob):
     return (n1 // 192) * (n2 // 192)
 
 
+def _window_outputs(problems, ln):
+    """addresses a launch of these problems writes: weight / bias gradients and the LayerNorm dgamma / dbeta rows"""
+    outs = set()
+    for q in problems:
+        outs.add(q[2].data_ptr())
+        if q[5] is not None:
+            outs.add(q[5].data_ptr())
+    for (_ws, _n, _c, dgamma, dbeta) in ln:
+        outs.add(dgamma.data_ptr())
+        outs.add(dbeta.data_ptr())
+    return outs
+
+
 def _window_add(problems, ln, params):
     """-> True when the window took the block's weight gradients"""
     from ._lib import TN_MAX_GROUP, LN_MAX_BATCH
@@ -218,15 +238,25 @@ def _window_add(problems, ln, params):
     if len(problems) > TN_MAX_GROUP or len(ln) > LN_MAX_BATCH:
         return False
     w = _window
-    if not w["armed"]:
-        try:                          # inside a backward pass: the engine calls back when it is over
-            torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_window)
-        except RuntimeError:
-            return False
-        w["armed"] = True
+    gid = _graph_task_id() if _graph_task_id is not None else 0
+    if w["armed"] != gid:
+        # first block of THIS backward pass.  Whatever the window still holds belongs to a pass that raised (the engine runs no
+        # callbacks then): those gradients are void, and the operands they pin are released here.
+        if w["armed"] is not None:
+            reset_wgrad_window()
+        if _HAS_ENGINE_CALLBACK and gid != -1:
+            try:                      # inside a backward pass: the engine calls back when it is over
+                _ENGINE.queue_callback(flush_wgrad_window)
+            except RuntimeError:
+                return False
+        w["armed"] = gid
     tiles = sum(_tiles_192(q) for q in problems)
+    outs = _window_outputs(problems, ln)
+    # a parameter that is ALREADY in the window (a block applied twice before one backward, shared weights): its LayerNorm riders
+    # add with plain read-modify-writes and tn8_plan only sees duplicates inside one call -- launch what is held first, so the
+    # two uses are ordered by the stream like the one-launch-per-block path orders them.
     if w["problems"] and (w["tiles"] + tiles > WGRAD_WINDOW or len(w["problems"]) + len(problems) > TN_MAX_GROUP
-                          or len(w["ln"]) + len(ln) > LN_MAX_BATCH):
+                          or len(w["ln"]) + len(ln) > LN_MAX_BATCH or (outs & w["outs"])):
         _window_launch()
     if hasattr(_grad_sink, "hold"):
         _grad_sink.hold(params)       # (autograd fires their post-accumulate hooks when the block's backward returns)
@@ -234,13 +264,20 @@ def _window_add(problems, ln, params):
     w["ln"] += ln
     w["params"] += [p for p in params if p is not None]
     w["tiles"] += tiles
+    w["outs"] |= outs
+    # data parallel: when everything a gradient bucket still waits for sits in this window, launching now lets the bucket's
+    # all-reduce start under the rest of the backward pass (only once the launch is at least 60 % of a full window: a short
+    # launch cuts its problems along the token axis again)
+    if (w["tiles"] * 10 >= WGRAD_WINDOW * 6 and hasattr(_grad_sink, "completes_a_bucket") and _grad_sink.needs_stream_join()
+            and _grad_sink.completes_a_bucket(w["params"])):
+        _window_launch()
     return True
 
 
 def _window_launch():
     w = _window
     problems, ln, params = w["problems"], w["ln"], w["params"]
-    w["problems"], w["ln"], w["params"], w["tiles"] = [], [], [], 0
+    w["problems"], w["ln"], w["params"], w["tiles"], w["outs"] = [], [], [], 0, set()
     if problems:
         ops.gemm_tn_acc_grouped(problems, ln=ln)
     elif ln:
@@ -252,13 +289,13 @@ def _window_launch():
 
 def flush_wgrad_window():
     """launch what the window holds (the end of every backward pass does; harmless when it is empty)"""
-    _window["armed"] = False
+    _window["armed"] = None
     _window_launch()
 
 
 def reset_wgrad_window():
     """drop what a backward pass that raised left behind"""
-    _window.update(problems=[], ln=[], params=[], tiles=0, armed=False)
+    _window.update(problems=[], ln=[], params=[], tiles=0, armed=None, outs=set())
 
 
 fuse_ln_reduce = os.environ.get("AP_FUSE_LN_REDUCE", "1") != "0"

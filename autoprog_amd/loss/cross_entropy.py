@@ -43,6 +43,9 @@ class TokenLabelSoftTargetCrossEntropy(nn.Module):
         return _dense_ce(x.to(torch.bfloat16), target)
 
 
+SPARSE_CE_MAX_PAIRS, SPARSE_CE_MAX_CLASSES = 16, 1024        # CE_MAXK and 64 * 2 * CE_MAXV of csrc/softce.hip
+
+
 class _TokenLabelBase(nn.Module):
     def __init__(self, dense_weight=1.0, cls_weight=1.0, mixup_active=True, classes=1000):
         super().__init__()
@@ -61,7 +64,11 @@ class _TokenLabelBase(nn.Module):
         bbx1, bby1, bbx2, bby2 = bb
         B, N, C = aux_output.shape
         if isinstance(target, SparseTokenLabelTarget):
-            if type(self)._adjust_cls is _TokenLabelBase._adjust_cls and target.idx.is_cuda and target.idx.shape[1] == 2 + N:
+            # the sparse kernel takes up to 16 (class, score) pairs per row -- the mix-token class row carries 2K -- and rows of up to
+            # 1024 (padded) classes; anything beyond is densified and takes the dense kernels
+            K = target.idx.shape[-1]
+            if (type(self)._adjust_cls is _TokenLabelBase._adjust_cls and target.idx.is_cuda and target.idx.shape[1] == 2 + N
+                    and 2 * K <= SPARSE_CE_MAX_PAIRS and -(-C // 8) * 8 <= SPARSE_CE_MAX_CLASSES):
                 lam = 1 - ((bbx2 - bbx1) * (bby2 - bby1) / N)
                 return AF.SparseTokenLabelCEFn.apply(output.to(torch.bfloat16), aux_output.to(torch.bfloat16), target.idx, target.val,
                                                      target.smoothing, float(lam), float(self.cls_weight), float(self.dense_weight))

@@ -200,7 +200,7 @@ def quantize_fp8_now(x):
 
 def gemm_nt_fp8_emits(M, N, K):
     """can this launch also emit its GELU output as e4m3 (q8)?  -- the 8-phase kernel's launches: see use_8p() in csrc/gemm.hip"""
-    return K % 128 == 0 and M >= 4096 and N % 8 == 0 and (N >= 1024 or N % 192 == 0 or (N % 256 == 0 and N >= 192)) and os.environ.get("AP_GEMM_8P", "1") != "0"
+    return K % 128 == 0 and K >= 256 and M >= 4096 and N % 8 == 0 and N >= 192 and (N >= 1024 or N % 192 == 0 or (N % 256 == 0 and N >= 192)) and os.environ.get("AP_GEMM_8P", "1") != "0"
 
 
 def gemm_nt_fp8(a8, b8, dq_a, dq_b, n=None, bias=None, gelu=False, preact_out=None, residual=None, row_scale=None, rows_per_scale=1,

@@ -24,10 +24,17 @@ from .helpers import ActiveLayerMask
 
 class AutoProgDriver:
     def __init__(self, model, loss_fn, optimizer, reducer, get_batch, r_list, l_list, dp_list, grow_epochs, steps_per_epoch,
-                 search_epochs=2, auto_grow=True, probe_batches=4, time_steps=4, seed=0, log=None):
+                 search_epochs=2, auto_grow=True, probe_batches=4, time_steps=4, seed=0, log=None, original_batch_splits=1,
+                 r_max=None):
         """model: supernet sized for l_list[-1] (e.g. volo_h12_l18); optimizer: FlatAdamWEma over it; reducer: its
         GradientBucketReducer; r_list / l_list / dp_list / grow_epochs: the stage schedule (prog/progressive.py:4-31);
-        get_batch(r): a training batch (images at ANY size -- the stem resizes to r -- and a token-label target for r // 16)."""
+        get_batch(r): a training batch (images at ANY size -- the stem resizes to r -- and a token-label target for r // 16).
+        original_batch_splits: the reference's --batch-splits-list[-1] (main_prog.py:567): micro-batches per update at the LARGEST
+        (l, r); a stage runs `get_divisor(original_batch_splits, l r^2 / (l_max r_max^2))` of them (main_prog.py:570, 842) -- the
+        driver then calls get_batch(r, splits) and expects a micro-batch of batch_size // splits images (get_batch(r) when 1)."""
+        self.original_batch_splits = int(original_batch_splits)
+        self.r_max = r_max if r_max is not None else max(r_list)
+        self.batch_splits = 1
         self.model, self.loss_fn, self.opt, self.reducer, self.get_batch = model, loss_fn, optimizer, reducer, get_batch
         self.r_list, self.l_list, self.dp_list, self.grow_epochs = list(r_list), list(l_list), list(dp_list), list(grow_epochs)
         self.steps_per_epoch, self.search_epochs, self.auto_grow = steps_per_epoch, search_epochs, auto_grow
@@ -58,6 +65,13 @@ class AutoProgDriver:
             self.opt.grow(self.mask, new_mask, model_source="ema_last" if l >= self.current_l else "model")
         self.mask = self._activate(l, r, dp)
         self.current_l, self.current_r, self.current_dp = l, r, dp
+        self.batch_splits = self.splits_for(l, r)
+
+    def splits_for(self, l, r):
+        """micro-batches per update at (l, r): main_prog.py:568-570, 839-842"""
+        if self.original_batch_splits <= 1:
+            return 1
+        return S.get_divisor(self.original_batch_splits, (l * r * r) / (self.l_max * self.r_max * self.r_max))
 
     def _rank_mean(self, values):
         """mean over the ranks of the reducer's process group of a list of host floats (the reference reduces its probe losses
@@ -72,15 +86,25 @@ class AutoProgDriver:
         dist.all_reduce(t, group=self.reducer.group)
         return (t / world).tolist()
 
-    def _train_step(self, l, r, dp):
+    def _train_step(self, l, r, dp, splits=None):
+        """one optimizer update = `splits` micro-batches, backward on loss / splits each (main_prog.py:1019 `loss / args.batch_splits`),
+        the gradient exchange and the optimizer on the last one (`update`, main_prog.py:971,1026).  -> mean loss (device scalar)"""
         self._activate(l, r, dp)
-        images, target = self.get_batch(r)
+        k = self.splits_for(l, r) if splits is None else splits
+        if hasattr(self.reducer, "set_accumulate_steps"):
+            self.reducer.set_accumulate_steps(k)
+        elif k != 1:
+            raise ValueError("batch splits need a reducer with accumulate_steps")
         self.reducer.zero_grad()
-        loss = self.loss_fn(self.model(images), target)
-        loss.backward()
-        self.reducer.finish()
+        total = None
+        for _ in range(k):
+            images, target = self.get_batch(r) if k == 1 else self.get_batch(r, k)
+            loss = self.loss_fn(self.model(images), target)
+            (loss if k == 1 else loss / k).backward()
+            self.reducer.finish()
+            total = loss.detach() if total is None else total + loss.detach()
         self.opt.step()
-        return loss.detach()
+        return total if k == 1 else total / k
 
     # ------------------------------------------------------------------ search (main_prog.py:1558-1821)
     def _probe(self, cands, ema_index=0):
@@ -89,12 +113,14 @@ class AutoProgDriver:
         with self.opt.ema_weights(ema_index), torch.no_grad():
             for (r, l) in cands:
                 self._activate(l, r, 0.0)
-                tot = 0.0
+                tot = None
                 for _ in range(self.probe_batches):
                     images, target = self.get_batch(r)
-                    tot += float(self.loss_fn(self.model(images), target))
+                    loss = self.loss_fn(self.model(images), target).float()
+                    tot = loss if tot is None else tot + loss
                 out[(r, l)] = tot / self.probe_batches
-        return dict(zip(cands, self._rank_mean([out[c] for c in cands])))
+        vals = torch.stack([out[c] for c in cands]).tolist()          # ONE read-back per probe
+        return dict(zip(cands, self._rank_mean(vals)))
 
     def _time(self, cands):
         """mean forward+backward seconds per candidate, measured once at search start (main_prog.py:1886-1902)"""
@@ -163,9 +189,11 @@ class AutoProgDriver:
                 self._transition(l, r, self.dp_list[stage])
             if epoch in skip:
                 continue
-            tot = 0.0
+            tot = None                    # summed on the device: one read-back per epoch, not one per step
             for _ in range(self.steps_per_epoch):
-                tot += float(self._train_step(self.current_l, self.current_r, self.current_dp))
+                loss = self._train_step(self.current_l, self.current_r, self.current_dp)
+                tot = loss.float() if tot is None else tot + loss
+            tot = float(tot)
             self.history.append(dict(epoch=epoch, kind="train", r=self.current_r, l=self.current_l, dp=self.current_dp,
                                      loss=tot / self.steps_per_epoch))
             self.log("epoch %d: r=%d l=%d loss %.4f" % (epoch, self.current_r, self.current_l, tot / self.steps_per_epoch))

@@ -202,3 +202,215 @@ def test_search_decision_is_identical_on_every_rank():
     assert means0 == means1 == [1.5, 1.7, 1.8, 0.9]
     assert pick0 == pick1
     assert local0 != local1            # the rank-local rankings really disagreed
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# gradient accumulation (the reference's --batch-splits / `update` flag: main_prog.py:567-574,971,1019-1027, prog/scaler.py:60-68)
+def _accum_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from autoprog_amd.dist import GradientBucketReducer
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
+        params = list(net.parameters())
+        k = 3
+        red = GradientBucketReducer(params, bucket_bytes=512, world_size=world, accumulate_steps=k)
+        assert len(red.buckets) >= 3
+        torch.manual_seed(500 + rank)
+        big = torch.randn(8 * k, 16)                       # this rank's share of the update's batch
+        red.zero_grad()
+        for i in range(k):
+            loss = net(big[8 * i:8 * (i + 1)]).pow(2).mean()
+            (loss / k).backward()
+            if i < k - 1:
+                assert not any(red._launched), "a bucket left on a micro-batch that only accumulates"
+            red.finish()
+            assert red.is_update_step == (i == k - 1)
+        got = [p.grad.clone() for p in params]
+        # == ONE large batch per rank (mean over its 8k samples), averaged over the ranks
+        ref = [torch.zeros_like(p) for p in params]
+        for r in range(world):
+            torch.manual_seed(500 + r)
+            xr = torch.randn(8 * k, 16)
+            for acc, g in zip(ref, torch.autograd.grad(net(xr).pow(2).mean(), params)):
+                acc += g / world
+        for a, b in zip(got, ref):
+            assert torch.allclose(a, b, atol=1e-6), (rank, "accumulation")
+        # a second update after zero_grad(): the micro-batch counter starts over; and the split count may change between updates
+        red.set_accumulate_steps(2)
+        red.zero_grad()
+        for i in range(2):
+            (net(big[8 * i:8 * (i + 1)]).pow(2).mean() / 2).backward()
+            red.finish()
+        ref2 = [torch.zeros_like(p) for p in params]
+        for r in range(world):
+            torch.manual_seed(500 + r)
+            xr = torch.randn(8 * k, 16)[:16]
+            for acc, g in zip(ref2, torch.autograd.grad(net(xr).pow(2).mean(), params)):
+                acc += g / world
+        for a, b in zip([p.grad for p in params], ref2):
+            assert torch.allclose(a, b, atol=1e-6), (rank, "second update")
+        q.put((rank, "ok"))
+    except Exception as e:                          # pragma: no cover
+        import traceback
+        q.put((rank, "fail: %r %s" % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=fn, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    return out
+
+
+def test_gradient_accumulation_equals_one_large_batch_world_size_2():
+    out = _spawn(_accum_worker)
+    assert all(msg == "ok" for _, msg in out), out
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# the weight-gradient window of functional.py under data parallelism: the REAL window code (collect the blocks' problems, launch when
+# a window is full or when it completes a gradient bucket, deliver through param_ready) over the REAL reducer; only the HIP launch
+# itself (ops.gemm_tn_acc_grouped) is replaced by the same arithmetic in torch, so that this runs without a GPU.
+def _window_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from autoprog_amd import functional as AF, ops
+        from autoprog_amd.dist import GradientBucketReducer
+
+        launches = []                                   # (blocks whose backward had run, problems in the launch)
+        done_blocks = [0]
+
+        def cpu_grouped(problems, ln=None):
+            launches.append((done_blocks[0], len(problems)))
+            for prob in problems:
+                a, b, c, n1, n2, colsum = prob[:6]
+                c += a[:, :n1].float().t() @ b[:, :n2].float()
+                if colsum is not None:
+                    colsum += a[:, :n1].float().sum(0)
+        ops.gemm_tn_acc_grouped = cpu_grouped
+        AF.WGRAD_WINDOW = 4                             # tiles per launch: every problem below is ONE 192 x 192 tile
+
+        T, C, NB = 4096, 192, 12
+
+        class Block(torch.autograd.Function):          # y = x W^T + b with a sunk, windowed weight gradient (the shape of functional.*BlockFn)
+            @staticmethod
+            def forward(ctx, x, w, b):
+                ctx.save_for_backward(x, w)
+                ctx.params = (w, b)
+                return (x.float() @ w.t() + b).to(torch.bfloat16)
+
+            @staticmethod
+            def backward(ctx, dy):
+                x, w = ctx.saved_tensors
+                bufs, sunk = AF._param_grad_buffers(ctx.params)
+                assert sunk
+                with AF.wgrad_batch(sunk=True, params=ctx.params) as batch:
+                    AF._wgrad_batch.append((dy.contiguous(), x, bufs[0], C, C, bufs[1]))
+                assert batch.deferred
+                AF._finish_param_grads(ctx.params, bufs, sunk, deferred=True)
+                done_blocks[0] += 1
+                return (dy.float() @ w).to(torch.bfloat16), None, None
+
+        torch.manual_seed(0)
+        ws = [torch.nn.Parameter(torch.randn(C, C) * 0.05) for _ in range(NB)]
+        bs = [torch.nn.Parameter(torch.zeros(C)) for _ in range(NB)]
+        params = [p for pair in zip(ws, bs) for p in pair]
+        red = GradientBucketReducer(params, bucket_bytes=3 * (C * C + C) * 4, world_size=world)      # a bucket = three blocks
+        assert len(red.buckets) == 4
+        red.install_sink()
+        torch.manual_seed(700 + rank)
+        x = (torch.randn(T, C) * 0.5).to(torch.bfloat16)
+
+        def run(twice=None):
+            red.zero_grad()
+            launches.clear()
+            done_blocks[0] = 0
+            h = x.clone().requires_grad_(True)
+            for i in range(NB):
+                h = Block.apply(h, ws[i], bs[i])
+                if twice == i:
+                    h = Block.apply(h, ws[i], bs[i])     # the same parameters a second time in one backward pass
+            h.float().pow(2).mean().backward()
+            log = list(red.launch_log)
+            red.finish()
+            return log
+
+        log = run()
+        # the window launched DURING the backward pass, and bucket all-reduces left before it was over
+        assert len(launches) >= 3 and launches[0][0] < NB, launches
+        assert any(n_seen < len(params) for _, n_seen in log), ("no bucket left before the end of backward", log)
+        assert len(log) == 4 and [b for b, _ in log] == sorted(b for b, _ in log), log          # reverse registration = backward order
+        # the second bucket (blocks 8..6) completes inside a window of 4 tiles: the window launched early for it (3 problems, not 4)
+        assert any(n == 3 for _, n in launches), launches
+        got = [p.grad.clone() for p in params]
+
+        def reference(twice=None):
+            acc = [torch.zeros_like(p) for p in params]
+            for r in range(world):
+                torch.manual_seed(700 + r)
+                h = (torch.randn(T, C) * 0.5).to(torch.bfloat16)
+                hs = h.clone().requires_grad_(True)
+                h = hs
+                for i in range(NB):
+                    for _ in range(2 if twice == i else 1):
+                        h = (h.float() @ ws[i].t() + bs[i]).to(torch.bfloat16)
+                for a, g in zip(acc, torch.autograd.grad(h.float().pow(2).mean(), params)):
+                    a += g / world
+            return acc
+        for a, b in zip(got, reference()):
+            assert torch.allclose(a, b, rtol=2e-2, atol=2e-4), (rank, "window")
+        # a block applied twice before one backward: the second use must not share a launch with the first -- the window
+        # launches what it holds when a parameter comes in again -- and the two uses add up
+        run(twice=5)
+        ref2 = reference(twice=5)
+        for a, b in zip([p.grad for p in params], ref2):
+            assert torch.allclose(a, b, rtol=2e-2, atol=2e-4), (rank, "twice")
+        # a backward pass that raises leaves problems behind; the next pass drops them instead of adding them to its gradients
+        red.zero_grad()
+        h = x.clone().requires_grad_(True)
+        for i in range(3):
+            h = Block.apply(h, ws[i], bs[i])
+
+        class Boom(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                return t.clone()
+
+            @staticmethod
+            def backward(ctx, g):
+                raise RuntimeError("boom")
+        y = Boom.apply(h)
+        for i in range(3, 5):
+            y = Block.apply(y, ws[i], bs[i])
+        try:
+            y.float().pow(2).mean().backward()
+            raise AssertionError("backward did not raise")
+        except RuntimeError as e:
+            assert "boom" in str(e)
+        assert AF._window["problems"], "the failed pass should have left its problems in the window"
+        log = run()
+        for a, b in zip([p.grad for p in params], reference()):
+            assert torch.allclose(a, b, rtol=2e-2, atol=2e-4), (rank, "after a failed pass")
+        red.remove()
+        q.put((rank, "ok"))
+    except Exception as e:                          # pragma: no cover
+        import traceback
+        q.put((rank, "fail: %r %s" % (e, traceback.format_exc())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_weight_gradient_window_lets_buckets_leave_before_backward_ends_world_size_2():
+    out = _spawn(_window_worker)
+    assert all(msg == "ok" for _, msg in out), out
