@@ -129,6 +129,44 @@ def cpu_baseline(variant, res, seconds_budget, threads):
                                           "sample": "oracle vit_forward(deit_h3_l4) fp32 fwd+CE+bwd, 224px, batch 32, %d steps in %.1fs" % (n2, dt2)}}
 
 
+def cpu_baseline_other(workload, seconds_budget, threads):
+    """the CPU oracle on a bounded sample of the d5 / deit_base workloads (reported beside those lines; never part of `value`)"""
+    from oracle import ref_cpu as R
+    from autoprog_amd.models import create_model
+    torch.set_num_threads(threads)
+    torch.manual_seed(42)
+    g = torch.Generator().manual_seed(42)
+    if workload == "d5":
+        arch = dict(R.VOLO_PRESETS["volo_d5"])
+        model = create_model("volo_d5", img_size=448, drop_path_rate=0.1)
+        p = {k: v.detach().clone().float().requires_grad_(v.dtype.is_floating_point and "running_" not in k) for k, v in model.state_dict().items()}
+        del model
+        B, res = 1, 448
+        x = torch.randn(B, 3, res, res, generator=g)
+        target = make_target(B, 1000, (res // 16) ** 2, "cpu", g)
+        rng = np.random.RandomState(42)
+
+        def step():
+            lam, box = R.draw_mix_box((B, res // 8, res // 8, arch["embed_dims"][0]), 2, 1.0, rng)
+            out = R.volo_forward(p, x, train=True, mix=(lam, box), drop_path_rate=0.1, **arch)
+            torch.autograd.grad(R.token_label_ce(out, target, 0.5, 1.0), [v for v in p.values() if v.requires_grad], allow_unused=True)
+        what = "oracle/ref_cpu.py fp32 fwd+loss+bwd, volo_d5 448px, batch 1"
+    else:
+        model = create_model("model_variant", variant="deit_h12_l12")
+        p = {k: v.detach().clone().float().requires_grad_(True) for k, v in model.state_dict().items()}
+        del model
+        B = 8
+        x = torch.randn(B, 3, 224, 224, generator=g)
+        t = torch.softmax(torch.randn(B, 1000, generator=g) * 3, dim=-1)
+
+        def step():
+            torch.autograd.grad(R.soft_target_ce(R.vit_forward(p, x, depth=12, heads=12), t), list(p.values()), allow_unused=True)
+        what = "oracle vit_forward(deit_h12_l12) fp32 fwd+CE+bwd, 224px, batch 8"
+    n, dt = _time_steps(step, seconds_budget, max_steps=4)
+    return {"value": round(B * n / dt, 3), "unit": "images/sec", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "%s, %d steps in %.1fs (no optimizer)" % (what, n, dt)}
+
+
 class GemmProbe:
     """HIP-event timing of every ap_gemm_nt launch (events recorded on the launch stream)"""
 
@@ -136,6 +174,7 @@ class GemmProbe:
         self.records = []
         self.keys = []
         self.bytes = 0.0
+        self.fp8_launches = 0
 
     def install(self):
         from autoprog_amd import ops
@@ -157,10 +196,29 @@ class GemmProbe:
             probe.bytes += 2.0 * (a.shape[0] * kk + nn * kk + a.shape[0] * nn * (1 + extra))
             return out
         ops.gemm_nt = timed
+        # the e4m3 launches of --fp8 (ops.gemm_nt_fp8: one byte per operand element, bf16 outputs) belong to the same kernel family
+        self._orig8 = ops.gemm_nt_fp8
+
+        def timed8(a8, b8, dq_a, dq_b, n=None, **kw):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = probe._orig8(a8, b8, dq_a, dq_b, n=n, **kw)
+            e1.record()
+            nn = b8.shape[0] if n is None else n
+            kk = a8.shape[1]
+            probe.records.append((e0, e1, 2.0 * a8.shape[0] * nn * kk))
+            probe.keys.append((a8.shape[0], nn, kk, "fp8:" + ("+".join(k2 for k2 in ("bias", "gelu", "row_scale", "residual", "q8") if kw.get(k2) is not None and kw.get(k2) is not False) or "plain")))
+            extra = sum(1 for k2 in ("residual", "preact_out") if kw.get(k2) is not None)
+            probe.bytes += 1.0 * (a8.shape[0] * kk + nn * kk) + 2.0 * a8.shape[0] * nn * (1 + extra) + (1.0 * a8.shape[0] * nn if kw.get("q8") is not None else 0.0)
+            probe.fp8_launches += 1
+            return out
+        ops.gemm_nt_fp8 = timed8
 
     def remove(self):
         from autoprog_amd import ops
         ops.gemm_nt = self._orig
+        ops.gemm_nt_fp8 = self._orig8
 
     def table(self):
         """per-shape HIP-event times INSIDE the training step (AP_GEMM_TABLE=1): the ground truth for tile-variant choices --
@@ -452,7 +510,7 @@ def main():
                     "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / PEAK_BF16_TFLOPS, 4),
                     "hbm_tbs_algorithmic": round(tbs, 3), "hbm_frac": round(tbs / PEAK_HBM_TBS, 4),
                     "algorithmic_bytes_per_launch": round(probe.bytes / max(launches, 1)),
-                    "launches_per_step": launches // nprobe, "avg_launch_us": round(ms * 1e3 / launches, 2),
+                    "launches_per_step": launches // nprobe, "fp8_launches_per_step": probe.fp8_launches // nprobe, "avg_launch_us": round(ms * 1e3 / launches, 2),
                     "gemm_ms_per_step": round(ms / nprobe, 3), "gemm_gflop_per_step": round(flops / nprobe / 1e9, 1)}
 
     cpu = None
@@ -460,6 +518,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("d1", "stages") and args.variant.startswith("volo_h"):
         threads = min(os.cpu_count() or 1, 64)
         cpu = cpu_baseline(args.variant, res, args.cpu_seconds, threads)
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("d5", "deit_base"):
+        cpu = cpu_baseline_other(args.workload, args.cpu_seconds, min(os.cpu_count() or 1, 64))
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3

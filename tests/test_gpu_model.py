@@ -163,10 +163,7 @@ def test_d1_shapes_droppath_and_oracle_agreement():
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
 
 
-def test_volo_d5_shapes_448_vs_oracle():
-    """BASELINE configs[4] shapes in bf16: VOLO-D5 widths (384 / 768 channels, 12 / 16 heads -> head_dim 32 outlook, head_dim 48
-    attention, mlp ratio 4, stem width 128; models/volo.py:799-821) at 448 px (56x56 outlook grid, 784 tokens -> the key/query-
-    blocked attention kernels), one block per kind, batch 1: forward, loss and every parameter gradient against the oracle."""
+def _d5_shapes_vs_oracle(out_tol, loss_tol, grad_tol, stem_tol, tag):
     from autoprog_amd.models.volo import VOLO
     from autoprog_amd.loss import TokenLabelCrossEntropy
     torch.manual_seed(0)
@@ -194,12 +191,44 @@ def test_volo_d5_shapes_448_vs_oracle():
     ref = R.volo_forward(p, x.double().cpu(), train=True, mix=(lam, box), **arch)
     ref_loss = R.token_label_ce(ref, target.double().cpu(), 0.5, 1.0)
     ref_loss.backward()
-    assert rel(x_cls, ref[0]) < 3e-2 and rel(x_aux, ref[1]) < 3e-2, (rel(x_cls, ref[0]), rel(x_aux, ref[1]))
-    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 3e-3 * float(ref_loss.detach())
+    e_out = (rel(x_cls, ref[0]), rel(x_aux, ref[1]))
+    e_loss = abs(float(loss.detach()) - float(ref_loss.detach())) / float(ref_loss.detach())
     errs = {n: rel(q.grad, p[n].grad) for n, q in model.named_parameters() if float(p[n].grad.norm()) > 1e-9}
-    print("D5-shape grad errors: max %.4f (%s)" % (max(errs.values()), max(errs, key=errs.get)))
-    bad = {k: v for k, v in errs.items() if v > (0.14 if k.startswith("patch_embed.") else 6e-2)}
+    print("D5-shape %s: outputs %.4f / %.4f, loss rel %.5f, grad errors: median %.4f max %.4f (%s)"
+          % (tag, e_out[0], e_out[1], e_loss, float(np.median(list(errs.values()))), max(errs.values()), max(errs, key=errs.get)))
+    assert max(e_out) < out_tol, e_out
+    assert e_loss < loss_tol, e_loss
+    bad = {k: v for k, v in errs.items() if v > (stem_tol if k.startswith("patch_embed.") else grad_tol)}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+
+
+def test_volo_d5_shapes_448_vs_oracle():
+    """BASELINE configs[4] shapes in bf16: VOLO-D5 widths (384 / 768 channels, 12 / 16 heads -> head_dim 32 outlook, head_dim 48
+    attention, mlp ratio 4, stem width 128; models/volo.py:799-821) at 448 px (56x56 outlook grid, 784 tokens -> the key/query-
+    blocked attention kernels), one block per kind, batch 1: forward, loss and every parameter gradient against the oracle."""
+    _d5_shapes_vs_oracle(out_tol=3e-2, loss_tol=3e-3, grad_tol=6e-2, stem_tol=0.14, tag="bf16")
+
+
+def test_volo_d5_shapes_448_fp8_vs_oracle(monkeypatch):
+    """The same D5-shape network under functional.FP8_LINEAR (configs[4]: "mixed MFMA fp8 GEMM / bf16 accum"): the
+    forward Linear products of its transformer blocks run on e4m3 operands at the D5 shapes (K = 768 / 3072, head_dim 48 blocked
+    attention emitting its e4m3 output) -- compared with the fp64 ORACLE, not with the bf16 HIP path.  e4m3 keeps 3 mantissa bits
+    (2^-4 relative per element, ~1/sqrt(K) of it after a K-long dot product), so the bounds are wider than the bf16 test's: outputs
+    <= 8e-2, loss <= 1e-2 relative, parameter gradients <= 0.12 per tensor (0.2 in the conv stem, whose BatchNorm backward amplifies
+    the perturbation of everything above it).  Measured (round 4): outputs 4.8e-2 / 6.0e-2, loss 4.0e-3, gradients median 3.6e-2, max
+    0.103 (patch_embed.conv.1.weight); the bf16 run of the same network: 7.0e-3 / 8.4e-3, 7e-5, 7.4e-3, 9.8e-2."""
+    from autoprog_amd import functional as AF, ops
+    AF.reset_fp8_state()
+    monkeypatch.setattr(AF, "FP8_LINEAR", True)
+    calls = []
+    real = ops.gemm_nt_fp8
+    monkeypatch.setattr(ops, "gemm_nt_fp8", lambda *a, **k: (calls.append(tuple(a[0].shape)), real(*a, **k))[1])
+    try:
+        _d5_shapes_vs_oracle(out_tol=8e-2, loss_tol=1e-2, grad_tol=0.12, stem_tol=0.2, tag="fp8 forward GEMMs")
+    finally:
+        AF.reset_fp8_state()
+    # two transformer blocks x (qkv, proj, fc1, fc2) at 784 tokens: K = 768 (x3) and 3072
+    assert len(calls) == 8 and sorted({s[1] for s in calls}) == [768, 3072], calls
 
 
 def test_volo_d5_full_depth_448_smoke():
@@ -520,6 +549,50 @@ def test_loss_curve_realistic_init_vs_reference():
     assert dev[0] < 1e-3 and dev[:4].max() < 2e-3, dev.tolist()
     assert dev.max() < 2.5e-2, (losses, d["losses"].tolist())
     assert dev.max() < 0.1 * np.abs(d["losses_bf16_autocast"] - d["losses"]).max()
+
+
+def test_late_state_vs_reference_golden():
+    """Parity on a TRAINED network (VERDICT r3, Weak 2; tests/golden/late_state.npz, tools/gen_golden.py::gen_late_state): the
+    reference's volo_h4_l6 after 300 fp64 AdamW steps on its batch (loss 5.4 -> 3.0), its weights as fp32, evaluated by the reference in
+    fp64 on a fresh mix-token draw.  The HIP model loads those weights and runs the same step.  Asserted (bounds from the first GPU
+    run of this test, stated next to the measured values): logits <= 2e-2 rel-L2, loss <= 1e-2 relative, all parameter gradients as ONE
+    vector <= 0.1 rel-L2, no tensor above 0.25 outside the 16-wide conv stem of this fixture (which runs through MIOpen in bf16
+    under a batch-of-8 BatchNorm) and 0.5 inside it.  The fixture also records the reference's own network under torch.autocast(bf16)
+    on these weights: logits off by 107 % / 135 %, loss 5.73 instead of 3.30, gradients off by a factor of 100 -- the CPU autocast
+    recipe (LayerNorm and softmax in bf16 as well) does not survive this state at all, so it is no yardstick here; the fp64 numbers are."""
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    d = load("late_state")
+    classes = int(d["classes"])
+    model = build("volo_h4_l6", classes)
+    sd = {k[2:]: torch.from_numpy(np.asarray(v)) for k, v in d.items() if k.startswith("w.")}
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    x = torch.from_numpy(d["x"]).cuda()
+    target = torch.from_numpy(d["target"]).cuda()
+    np.random.seed(int(d["np_seed"]))
+    out = model(x)
+    assert [int(v) for v in out[2]] == [int(v) for v in d["box"]]
+    e_cls, e_aux = rel(out[0], d["y_cls"]), rel(out[1], d["y_aux"])
+    loss = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=classes)(out, target)
+    loss.backward()
+    named = dict(model.named_parameters())
+    names = [str(n) for n in d["grad_names"]]
+    ref = {k: torch.from_numpy(d["g16." + k].astype(np.float64)) * float(d["gs." + k]) for k in names}
+    errs = {k: rel(named[k].grad, ref[k]) for k in names}
+    va = torch.cat([named[k].grad.detach().double().cpu().flatten() for k in names])
+    vb = torch.cat([ref[k].flatten() for k in names])
+    one = float((va - vb).norm() / vb.norm())
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
+    print("late state: logits %.4f / %.4f, loss %.5f (reference %.5f), gradients: one vector %.4f, median %.4f, worst %s"
+          % (e_cls, e_aux, float(loss), float(d["loss"]), one, float(np.median(list(errs.values()))), [(k, round(v, 4)) for k, v in worst]))
+    assert e_cls < 2e-2 and e_aux < 2e-2, (e_cls, e_aux)
+    assert abs(float(loss) - float(d["loss"])) < 1e-2 * float(d["loss"])
+    # measured (round 4): logits 2.1e-3 / 7.2e-3, loss 3.29842 against 3.29845, gradients: one vector 7.8e-2, median 5.7e-2, worst
+    # 0.20 (patch_embed.conv.4.bias), 0.16 (aux_head.weight) -- in this memorising state the gradients themselves are small
+    # differences of large terms, which is why they sit an order of magnitude above the first-step gradients of the same network
+    assert one < 0.1, one
+    bad = {k: v for k, v in errs.items() if v > (0.5 if k.startswith("patch_embed.conv") else 0.25)}
+    assert not bad, bad
 
 
 def test_hip_stem_eval_and_elastic_resolution_vs_oracle():

@@ -315,3 +315,34 @@ def test_vit_block_against_an_independent_statement():
     assert rel_err(xo.grad, x.grad) < 1e-10
     for k in p:
         assert rel_err(po[k].grad, p[k].grad) < 1e-10, k
+
+
+def _late_state_reference(d):
+    names = [str(n) for n in d["grad_names"]]
+    return names, {k: torch.from_numpy(d["g16." + k].astype(np.float64)) * float(d["gs." + k]) for k in names}
+
+
+def test_late_state_outputs_loss_and_gradients():
+    """the oracle on a TRAINED state (tests/golden/late_state.npz: the reference's volo_h4_l6 after 300 fp64 AdamW steps, evaluated by
+    the reference in fp64): logits <= 1e-9 rel, loss <= 1e-9, every parameter gradient <= 2e-3 rel (the fixture stores gradients as fp16
+    mantissas with a per-tensor scale) and all gradients as one vector <= 5e-4."""
+    d = load("late_state")
+    arch = R.variant_arch("volo_h4_l6")
+    p = {k[2:]: torch.from_numpy(np.asarray(v)).double() for k, v in d.items() if k.startswith("w.") and np.asarray(v).dtype.kind == "f"}
+    for k, v in p.items():
+        if "running_" not in k:
+            v.requires_grad_(True)
+    x = torch.from_numpy(d["x"]).double()
+    t = torch.from_numpy(d["target"]).double()
+    lam, box = R.draw_mix_box((x.shape[0], 8, 8, 64), 2, 1.0, np.random.RandomState(int(d["np_seed"])))
+    assert list(box) == [int(v) for v in d["box"]]
+    out = R.volo_forward(p, x, train=True, mix=(lam, box), **arch)
+    assert rel_err(out[0], d["y_cls"]) < 1e-9 and rel_err(out[1], d["y_aux"]) < 1e-9
+    loss = R.token_label_ce(out, t, 0.5, 1.0)
+    assert abs(float(loss.detach()) - float(d["loss"])) < 1e-9
+    loss.backward()
+    names, ref = _late_state_reference(d)
+    for k in names:
+        assert rel_err(p[k].grad, ref[k]) < 2e-3, k
+    va = torch.cat([p[k].grad.flatten() for k in names]); vb = torch.cat([ref[k].flatten() for k in names])
+    assert float((va - vb).norm() / vb.norm()) < 5e-4

@@ -435,6 +435,80 @@ def gen_step_curve_init(ns):
     save("step_curve_init", **out)
 
 
+def gen_late_state(ns):
+    """Parity in the regime a TRAINED network is in (Weak 2): the realistic-init volo_h4_l6 of step_curve_init is trained by
+    the reference, in fp64, for 300 AdamW steps on its batch (lr 1e-3: the residual stream grows, attention logits sharpen, the loss
+    falls from 5.7 to the memorising regime); then the late state -- rounded to fp32, the precision a checkpoint holds -- is evaluated
+    once more by the reference in fp64 on a fresh mix-token draw: logits, loss, every parameter gradient.  Next to it the reference's
+    OWN bf16-autocast evaluation of the same weights (per-tensor gradient errors and the error of all gradients as one vector): the
+    yardstick for any implementation in that arithmetic class.  Gradients are stored as fp16 mantissas with a per-tensor scale
+    (relative error 5e-4, far below what is asserted against them)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from tests._initweights import init_state_dict
+    gen = torch.Generator().manual_seed(77)
+    classes, B, r, seed, steps = 32, 8, 64, 2024, 300
+    x = torch.randn(B, 3, r, r, generator=gen)
+    target = make_target(B, classes, (r // 16) ** 2, gen)
+    net = tiny_volo(ns, "volo_h4_l6", r, classes).train()
+    net.load_state_dict(init_state_dict(net.state_dict(), seed), strict=True)
+    net = net.double()
+    loss_fn = ns.cross_entropy.TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=classes)
+    decay, no_decay = [], []
+    for n, p in net.named_parameters():
+        (no_decay if (p.dim() == 1 or n.endswith(".bias") or n in ("pos_embed", "cls_token")) else decay).append(p)
+    opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.05}, {"params": no_decay, "weight_decay": 0.0}], lr=1e-3)
+    np.random.seed(123)
+    curve = []
+    for step in range(steps):
+        loss = loss_fn(net(x.double()), target.double())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        curve.append(float(loss.detach()))
+    print("late_state: loss %.4f -> %.4f after %d steps" % (curve[0], curve[-1], steps))
+    # the late state as a checkpoint would hold it
+    sd32 = {k: (v.float() if v.dtype.is_floating_point else v) for k, v in net.state_dict().items()}
+    out = {"x": npy(x), "target": npy(target), "np_seed": np.array(7), "classes": np.array(classes), "steps": np.array(steps),
+           "train_curve": np.array(curve)}
+    out.update({"w." + k: npy(v) for k, v in sd32.items()})
+
+    def evaluate(dtype, amp=None):
+        m = tiny_volo(ns, "volo_h4_l6", r, classes).train()
+        m.load_state_dict(sd32, strict=True)
+        m = m.to(dtype)
+        np.random.seed(7)
+        if amp is not None:
+            with torch.autocast("cpu", dtype=amp):
+                o = m(x.to(dtype))
+            o = (o[0].float(), o[1].float(), o[2])
+        else:
+            o = m(x.to(dtype))
+        l = loss_fn(o, target.to(dtype))
+        l.backward()
+        return o, l, {k: v.grad.detach().double() for k, v in m.named_parameters() if v.grad is not None}
+    o64, l64, g64 = evaluate(torch.float64)
+    ob, lb, gb = evaluate(torch.float32, torch.bfloat16)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    out["y_cls"], out["y_aux"], out["box"], out["loss"] = npy(o64[0]), npy(o64[1]), np.array([int(v) for v in o64[2]]), np.array(float(l64))
+    names = sorted(k for k, g in g64.items() if float(g.norm()) > 1e-12)
+    out["grad_names"] = np.array(names)
+    for k in names:
+        g = g64[k]
+        sc = float(g.abs().max())
+        out["gs." + k] = np.array(sc)
+        out["g16." + k] = (g / sc).to(torch.float16).numpy()
+    out["yard_names"] = np.array(names)
+    out["yard_bf16_autocast"] = np.array([rel(gb[k], g64[k]) for k in names])
+    va = torch.cat([gb[k].flatten() for k in names]); vb = torch.cat([g64[k].flatten() for k in names])
+    out["yard_bf16_autocast_one_vector"] = np.array(float((va - vb).norm() / vb.norm()))
+    out["yard_bf16_autocast_logits"] = np.array([rel(ob[0], o64[0]), rel(ob[1], o64[1])])
+    out["yard_bf16_autocast_loss"] = np.array(float(lb))
+    print("late_state: loss %.5f; reference bf16-autocast: logits %.4f / %.4f, loss %.5f, gradients median %.4f max %.4f one-vector %.4f"
+          % (float(l64), rel(ob[0], o64[0]), rel(ob[1], o64[1]), float(lb), float(np.median(out["yard_bf16_autocast"])),
+             float(out["yard_bf16_autocast"].max()), float(out["yard_bf16_autocast_one_vector"])))
+    save("late_state", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="", help="comma-separated generator names (e.g. step_curve_init); default all")
@@ -444,7 +518,7 @@ def main():
     torch.set_num_threads(4)
     ns = ref_import.load_reference()
     for fn in (gen_int_tables, gen_outlook, gen_blocks, gen_stem, gen_stem64, gen_pos_interp, gen_volo_full, gen_loss, gen_step_curve,
-               gen_step_curve_init):
+               gen_step_curve_init, gen_late_state):
         if not only or fn.__name__[4:] in only:
             fn(ns)
 
