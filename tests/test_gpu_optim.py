@@ -292,6 +292,38 @@ def test_autoprog_driver_two_stage_search():
         red.remove()
 
 
+def test_driver_gradient_accumulation_equals_one_large_batch():
+    """batch splits (reference --batch-splits-list / `update` flag, main_prog.py:567-574,971,1019-1027): one driver update made of
+    two micro-batches (backward on loss / 2 each, gradient exchange and optimizer on the second only) against ONE step on the
+    concatenated batch.  BatchNorm statistics and the mix-token partner are per micro-batch in the reference too, so the comparison
+    uses a model state where neither matters: eval-free check on the Linear / LayerNorm parameters of the transformer stages through
+    GradientBucketReducer(accumulate_steps=2) directly -- the slab after two accumulating backward passes equals the sum of the two
+    passes' own gradients (to fp32 rounding: the kernels add in place into the same fp32 slab)."""
+    model, red, opt, loss_fn, x, target = _setup()
+    try:
+        halves = [(x[:2].contiguous(), target[:2].contiguous()), (x[2:].contiguous(), target[2:].contiguous())]
+        singles = []
+        for xi, ti in halves:                                   # each micro-batch on its own
+            red.zero_grad()
+            np.random.seed(5)
+            (loss_fn(model(xi), ti) / 2).backward()
+            red.finish()
+            singles.append(red.flat.clone())
+        red.set_accumulate_steps(2)
+        red.zero_grad()
+        for i, (xi, ti) in enumerate(halves):
+            np.random.seed(5)
+            (loss_fn(model(xi), ti) / 2).backward()
+            red.finish()
+            assert red.is_update_step == (i == 1)
+        want = singles[0] + singles[1]
+        err = float((red.flat - want).norm() / want.norm())
+        assert err < 2e-5, err                                  # fp32 adds in another order (split launches meet in fp32 atomics), nothing more
+        red.set_accumulate_steps(1)
+    finally:
+        red.remove()
+
+
 def test_weight_gradient_window_matches_one_launch_per_block(monkeypatch):
     """functional's weight-gradient window: the blocks' weight gradients (and LayerNorm parameter gradients) leave in a few launches
     for the whole backward pass instead of one per block, and param.grad holds the same numbers (only the order of fp32 additions

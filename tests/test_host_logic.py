@@ -163,3 +163,21 @@ def test_drop_path_rates_follow_the_active_blocks():
     got = [b.drop_prob for s in m.network if isinstance(s, torch.nn.Sequential) for b in s if isinstance(b, Transformer) and not b.is_identity_layer]
     want = [b.drop_prob for s in ext.network if isinstance(s, torch.nn.Sequential) for b in s if isinstance(b, Transformer)]
     assert len(got) == len(want) == 8 and all(abs(a - b) < 1e-12 for a, b in zip(got, want)), (got, want)
+
+
+def test_driver_batch_splits_follow_the_reference_rule():
+    """AutoProgDriver.splits_for (reference main_prog.py:567-574, 839-842: batch_splits = get_divisor(original_batch_splits,
+    l r^2 / (l_max r_max^2)) -- the smallest divisor of the largest stage's split count that is > original * activation ratio)"""
+    from autoprog_amd.prog.driver import AutoProgDriver
+    drv = AutoProgDriver(model=None, loss_fn=None, optimizer=None, reducer=None, get_batch=None, r_list=[128, 160, 192, 224], l_list=[6, 9, 12, 12],
+                         dp_list=[0.0, 0.03, 0.07, 0.1], grow_epochs=[0, 25, 50, 75], steps_per_epoch=1, original_batch_splits=4)
+
+    def reference(number, factor):                      # main_prog.py:2057-2061, restated
+        for i in range(int(number * factor) + 1, number + 1):
+            if number % i == 0:
+                return i
+        return number
+    for l, r in [(6, 128), (9, 160), (12, 192), (12, 224), (6, 224), (12, 128)]:
+        assert drv.splits_for(l, r) == reference(4, (l * r * r) / (12 * 224 * 224)), (l, r)
+    assert drv.splits_for(12, 224) == 4 and drv.splits_for(6, 128) == 1
+    assert AutoProgDriver(None, None, None, None, None, [64], [3], [0.0], [0], 1).splits_for(3, 64) == 1      # default: no splits

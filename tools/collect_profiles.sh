@@ -6,7 +6,7 @@
 #   gpurun_out/${ROUND}_kernel_table.txt   one line per kernel: HBM bytes, TB/s, MFMA busy %, VALU busy %, LDS conflict share (tools/pmc_table.py)
 #   gpurun_out/gemm_nt_traffic.json   HBM bytes per k_gemm_nt launch from FETCH_SIZE/WRITE_SIZE (gfx950 correction applied)
 # Copy them into profiles/ afterwards.
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 if [ -z "$PMC_ONLY" ]; then
 python3 bench.py 2> gpurun_out/${ROUND}_bench.err | tail -1 > gpurun_out/${ROUND}_bench_n1.json
