@@ -124,6 +124,94 @@ k_ln_fwd(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const fl
     }
 }
 
+// Round 4: the forward at LOW register pressure.  k_ln_fwd<3, 2> holds the lane's 48 affine parameters and two rows in registers: 116
+// VGPRs, four workgroups per CU -- and the training step launches it with 6.1 workgroups per CU (one row per lane group), i.e. a
+// second, half-empty round that costs a whole load -> reduce -> store chain again.  Here the parameters stay in LDS (as float4 planes
+// [gamma lo | gamma hi | beta lo | beta hi][chunk]: consecutive lanes read consecutive 16-byte words, no bank conflicts) and are read
+// where they are used; the lane's row chunks are requested FIRST and the parameter loads behind them wait on a counted vmcnt, so the
+// parameters' trip through LDS runs under the rows' memory latency.  <= 72 VGPRs: seven workgroups per CU, one round.
+template <int V>
+__global__ void __launch_bounds__(256, 7)
+k_ln_fwd_lp(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+            bf16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int C, int G, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float sgb[];     // 4 planes x [nchunks] float4
+    const int lane_in_group = threadIdx.x & (G - 1);
+    const int groups_per_block = 256 / G;
+    const int group = threadIdx.x / G;
+    const int nchunks = C >> 3;
+    const float invC = 1.0f / (float)C;
+    const int64_t row_stride = (int64_t)gridDim.x * groups_per_block;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    // parameter loads first in program order (they are waited for first), the row right behind them
+    float gt[8], bt[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int c = threadIdx.x + k * 256; gt[k] = c < C ? gamma[c] : 0.f; bt[k] = c < C ? beta[c] : 0.f; }
+    int64_t row = (int64_t)blockIdx.x * groups_per_block + group;
+    u32x4 rx[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int ch = lane_in_group + i * G;
+        rx[i] = (row < rows && ch < nchunks) ? ld16(x + row * C + 8 * ch) : z;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = threadIdx.x + k * 256;
+        if (c < C) {
+            const int idx = (((c >> 2) & 1) * nchunks + (c >> 3)) * 4 + (c & 3);
+            sgb[idx] = gt[k];
+            sgb[8 * nchunks + idx] = bt[k];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const f32x4* pl = reinterpret_cast<const f32x4*>(sgb);
+    while (row < rows) {
+        {
+            float v[V][8];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                unpack8(rx[i], v[i]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += v[i][k];
+            }
+            for (int o = G >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            const float mu = s * invC;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const int ch = lane_in_group + i * G;
+                if (ch < nchunks) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
+                }
+            }
+            for (int o = G >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            const float rs = rsqrtf(q * invC + eps);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const int ch = lane_in_group + i * G;
+                if (ch < nchunks) {
+                    const f32x4 g0 = pl[ch], g1 = pl[nchunks + ch], b0 = pl[2 * nchunks + ch], b1 = pl[3 * nchunks + ch];
+                    float o8[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        o8[k] = (v[i][k] - mu) * rs * g0[k] + b0[k];
+                        o8[4 + k] = (v[i][4 + k] - mu) * rs * g1[k] + b1[k];
+                    }
+                    st16_nt(y + row * C + 8 * ch, pack8(o8));
+                }
+            }
+            if (lane_in_group == 0) { mean[row] = mu; rstd[row] = rs; }
+        }
+        row += row_stride;                       // (a lane group's next row, if the grid was capped: all lanes of a group stay together)
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int ch = lane_in_group + i * G;
+            rx[i] = (row < rows && ch < nchunks) ? ld16(x + row * C + 8 * ch) : z;
+        }
+    }
+}
+
 template <int V, int U>
 __global__ void __launch_bounds__(256)
 k_ln_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
@@ -318,6 +406,14 @@ int ap_layernorm_fwd_fp8(const ap_bf16* x, const float* gamma, const float* beta
     const size_t lds = (size_t)2 * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
+    static int lp = -1;
+    if (lp < 0) { const char* e = getenv("AP_LN_FWD_LP"); lp = e ? atoi(e) : 1; }
+    if (lp && !y8 && V <= 3) {          // the low-register forward (no e4m3 side output; the widths it was measured on)
+        if (V == 1) hipLaunchKernelGGL((k_ln_fwd_lp<1>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
+        else if (V == 2) hipLaunchKernelGGL((k_ln_fwd_lp<2>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
+        else hipLaunchKernelGGL((k_ln_fwd_lp<3>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
+        return ap_check_launch();
+    }
     if (V == 1) hipLaunchKernelGGL((k_ln_fwd<1, 4>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps, y8, q_scale, q_amax);
     else if (V == 2) hipLaunchKernelGGL((k_ln_fwd<2, 4>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps, y8, q_scale, q_amax);
     else if (V == 3) hipLaunchKernelGGL((k_ln_fwd<3, 2>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps, y8, q_scale, q_amax);
@@ -385,6 +481,8 @@ int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, co
     const size_t lds = (size_t)2 * 4 * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
+    // (5 rows per trip instead of 4 -- every lane group of the VOLO-D1 launch then finishes its 8 or 9 rows in two trips instead of three for
+    // a sixth of them -- measured equal, 17.5 vs 17.7 us: the trips are not what the launch waits for)
     if (V == 1) hipLaunchKernelGGL((k_ln_bwd<1, 4>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);
     else if (V == 2) hipLaunchKernelGGL((k_ln_bwd<2, 2>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);
     else if (V == 3) hipLaunchKernelGGL((k_ln_bwd<3, 2>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);

@@ -228,3 +228,25 @@ def reduce_scalar_mean(t, world_size, group=None):
         dist.all_reduce(rt, op=dist.ReduceOp.SUM, group=group)
         rt /= world_size
     return rt
+
+
+def distribute_bn(model, world_size, reduce=False, group=None):
+    """timm.utils.distribute_bn as main_prog.py:883-887 calls it after every epoch (`--dist-bn reduce | broadcast`): every rank gets the
+    same BatchNorm running means / variances -- averaged over the ranks (reduce) or rank 0's (broadcast).  timm issues one collective
+    per buffer; here the buffers (six vectors of the stem's width for VOLO) travel as ONE flat message and are scattered back."""
+    bufs = [b for n, b in model.named_buffers() if ("running_mean" in n or "running_var" in n)]
+    if world_size <= 1 or not bufs:
+        return
+    flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+    if reduce:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= float(world_size)
+    else:
+        dist.broadcast(flat, 0, group=group)
+    off = 0
+    with torch.no_grad():
+        for b in bufs:
+            n = b.numel()
+            b.copy_(flat[off:off + n].view_as(b).to(b.dtype))
+            off += n
+

@@ -138,6 +138,18 @@ def _worker(rank, world, port, q):
         assert any(not torch.equal(got, want) for got, want in zip([p.grad for p in net.parameters()], ref))
         m = reduce_scalar_mean(torch.tensor(float(rank)), world)
         assert float(m) == pytest.approx((world - 1) / 2)
+        # distribute_bn (main_prog.py:883-887): running statistics averaged over the ranks, or rank 0's
+        from autoprog_amd.dist import distribute_bn
+        bn = torch.nn.Sequential(torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 4, 1), torch.nn.BatchNorm2d(4))
+        for k, mod in enumerate((bn[0], bn[2])):
+            mod.running_mean.fill_(float(rank + k)); mod.running_var.fill_(float(10 * rank + k + 1))
+        distribute_bn(bn, world, reduce=True)
+        assert torch.allclose(bn[0].running_mean, torch.full((4,), 0.5)) and torch.allclose(bn[2].running_var, torch.full((4,), 7.0))
+        assert int(bn[0].num_batches_tracked) == 0
+        for k, mod in enumerate((bn[0], bn[2])):
+            mod.running_mean.fill_(float(rank + k))
+        distribute_bn(bn, world, reduce=False)
+        assert torch.allclose(bn[0].running_mean, torch.zeros(4)) and torch.allclose(bn[2].running_mean, torch.ones(4))
         q.put((rank, "ok"))
     except Exception as e:                          # pragma: no cover
         q.put((rank, "fail: %r" % (e,)))
