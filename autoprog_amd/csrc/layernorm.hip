@@ -133,7 +133,11 @@ k_ln_fwd(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const fl
 template <int V>
 __global__ void __launch_bounds__(256, 7)
 k_ln_fwd_lp(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-            bf16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int C, int G, float eps) {
+            bf16_t* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int C, int G, float eps,
+            unsigned char* __restrict__ y8 = nullptr, const float* __restrict__ q_scale = nullptr, float* __restrict__ q_amax = nullptr) {
+    // y8 / q_scale / q_amax: the e4m3 side output of ap_layernorm_fwd_fp8, as in k_ln_fwd
+    const float qs = y8 ? q_scale[0] : 1.f;
+    float qmx = 0.f;
     extern __shared__ __attribute__((aligned(16))) float sgb[];     // 4 planes x [nchunks] float4
     const int lane_in_group = threadIdx.x & (G - 1);
     const int groups_per_block = 256 / G;
@@ -198,7 +202,24 @@ k_ln_fwd_lp(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const
                         o8[k] = (v[i][k] - mu) * rs * g0[k] + b0[k];
                         o8[4 + k] = (v[i][4 + k] - mu) * rs * g1[k] + b1[k];
                     }
-                    st16_nt(y + row * C + 8 * ch, pack8(o8));
+                    const u32x4 ob = pack8(o8);
+                    st16_nt(y + row * C + 8 * ch, ob);
+                    if (y8) {
+                        float r8[8];
+                        unpack8(ob, r8);
+                        u32x2 o;
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            float c4[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { qmx = fmaxf(qmx, fabsf(r8[4 * h2 + e])); c4[e] = fminf(fmaxf(r8[4 * h2 + e] * qs, -448.f), 448.f); }
+                            int w = 0;
+                            w = __builtin_amdgcn_cvt_pk_fp8_f32(c4[0], c4[1], w, false);
+                            w = __builtin_amdgcn_cvt_pk_fp8_f32(c4[2], c4[3], w, true);
+                            o[h2] = (unsigned)w;
+                        }
+                        *reinterpret_cast<u32x2*>(y8 + row * C + 8 * ch) = o;
+                    }
                 }
             }
             if (lane_in_group == 0) { mean[row] = mu; rstd[row] = rs; }
@@ -208,6 +229,15 @@ k_ln_fwd_lp(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const
         for (int i = 0; i < V; ++i) {
             const int ch = lane_in_group + i * G;
             rx[i] = (row < rows && ch < nchunks) ? ld16(x + row * C + 8 * ch) : z;
+        }
+    }    if (y8 && q_amax) {                       // one atomic per workgroup, and only when it raises the value (see k_quantize_fp8)
+        __syncthreads();
+        qmx = group_max<64>(qmx);
+        if ((threadIdx.x & 63) == 0) sgb[threadIdx.x >> 6] = qmx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(sgb[0], sgb[1]), fmaxf(sgb[2], sgb[3]));
+            if (__float_as_int(m) > *reinterpret_cast<volatile int*>(q_amax)) atomicMax(reinterpret_cast<int*>(q_amax), __float_as_int(m));
         }
     }
 }
@@ -408,10 +438,10 @@ int ap_layernorm_fwd_fp8(const ap_bf16* x, const float* gamma, const float* beta
     (void)hipGetLastError();
     static int lp = -1;
     if (lp < 0) { const char* e = getenv("AP_LN_FWD_LP"); lp = e ? atoi(e) : 1; }
-    if (lp && !y8 && V <= 3) {          // the low-register forward (no e4m3 side output; the widths it was measured on)
-        if (V == 1) hipLaunchKernelGGL((k_ln_fwd_lp<1>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
-        else if (V == 2) hipLaunchKernelGGL((k_ln_fwd_lp<2>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
-        else hipLaunchKernelGGL((k_ln_fwd_lp<3>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps);
+    if (lp && V <= 3) {          // the low-register forward (the widths it was measured on: 192, 384, 768)
+        if (V == 1) hipLaunchKernelGGL((k_ln_fwd_lp<1>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps, y8, q_scale, q_amax);
+        else if (V == 2) hipLaunchKernelGGL((k_ln_fwd_lp<2>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps, y8, q_scale, q_amax);
+        else hipLaunchKernelGGL((k_ln_fwd_lp<3>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps, y8, q_scale, q_amax);
         return ap_check_launch();
     }
     if (V == 1) hipLaunchKernelGGL((k_ln_fwd<1, 4>), dim3((int)grid), dim3(256), lds, s, x, gamma, beta, y, mean, rstd, rows, C, G, eps, y8, q_scale, q_amax);
