@@ -16,6 +16,11 @@ if "--after" in sys.argv:
             seen += 1
             if seen == nth:
                 t0 = int(r["End_Timestamp"]); break
+# kernels that ask for dynamic LDS (bytes per workgroup at the VOLO-D1 shapes; csrc/*.hip)
+DYNAMIC_LDS = [("k_gemm_nt_8p", 163840), ("k_gemm_tn_8p", 150528), ("k_mhsa_fwd_p", 57344), ("k_mhsa_bwd_ds", 163840), ("k_outlook_p<512, 3, 1, true>", 75000),
+               ("k_outlook_p<512, 3, 1, false>", 50000), ("k_conv3x3_c64", 163840), ("k_conv7_s2d", 40000), ("k_ln_fwd", 3072), ("k_ln_bwd", 12288)]
+
+
 def col(r, *names):
     for n in names:
         if n in r and r[n] != "":
@@ -28,8 +33,12 @@ for r in rows:
     wg = max(1, col(r, "Workgroup_Size_X", "Workgroup_Size") * max(1, col(r, "Workgroup_Size_Y")) * max(1, col(r, "Workgroup_Size_Z")))
     grid = max(1, col(r, "Grid_Size_X", "Grid_Size") * max(1, col(r, "Grid_Size_Y")) * max(1, col(r, "Grid_Size_Z")))
     nwg = grid // wg
-    vg = col(r, "VGPR_Count", "Arch_VGPR_Count") + col(r, "Accum_VGPR_Count")
-    lds = col(r, "LDS_Block_Size", "LDS_Block_Size_v")
+    # rocprofv3 reports the allocation per SIMD32 half of a wave64: twice that is what .vgpr_count of the code object says
+    vg = 2 * (col(r, "VGPR_Count", "Arch_VGPR_Count") + col(r, "Accum_VGPR_Count"))
+    lds = col(r, "LDS_Block_Size", "LDS_Block_Size_v")          # static LDS only: the dynamic allocations are listed below
+    for sub, dyn in DYNAMIC_LDS:
+        if sub in r["Kernel_Name"]:
+            lds = max(lds, dyn)
     waves = (wg + 63) // 64
     per_simd = max(1, min(8, 512 // max(vg, 1))) if vg else 8
     by_vgpr = (per_simd * 4) // waves if waves <= per_simd * 4 else 0
