@@ -495,9 +495,10 @@ def main():
         # from FETCH_SIZE / WRITE_SIZE with the gfx950 correction of MI355X_MICROARCH.md); null when that file is absent
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "gemm_nt_traffic.json")) as fh:
+            tname = "gemm_nt_traffic.json" if args.workload == "d1" else "gemm_nt_traffic_%s.json" % args.workload      # tools/collect_traffic.sh
+            with open(os.path.join(ROOT, "profiles", tname)) as fh:
                 tj = json.load(fh)
-            if args.workload == "d1" and tj.get("src_sha256") == kernel_source_hash():
+            if tj.get("src_sha256") == kernel_source_hash() and not args.fp8:
                 traffic = tj.get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             pass
