@@ -314,7 +314,7 @@ k_gemm_nt_skinny(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict
     extern __shared__ __attribute__((aligned(16))) float sk_part[];          // [8 waves][64][SK_STRIDE]
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
-    const int nch = K >> 5;
+    const int nch = (K + 31) >> 5;            // the last chunk may be partial (K % 8 == 0: whole 16-byte pieces; lanes beyond K load zeros)
     const bf16_t* arow[4];
     const bf16_t* brow[2];
 #pragma unroll
@@ -332,7 +332,7 @@ k_gemm_nt_skinny(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int ch = c0 + 8 * r;
-            const bool ok = ch < nch;
+            const bool ok = ch < nch && ch * 32 + g * 8 < K;
 #pragma unroll
             for (int t = 0; t < 4; ++t) xa[r][t] = ok ? ld16(arow[t] + ch * 32) : zero4;
 #pragma unroll
@@ -834,7 +834,7 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     (void)hipGetLastError();
     static int skinny = -1;
     if (skinny < 0) { const char* e = getenv("AP_GEMM_NT_NO_SKINNY"); skinny = (e && e[0] == '1') ? 0 : 1; }
-    if (skinny && M <= 256 && (K & 31) == 0) {
+    if (skinny && M <= 256 && (K & 7) == 0) {          // (K = 1000: the head's input gradient ran on three 128 x 128 workgroups, 31 us, until round 4)
         const size_t lds = (size_t)8 * 64 * SK_STRIDE * sizeof(float);
         static bool sk_attr = false;
         if (!sk_attr) { (void)hipFuncSetAttribute((const void*)k_gemm_nt_skinny, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); sk_attr = true; (void)hipGetLastError(); }

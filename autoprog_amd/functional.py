@@ -204,8 +204,8 @@ _window = {"problems": [], "ln": [], "params": [], "tiles": 0, "armed": None, "o
 # caller is inside) and _current_graph_task_id (which backward pass that is).  Both are probed once; without them the window still
 # works and is flushed by GradientBucketReducer.finish() -- the sink's contract is "call finish() after backward()" either way.
 _ENGINE = getattr(getattr(torch.autograd, "Variable", None), "_execution_engine", None)
-_HAS_ENGINE_CALLBACK = hasattr(_ENGINE, "queue_callback")
 _graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
+_HAS_ENGINE_CALLBACK = hasattr(_ENGINE, "queue_callback") and _graph_task_id is not None     # (a callback is queued once per pass: both or neither)
 
 
 def _tiles_192(prob):

@@ -85,7 +85,8 @@ def test_layernorm(ops, rows, C, eps):
 
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 192, 192), (300, 486, 192), (128, 1152, 384), (77, 1000, 384),
                                    (512, 384, 1152), (130, 32, 32), (64, 96, 96), (200, 16, 64), (392, 384, 768),
-                                   (2304, 192, 192), (4100, 384, 384), (2500, 1152, 384), (3000, 576, 192), (70000, 192, 576)])
+                                   (2304, 192, 192), (4100, 384, 384), (2500, 1152, 384), (3000, 576, 192), (70000, 192, 576),
+                                   (128, 384, 1000), (100, 64, 40), (256, 392, 1064)])       # few rows, K not a multiple of 32 (the head's input gradient)
 def test_gemm_nt_plain_and_bias(ops, M, N, K):
     a, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
     bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
