@@ -9,8 +9,13 @@ Parity pin: every function here is checked against golden vectors emitted by the
 reference (``tools/gen_golden.py`` imports /root/reference in the build container and
 writes ``tests/golden/*.npz``); see ``tests/test_oracle_golden.py``.  DeiT arithmetic
 lives in un-vendored timm 0.4.5 (``timm.models.vision_transformer``) and is restated
-from its published algorithm: **parity unpinned** for ``vit_forward`` (cross-checked
-against the pinned VOLO blocks instead).
+from its published algorithm: **parity unpinned** for ``vit_forward`` -- no vector the reference
+holds constrains it.  What stands in: its blocks are the pinned VOLO Transformer arithmetic; the
+block equals ``torch.nn.MultiheadAttention`` + pre-LN wiring (fp64, 1e-10); and the whole network
+-- patch embedding, class / distillation tokens, position embedding, blocks, final norm, both heads
+and their eval average, outputs AND gradients -- equals the ``transformers`` library's DeiT (the
+port of facebook/deit, the family models/deit.py registers) on the same weights to 1e-9
+(``test_vit_and_distilled_deit_against_the_transformers_library``).
 
 All ``file:line`` citations are relative to the reference tree.
 """

@@ -346,3 +346,71 @@ def test_late_state_outputs_loss_and_gradients():
         assert rel_err(p[k].grad, ref[k]) < 2e-3, k
     va = torch.cat([p[k].grad.flatten() for k in names]); vb = torch.cat([ref[k].flatten() for k in names])
     assert float((va - vb).norm() / vb.norm()) < 5e-4
+
+
+def test_vit_and_distilled_deit_against_the_transformers_library():
+    """Rows D2 / D3: the reference's DeiT (models/deit.py:20-59) sits on timm 0.4.5's VisionTransformer, which is not under /root/reference,
+    so no reference-held vector constrains the oracle's `vit_forward` (parity unpinned -- stays so).  The closest independent statement
+    in this image: the `transformers` library's DeiT (the port of facebook/deit, the model family models/deit.py registers) -- whole
+    network: patch embedding, class + distillation tokens, position embedding, pre-LN blocks with separate q / k / v projections, final
+    LayerNorm, the two heads and their eval-mode average.  Same weights (the packed qkv of the timm layout split into the three
+    projections), fp64, 2 x 32 px images: class / distillation logits, their eval average and every parameter gradient agree to 1e-9."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import DeiTConfig, DeiTForImageClassificationWithTeacher
+    torch.manual_seed(0)
+    C, depth, heads, hidden, classes, img, patch = 48, 3, 3, 192, 10, 32, 16
+    cfg = DeiTConfig(hidden_size=C, num_hidden_layers=depth, num_attention_heads=heads, intermediate_size=hidden, image_size=img, patch_size=patch,
+                     num_labels=classes, hidden_act="gelu", layer_norm_eps=1e-6, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, qkv_bias=True)
+    hf = DeiTForImageClassificationWithTeacher(cfg).double().eval()
+    with torch.no_grad():
+        for q in hf.parameters():
+            q.copy_(torch.randn(q.shape, dtype=torch.float64) * 0.2)
+    sd = hf.state_dict()
+    keys = set(sd.keys())
+    # timm-layout parameter dict of the oracle from the library's tensors
+    def pick(*names):
+        for n in names:
+            if n in sd:
+                keys.discard(n)
+                return sd[n].detach().clone()
+        raise KeyError(names)
+    p = {"cls_token": pick("deit.embeddings.cls_token"), "dist_token": pick("deit.embeddings.distillation_token"),
+         "pos_embed": pick("deit.embeddings.position_embeddings"),
+         "patch_embed.proj.weight": pick("deit.embeddings.patch_embeddings.projection.weight"),
+         "patch_embed.proj.bias": pick("deit.embeddings.patch_embeddings.projection.bias"),
+         "norm.weight": pick("deit.layernorm.weight"), "norm.bias": pick("deit.layernorm.bias"),
+         "head.weight": pick("cls_classifier.weight"), "head.bias": pick("cls_classifier.bias"),
+         "head_dist.weight": pick("distillation_classifier.weight"), "head_dist.bias": pick("distillation_classifier.bias")}
+    for i in range(depth):
+        L, A = "deit.layers.%d." % i, ("deit.layers.%d.attention." % i)
+        alt = "deit.encoder.layer.%d." % i                       # older releases of the library
+        q = pick(A + "q_proj.weight", alt + "attention.attention.query.weight"); k = pick(A + "k_proj.weight", alt + "attention.attention.key.weight")
+        v = pick(A + "v_proj.weight", alt + "attention.attention.value.weight")
+        qb = pick(A + "q_proj.bias", alt + "attention.attention.query.bias"); kb = pick(A + "k_proj.bias", alt + "attention.attention.key.bias")
+        vb = pick(A + "v_proj.bias", alt + "attention.attention.value.bias")
+        b = "blocks.%d." % i
+        p[b + "attn.qkv.weight"], p[b + "attn.qkv.bias"] = torch.cat([q, k, v], 0), torch.cat([qb, kb, vb], 0)
+        p[b + "attn.proj.weight"], p[b + "attn.proj.bias"] = pick(A + "o_proj.weight", alt + "attention.output.dense.weight"), pick(A + "o_proj.bias", alt + "attention.output.dense.bias")
+        p[b + "norm1.weight"], p[b + "norm1.bias"] = pick(L + "layernorm_before.weight", alt + "layernorm_before.weight"), pick(L + "layernorm_before.bias", alt + "layernorm_before.bias")
+        p[b + "norm2.weight"], p[b + "norm2.bias"] = pick(L + "layernorm_after.weight", alt + "layernorm_after.weight"), pick(L + "layernorm_after.bias", alt + "layernorm_after.bias")
+        p[b + "mlp.fc1.weight"], p[b + "mlp.fc1.bias"] = pick(L + "mlp.fc1.weight", alt + "intermediate.dense.weight"), pick(L + "mlp.fc1.bias", alt + "intermediate.dense.bias")
+        p[b + "mlp.fc2.weight"], p[b + "mlp.fc2.bias"] = pick(L + "mlp.fc2.weight", alt + "output.dense.weight"), pick(L + "mlp.fc2.bias", alt + "output.dense.bias")
+    assert not keys, ("library tensors the mapping did not consume", sorted(keys))
+    for t in p.values():
+        t.requires_grad_(True)
+    x = torch.randn(2, 3, img, img, dtype=torch.float64)
+    out = hf(pixel_values=x)
+    y, yd = R.vit_forward(p, x, depth=depth, heads=heads, patch=patch, distilled=True, train=True)
+    assert rel_err(y, out.cls_logits) < 1e-9 and rel_err(yd, out.distillation_logits) < 1e-9
+    assert rel_err(R.vit_forward(p, x, depth=depth, heads=heads, patch=patch, distilled=True, train=False), out.logits) < 1e-9
+    w = torch.randn(2, classes, dtype=torch.float64)
+    ((out.cls_logits * w).sum() + (out.distillation_logits * w.flip(0)).sum()).backward()
+    ((y * w).sum() + (yd * w.flip(0)).sum()).backward()
+    hg = {n: q.grad for n, q in hf.named_parameters()}
+    assert rel_err(p["head.weight"].grad, hg["cls_classifier.weight"]) < 1e-9
+    assert rel_err(p["pos_embed"].grad, hg["deit.embeddings.position_embeddings"]) < 1e-9
+    assert rel_err(p["patch_embed.proj.weight"].grad, hg["deit.embeddings.patch_embeddings.projection.weight"]) < 1e-9
+    qn = next(n for n in hg if n.endswith(("layers.1.attention.q_proj.weight", "layer.1.attention.attention.query.weight")))
+    assert rel_err(p["blocks.1.attn.qkv.weight"].grad[:C], hg[qn]) < 1e-9
+    f2 = next(n for n in hg if n.endswith(("layers.2.mlp.fc2.weight", "layer.2.output.dense.weight")))
+    assert rel_err(p["blocks.2.mlp.fc2.weight"].grad, hg[f2]) < 1e-9
