@@ -344,7 +344,8 @@ def main():
             AF.FP8_LINEAR = True
         args.variant, args.res = "volo_d5", 448
         if args.batch == 128:
-            args.batch = 16
+            args.batch = 64          # sized for 288 GB of HBM: 16 images (rounds 2 - 3) leave the D5 GEMMs at 147 - 588 tiles for 256 CUs;
+                                     # measured 268 / 297 / 320 / 333 images/s at batch 16 / 32 / 64 / 96 (profiles/r04_d5_batch_scaling.txt)
         model = create_model("volo_d5", img_size=448, drop_path_rate=0.1).to(dev).train()
     else:
         model = create_model("model_variant", variant=args.variant, drop_path_rate=0.1).to(dev).train()
