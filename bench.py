@@ -45,6 +45,11 @@ PEAK_HBM_TBS = 8.0              # HBM3E peak
 STAGES = [(9, 128, 0.0), (12, 160, 0.0333), (15, 192, 0.0667), (18, 224, 0.1)]      # prog/progressive.py:4-31 with scripts/train_autoprog.sh
 
 
+def default_batch(workload):
+    """per-GPU batch of a workload when --batch is not given (128: the reference script's, scripts/train_autoprog.sh:3)"""
+    return 64 if workload == "d5" else 128
+
+
 def kernel_source_hash():
     """sha256 over the kernel sources: profiles/gemm_nt_traffic.json records the hash of the tree its counters were collected on,
     and the bench line carries `roofline.traffic` only while the sources are still those (a stale file reads as null)"""
@@ -344,7 +349,7 @@ def main():
             AF.FP8_LINEAR = True
         args.variant, args.res = "volo_d5", 448
         if args.batch == 128:
-            args.batch = 64          # sized for 288 GB of HBM: 16 images (rounds 2 - 3) leave the D5 GEMMs at 147 - 588 tiles for 256 CUs;
+            args.batch = default_batch("d5")          # sized for 288 GB of HBM: 16 images (rounds 2 - 3) leave the D5 GEMMs at 147 - 588 tiles for 256 CUs;
                                      # measured 268 / 297 / 320 / 333 images/s at batch 16 / 32 / 64 / 96 (profiles/r04_d5_batch_scaling.txt)
         model = create_model("volo_d5", img_size=448, drop_path_rate=0.1).to(dev).train()
     else:
@@ -499,7 +504,7 @@ def main():
             tname = "gemm_nt_traffic.json" if args.workload == "d1" else "gemm_nt_traffic_%s.json" % args.workload      # tools/collect_traffic.sh
             with open(os.path.join(ROOT, "profiles", tname)) as fh:
                 tj = json.load(fh)
-            if tj.get("src_sha256") == kernel_source_hash() and not args.fp8:
+            if tj.get("src_sha256") == kernel_source_hash() and not args.fp8 and tj.get("per_gpu_batch", default_batch(args.workload)) == B:
                 traffic = tj.get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             pass

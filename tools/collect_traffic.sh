@@ -22,7 +22,7 @@ for b in re.split(r"\n(?=\S)", txt):
             k = int(mf.group(2)); fetch += float(mf.group(1)) * k; write += float(mw.group(1)) * k; n += k
 if n:
     import bench
-    json.dump({"kernel": "k_gemm_nt_8p + k_gemm_nt (all instantiations)", "workload": W, "hbm_bytes_per_launch": round((2.0 * fetch + write) / n * 1024.0),
+    json.dump({"kernel": "k_gemm_nt_8p + k_gemm_nt (all instantiations)", "workload": W, "per_gpu_batch": bench.default_batch(W), "hbm_bytes_per_launch": round((2.0 * fetch + write) / n * 1024.0),
                "launches": int(n), "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB per dispatch, dispatch-weighted over the k_gemm_nt* instantiations",
                "src_sha256": bench.kernel_source_hash()}, open("gpurun_out/gemm_nt_traffic_%s.json" % W, "w"))
     print(open("gpurun_out/gemm_nt_traffic_%s.json" % W).read())
