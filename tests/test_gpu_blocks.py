@@ -11,6 +11,7 @@ from oracle import ref_cpu as R
 
 pytestmark = pytest.mark.gpu
 TOL = 2.5e-2
+STEM_KERNEL_TOL = 5e-3
 
 
 def rel(a, b):
@@ -191,6 +192,57 @@ def test_hip_stem64_vs_reference_golden(monkeypatch):
     print("stem64 vs oracle (3 x 48 x 48) gradient errors:", {k: round(v, 4) for k, v in sorted(errs2.items(), key=lambda kv: -kv[1])})
     bad = {k: v for k, v in errs2.items() if v > (1.5e-2 if k.startswith("proj") else 1.3 * max(base.values()))}
     assert not bad, bad
+
+
+def test_hip_stem64_kernels_vs_fp64_with_the_same_rounding_points():
+    """The stem KERNELS held to 5e-3 (measured 2.6e-3 at worst), independently of what bf16 activations cost under three training-mode BatchNorms (the test above
+    can only hold them to an independent bf16 implementation's error, up to 0.16 per tensor): the oracle's PatchEmbed in fp64 with every
+    tensor that the HIP pipeline keeps in bf16 -- image, convolution outputs, activations, weight operands, and their gradients on the
+    way back -- rounded to bf16 at the same place (oracle/ref_cpu.py patch_embed(bf16_points=True)).  What is left is the kernels'
+    own arithmetic: fp32 accumulation order, fp32 BatchNorm statistics, roundings that flip on a near-tie.  Output, running statistics
+    and EVERY parameter gradient of csrc/conv7.hip, csrc/conv.hip (forward, input gradient, weight gradient, BatchNorm applied in the
+    staging), csrc/bnrelu.hip and the patch-addressed GEMMs, on the reference fixture's weights (2 x 32 x 32) and on an odd batch whose
+    feature map does not divide the convolution tiles (3 x 80 x 80).  Measured on MI355X: output 7.3e-4 / 6.8e-4; gradients 2e-4 behind one
+    BatchNorm backward, 9e-4 behind two, 1.9e-3 - 2.6e-3 behind all three (fixture: 512 samples per channel; 1.1e-3 - 1.4e-3 on the larger
+    input) -- a rounding that falls the other way is a 4e-3 step on that element and travels on through the layers below it.  Bound:
+    STEM_KERNEL_TOL = 5e-3 per tensor, 60x below what the bf16 recipe itself costs on this fixture."""
+    d = load("stem64")
+    cases = [("fixture", torch.from_numpy(d["train.x"]), torch.from_numpy(d["train.dy"]))]
+    g = torch.Generator().manual_seed(17)
+    cases.append(("3x80x80", torch.randn(3, 3, 80, 80, generator=g), None))
+    for tag, x, dy in cases:
+        pe = _stem64_module(d, hip=True)
+        p64 = {}
+        for k, v in pe.state_dict().items():
+            p64[k] = v.detach().double().cpu()
+            if p64[k].dtype.is_floating_point and "running" not in k:
+                p64[k].requires_grad_(True)
+        y = pe(x.cuda())
+        ref = R.patch_embed(x.double(), p64, train=True, patch_size=8, pre="", bf16_points=True)       # [B, h, w, C]
+        if dy is None:
+            dy = torch.randn(ref.permute(0, 3, 1, 2).shape, generator=g)
+        dyb = dy.to(torch.bfloat16)
+        ref.backward(dyb.double().permute(0, 2, 3, 1))
+        y.backward(dyb.cuda().to(y.dtype))
+        e_y = rel(y, ref.detach().permute(0, 3, 1, 2))
+        errs = {n: rel(p.grad, p64[n].grad) for n, p in pe.named_parameters()}
+        print("stem64 kernels vs rounding-matched fp64 (%s): output %.2e; gradients" % (tag, e_y),
+              {k: float("%.2e" % v) for k, v in sorted(errs.items(), key=lambda kv: -kv[1])})
+        assert e_y < STEM_KERNEL_TOL, (tag, e_y)
+        bad = {k: v for k, v in errs.items() if v > STEM_KERNEL_TOL}
+        assert not bad, (tag, bad)
+        # running statistics after one step (momentum 0.1, unbiased variance): from the oracle's rounded convolution outputs
+        xr = x.to(torch.bfloat16).double()
+        with torch.no_grad():
+            for i, (s, pad) in zip((0, 3, 6), ((2, 3), (1, 1), (1, 1))):
+                z = torch.nn.functional.conv2d(xr, p64["conv.%d.weight" % i].detach().to(torch.bfloat16).double(), None, stride=s, padding=pad)
+                z = z.to(torch.bfloat16).double()
+                n = z.numel() // z.shape[1]
+                bn = pe.conv[i + 1]
+                assert rel(bn.running_mean, 0.1 * z.mean((0, 2, 3))) < 2e-3, (tag, i)
+                assert rel(bn.running_var, 0.9 + 0.1 * z.var((0, 2, 3), unbiased=True)) < 2e-3, (tag, i, n)
+                xr = torch.relu(R.batchnorm_train(z, p64["conv.%d.weight" % (i + 1)].detach(), p64["conv.%d.bias" % (i + 1)].detach()))
+                xr = xr.to(torch.bfloat16).double()
 
 
 def test_stem64_fused_batchnorm_input_is_bit_identical_to_the_chain(monkeypatch):
