@@ -73,7 +73,7 @@ _SIGNATURES = {
     "ap_class_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "ap_mix_token_swap": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ap_soft_ce_fwd_bwd": (_I, [_P, _I, _P, _L, _L, _L, _I, _P, _P, _F, _L, _I, _F, _I, _P]),
-    "ap_soft_ce_sparse_fwd_bwd": (_I, [_P, _I, _P, _P, _I, _L, _L, _I, _F, _P, _P, _F, _L, _I, _P]),
+    "ap_soft_ce_sparse_fwd_bwd": (_I, [_P, _I, _P, _P, _I, _L, _L, _I, _F, _P, _P, _F, _L, _I, _F, _I, _P]),
     "ap_loss_combine": (_I, [_P, _L, _F, _P, _L, _F, _P, _P]),
     "ap_row_scale": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "ap_add_bcast": (_I, [_P, _P, _P, _L, _L, _P]),
@@ -110,7 +110,7 @@ _SIGNATURES["ap_conv3x3_c64_wgrad"] = (_I, [_P, _P, _P, _I, _I, _I, _P, ctypes.c
 _SIGNATURES["ap_sum_reps_acc"] = (_I, [_P, _P, _L, _I, _P])
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
-EXPECTED_ABI = 4                     # ap_abi_version() of the library these ctypes Structures mirror (include/autoprog_hip.h)
+EXPECTED_ABI = 5                     # ap_abi_version() of the library these ctypes Structures mirror (include/autoprog_hip.h)
 
 
 class AutoProgHipError(RuntimeError):

@@ -117,15 +117,19 @@ k_soft_ce(const bf16_t* __restrict__ logits, int ldx, const float* __restrict__ 
 //     t[c] = (1 - s) * sum_k [idx_k == c] * val_k + s / C
 // formed in registers from its K pairs: logits in, dlogits out, nothing else.  One wave per row, a lane owns class pairs
 // 2 (lane + 64 i).  Pairs of row r = (b, n), b = r / rows_per_batch, sit at pairs + b * p_sb + n * p_sn (K entries each).
+// mix_batches = B > 0 (the mix-token class target, loss/cross_entropy.py:150-152: lam * t[b] + (1 - lam) * t[B-1-b]): lanes K .. 2K-1
+// hold the pairs of the same slot of image B-1-b weighted 1 - lam, the row's own are weighted lam -- 2K <= CE_MAXK pairs, no
+// concatenated / flipped / scaled copies of the label maps on the host side.
 #define CE_MAXK 16
 #define CE_SR 4            // rows per wave, all of their loads issued before the first is reduced
 __global__ void __launch_bounds__(256)
 k_soft_ce_sparse(const bf16_t* __restrict__ logits, int ldx, const int* __restrict__ idx, const float* __restrict__ val, int K,
                  int64_t p_sb, int64_t p_sn, int rows_per_batch, float smoothing, float* __restrict__ row_loss,
-                 bf16_t* __restrict__ dlogits, float gscale, int64_t M, int C) {
+                 bf16_t* __restrict__ dlogits, float gscale, int64_t M, int C, float mix_lam, int mix_batches) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * CE_SR;
     if (row0 >= M) return;
+    const int KK = mix_batches > 0 ? 2 * K : K;              // pairs per row
     unsigned lraw[CE_SR][CE_MAXV];
     int my_i[CE_SR];
     float my_v[CE_SR];
@@ -136,9 +140,11 @@ k_soft_ce_sparse(const bf16_t* __restrict__ logits, int ldx, const int* __restri
 #pragma unroll
         for (int i = 0; i < CE_MAXV; ++i) lraw[r][i] = *reinterpret_cast<const unsigned*>(xr + min(2 * (lane + 64 * i), ldx - 2));
         const int64_t b = row / rows_per_batch, n = row - b * rows_per_batch;
-        const int64_t po = b * p_sb + n * p_sn;
-        my_i[r] = lane < K ? idx[po + lane] : -1;                    // lane k holds pair k of the row
-        my_v[r] = lane < K ? val[po + lane] * (1.0f - smoothing) : 0.f;
+        const bool other = lane >= K;                                // (mix) the partner image's pairs
+        const int64_t po = ((mix_batches > 0 && other) ? (int64_t)(mix_batches - 1) - b : b) * p_sb + n * p_sn + (other ? lane - K : lane);
+        const float wgt = mix_batches > 0 ? (other ? 1.0f - mix_lam : mix_lam) : 1.0f;
+        my_i[r] = lane < KK ? idx[po] : -1;                          // lane k holds pair k of the row
+        my_v[r] = lane < KK ? val[po] * wgt * (1.0f - smoothing) : 0.f;
     }
     const float base = smoothing / (float)C;
 #pragma unroll
@@ -157,7 +163,7 @@ k_soft_ce_sparse(const bf16_t* __restrict__ logits, int ldx, const int* __restri
             mx = fmaxf(mx, fmaxf(xv[i][0], xv[i][1]));
         }
         // the K pairs are wave-uniform once read with v_readlane: class ci = 2 * (owner + 64 * slot) + (ci & 1) lives in ONE lane
-        for (int k = 0; k < K; ++k) {
+        for (int k = 0; k < KK; ++k) {
             const int ci = __builtin_amdgcn_readlane(my_i[r], k);
             const float cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_v[r]), k));
             if (ci < 0 || ci >= C) continue;
@@ -240,13 +246,14 @@ extern "C" int ap_soft_ce_fwd_bwd(const ap_bf16* logits, int ldx, const float* t
 
 extern "C" int ap_soft_ce_sparse_fwd_bwd(const ap_bf16* logits, int ldx, const int* idx, const float* val, int K, int64_t p_sb, int64_t p_sn,
                                          int rows_per_batch, float smoothing, float* row_loss, ap_bf16* dlogits, float grad_scale,
-                                         int64_t M, int C, ap_stream_t stream) {
+                                         int64_t M, int C, float mix_lam, int mix_batches, ap_stream_t stream) {
     if (!logits || !idx || !val || !row_loss || !dlogits) return AP_ERR_NULL;
     if (C <= 0 || ldx < C || (ldx & 7) || rows_per_batch <= 0 || M < 0 || K <= 0 || K > CE_MAXK || smoothing < 0.f || smoothing >= 1.f) return AP_ERR_SHAPE;
+    if (mix_batches != 0 && (mix_batches < 0 || (int64_t)mix_batches * rows_per_batch != M || 2 * K > CE_MAXK)) return AP_ERR_SHAPE;
     if (ldx > 64 * 2 * CE_MAXV) return AP_ERR_UNSUPPORTED;
     if (M == 0) return AP_OK;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_soft_ce_sparse, dim3((unsigned)((M + 4 * CE_SR - 1) / (4 * CE_SR))), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const bf16_t*>(logits), ldx,
-                       idx, val, K, p_sb, p_sn, rows_per_batch, smoothing, row_loss, reinterpret_cast<bf16_t*>(dlogits), grad_scale, M, C);
+                       idx, val, K, p_sb, p_sn, rows_per_batch, smoothing, row_loss, reinterpret_cast<bf16_t*>(dlogits), grad_scale, M, C, mix_lam, mix_batches);
     return ap_check_launch();
 }

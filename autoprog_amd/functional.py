@@ -590,7 +590,10 @@ class ClassBlockFn(torch.autograd.Function):
         cls += proj(class_attn(LN1([cls; tokens])));  cls += fc2(gelu(fc1(LN2(cls))))
     The reference concatenates [cls; tokens] before every class block and slices the result apart again; LayerNorm and the kv
     projection act per row, so both run on the two pieces separately and the attention kernel reads key 0 from the class-token
-    piece (split layout of ap_class_attn_*): no concatenation, no slicing, and the residual adds sit in the GEMM epilogues."""
+    piece (split layout of ap_class_attn_*): no concatenation, no slicing, and the residual adds sit in the GEMM epilogues.
+    Returns (cls, tokens): the tokens pass through unchanged (models/volo.py:308 returns them inside the concatenation) so that the
+    NEXT consumer's gradient arrives here as the second output's and is added inside this block's LayerNorm backward kernel -- with
+    the tokens fanned out to two class blocks and the final norm, autograd would add three [B,N,C] gradients in two extra passes."""
 
     @staticmethod
     def forward(ctx, cls, tok, n1w, n1b, kv_w, kv_b, q_w, q_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, B, N, heads, eps):
@@ -614,17 +617,19 @@ class ClassBlockFn(torch.autograd.Function):
                               n1w, n1b, kv_w, kv_b, q_w, q_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
         ctx.cfg = (B, N, heads, scale)
         ctx.shapes = (cls.shape, tok.shape)
-        return c2
+        ctx.set_materialize_grads(False)          # an unused output hands None to backward, not a zero tensor
+        return c2, tok
 
     @staticmethod
-    def backward(ctx, dc2):
+    def backward(ctx, dc2, dtok_pass):
         (c0, t0, mc, rc, mt, rt, nc, nt, kv_t, kv_c, q, o, probs, c1, m2, r2, n2, h, a,
          n1w, n1b, kv_w, kv_b, q_w, q_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b) = ctx.saved_tensors
         B, N, heads, scale = ctx.cfg
         params = (n1w, n1b, kv_w, kv_b, q_w, q_b, proj_w, proj_b, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b)
         bufs, sunk = _param_grad_buffers(params)
         (dn1w, dn1b, dkv_w, dkv_b, dq_w, dq_b, dproj_w, dproj_b, dn2w, dn2b, dfc1_w, dfc1_b, dfc2_w, dfc2_b) = bufs
-        g = dc2.contiguous()
+        g = dc2.contiguous() if dc2 is not None else torch.zeros(c0.shape, dtype=BF16, device=c0.device)
+        dpass = dtok_pass.reshape(t0.shape).contiguous() if dtok_pass is not None else None
         with wgrad_batch() as batch:          # (not in the weight-gradient window: 12 small problems for one 8-tile one)
             dh = _linear_bwd(g, a, fc2_w, dfc2_w, dfc2_b, **_gelu_bwd_kw(h))
             dn2 = _linear_bwd(dh, n2, fc1_w, dfc1_w, dfc1_b)
@@ -637,7 +642,7 @@ class ClassBlockFn(torch.autograd.Function):
             wq_t = bank.get_t(q_w)
             dnc = ops.gemm_nt(dq, wq_t, n=wq_t.shape[0], k=wq_t.shape[1], residual=dnc_kv)      # dq Wq + dkv_c Wkv in one epilogue
             dcls = ops.layernorm_bwd(dnc, c0, n1w, mc, rc, dc1, dn1w, dn1b)       # reduced at once: it shares dn1w / dn1b with the deferred
-            dtok = ops.layernorm_bwd(dnt, t0, n1w, mt, rt, None, dn1w, dn1b, defer=batch.ln)      # token piece (two deferred sums into one vector would race)
+            dtok = ops.layernorm_bwd(dnt, t0, n1w, mt, rt, dpass, dn1w, dn1b, defer=batch.ln)     # token piece (two deferred sums into one vector would race)
         return (dcls.view(ctx.shapes[0]), dtok.view(ctx.shapes[1]), *_finish_param_grads(params, bufs, sunk, batch.deferred), None, None, None, None)
 
 
@@ -773,6 +778,25 @@ class ClassAttnFn(torch.autograd.Function):
         return dq, dkv.view(kvc.shape), None
 
 
+class ClsExpandFn(torch.autograd.Function):
+    """cls_token.expand(B, -1, -1) (models/volo.py:637) as a bf16 [B, C] view of one cast row; the gradient is the column sum over
+    the batch, accumulated in fp32 by ap_colsum_acc straight into the parameter's gradient (torch: cast, expand, a bf16 reduction
+    kernel that takes 14 us for 128 x 384, cast back, add)."""
+
+    @staticmethod
+    def forward(ctx, cls_token, B):
+        ctx.save_for_backward(cls_token)
+        return ops.cast_bf16(cls_token.detach().reshape(1, -1)).expand(B, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (cls_token,) = ctx.saved_tensors
+        bufs, sunk = _param_grad_buffers((cls_token,))
+        ops.colsum_acc(g.contiguous(), bufs[0].view(-1))
+        (dc,) = _finish_param_grads((cls_token,), bufs, sunk)
+        return dc, None
+
+
 class MixSwapFn(torch.autograd.Function):
     """y[b, r0:r1, c0:c1] = x[B-1-b, r0:r1, c0:c1] (models/volo.py:654-658, 685-689); the
     backward is the same permutation."""
@@ -875,7 +899,7 @@ class SparseTokenLabelCEFn(torch.autograd.Function):
     """TokenLabelCrossEntropy on the token-label target in its SOURCE form -- top-K (class, score) pairs per slot [B, 2+N, K] and a
     label-smoothing strength -- instead of the dense [B,C,2+N] tensor the reference builds from them on the GPU every step
     (main_prog.py:994-1004; loss/cross_entropy.py:136-156 for the loss itself).  Same three launches as TokenLabelCEFn; the
-    mix-token class target lam * t[b] + (1 - lam) * t[B-1-b] is 2K pairs per image (a [B, 2K] concatenation, built here)."""
+    mix-token class target lam * t[b] + (1 - lam) * t[B-1-b] is 2K pairs per image, gathered by the kernel from the two label maps."""
 
     @staticmethod
     def forward(ctx, x_cls, x_aux, idx, val, smoothing, lam, cls_weight, dense_weight):
@@ -892,12 +916,10 @@ class SparseTokenLabelCEFn(torch.autograd.Function):
         idx, val = idx.contiguous(), val.contiguous()
         rl_aux, d_aux = ops.soft_ce_sparse_fwd_bwd(padded(x_aux.reshape(B * N, C)), C, idx[:, 2:], val[:, 2:], (2 + N) * K, K, N, smoothing,
                                                    dense_weight / (B * N))
-        if lam < 1:
-            ci = torch.cat([idx[:, 1], idx[:, 1].flip(0)], dim=1).contiguous()
-            cv = torch.cat([val[:, 1] * lam, val[:, 1].flip(0) * (1.0 - lam)], dim=1).contiguous()
-        else:
-            ci, cv = idx[:, 1].contiguous(), val[:, 1].contiguous()
-        rl_cls, d_cls = ops.soft_ce_sparse_fwd_bwd(padded(x_cls.reshape(B, C)), C, ci, cv, ci.shape[1], 0, 1, smoothing, cls_weight / B)
+        # the class row: slot 1 of every image, in place (stride (2 + N) K); the mix-token target lam * t[b] + (1 - lam) * t[B-1-b] is
+        # formed by the kernel from the two images' pairs
+        rl_cls, d_cls = ops.soft_ce_sparse_fwd_bwd(padded(x_cls.reshape(B, C)), C, idx[:, 1], val[:, 1], (2 + N) * K, 0, 1, smoothing, cls_weight / B,
+                                                   mix_lam=lam, mix_batches=B if lam < 1 else 0)
         ctx.save_for_backward(d_cls, d_aux)
         ctx.dims = (B, N, C)
         return ops.loss_combine(rl_cls, cls_weight / B, rl_aux, dense_weight / (B * N))

@@ -263,14 +263,17 @@ class ClassBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
 
-    def forward_split(self, cls, tokens):
-        """class token [B,C] and tokens [B,N,C] kept apart -> updated class token [B,C] (one fused forward / backward pair)"""
+    def forward_split(self, cls, tokens, pass_tokens=False):
+        """class token [B,C] and tokens [B,N,C] kept apart -> updated class token [B,C] (one fused forward / backward pair).
+        pass_tokens: -> (class token, tokens); a caller that goes on with THAT tokens tensor instead of its own chains the token
+        gradients through the blocks' LayerNorm backward kernels (functional.ClassBlockFn) instead of fanning them out for autograd to add"""
         cls, tokens = _bf16(cls), _bf16(tokens)
         B, N, C = tokens.shape
         a, m = self.attn, self.mlp
-        return AF.ClassBlockFn.apply(cls, tokens, self.norm1.weight, self.norm1.bias, a.kv.weight, a.kv.bias, a.q.weight, a.q.bias,
-                                     a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
-                                     m.fc2.weight, m.fc2.bias, B, N, a.num_heads, self.norm1.eps)
+        out = AF.ClassBlockFn.apply(cls, tokens, self.norm1.weight, self.norm1.bias, a.kv.weight, a.kv.bias, a.q.weight, a.q.bias,
+                                    a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
+                                    m.fc2.weight, m.fc2.bias, B, N, a.num_heads, self.norm1.eps)
+        return out if pass_tokens else out[0]
 
     def forward_cls(self, x):
         """x [B,1+N,C] -> updated class token [B,1,C]"""
@@ -598,9 +601,9 @@ class VOLO(nn.Module):
     def forward_cls(self, x):
         """class blocks on the (class token, tokens) pair without ever concatenating them (models/volo.py:636-642 does)"""
         B = x.shape[0]
-        cls = self.cls_token.to(BF16).reshape(1, -1).expand(B, -1)
+        cls = AF.ClsExpandFn.apply(self.cls_token, B)
         for block in self.post_network:
-            cls = block.forward_split(cls, x)
+            cls, x = block.forward_split(cls, x, pass_tokens=True)      # the tokens come back unchanged: one gradient chain, no fan-out
         return cls.unsqueeze(1), x
 
     def forward(self, x):

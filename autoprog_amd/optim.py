@@ -11,6 +11,7 @@ import ctypes
 import torch
 
 from ._lib import check, lib
+from . import ops
 
 
 class FlatAdamWEma:
@@ -123,7 +124,7 @@ class FlatAdamWEma:
     def _refresh_transposes(self):
         if self._tr_desc is not None:
             check(lib.ap_batched_transpose_bf16(self.p16.data_ptr(), self.p16_t.data_ptr(), self._tr_desc.data_ptr(), self._tr_count,
-                                                self._tr_tiles, torch.cuda.current_stream().cuda_stream), "ap_batched_transpose_bf16")
+                                                self._tr_tiles, ops._stream()), "ap_batched_transpose_bf16")
 
     def step(self):
         self.step_count += 1
@@ -138,7 +139,7 @@ class FlatAdamWEma:
         check(lib.ap_adamw_ema_step(self.p.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.wd_mask.data_ptr(),
                                     self.n_pad, lr, self.betas[0], self.betas[1], self.eps, wd, self.step_count, float(self.reducer.take_pending_scale()),
                                     self._ema_ptrs, self._ema_decay, len(self.ema), self.p16.data_ptr(),
-                                    torch.cuda.current_stream().cuda_stream), "ap_adamw_ema_step")
+                                    ops._stream()), "ap_adamw_ema_step")
         self._refresh_transposes()
         from . import functional
         functional._WeightBank.generation += 1             # the kernel wrote the parameters behind autograd's back

@@ -230,10 +230,13 @@ int ap_soft_ce_fwd_bwd(const ap_bf16* logits, int ldx, const float* target, int6
  * feeds it to loss/cross_entropy.py:136-156.  Here the target of logits row r = (b, n), b = r / rows_per_batch, is
  *   t[c] = (1 - smoothing) * sum_k [idx[o + k] == c] * val[o + k] + smoothing / C,   o = b * p_sb + n * p_sn,   k < K <= 16
  * (repeated indices accumulate, indices outside [0, C) contribute nothing); loss and gradient as ap_soft_ce_fwd_bwd.  No dense
- * target exists: 101 MB less to read per step at B = 128. */
+ * target exists: 101 MB less to read per step at B = 128.
+ * mix_batches = B > 0 (ABI version 5; as in ap_soft_ce_fwd_bwd): the mix-token class target of loss/cross_entropy.py:150-152,
+ * t = mix_lam * t[b] + (1 - mix_lam) * t[B-1-b] -- row (b, n) takes the K pairs of its own slot weighted mix_lam and the K pairs of the
+ * same slot of image B-1-b weighted 1 - mix_lam (2 K <= 16; M == B * rows_per_batch).  0: no mixing (mix_lam ignored). */
 int ap_soft_ce_sparse_fwd_bwd(const ap_bf16* logits, int ldx, const int* idx, const float* val, int K, int64_t p_sb, int64_t p_sn,
                               int rows_per_batch, float smoothing, float* row_loss, ap_bf16* dlogits, float grad_scale,
-                              int64_t M, int C, ap_stream_t stream);
+                              int64_t M, int C, float mix_lam, int mix_batches, ap_stream_t stream);
 /* out[0] = wa * sum(a[0:na]) + wb * sum(b[0:nb]): cls_weight * mean(row losses) + dense_weight * mean(row losses)
  * of the token-label loss (loss/cross_entropy.py:154-156) in one launch */
 int ap_loss_combine(const float* a, int64_t na, float wa, const float* b, int64_t nb, float wb, float* out, ap_stream_t stream);

@@ -44,7 +44,7 @@ def dev(t):
 # ------------------------------------------------------------------------------------------
 def test_abi_loaded(ops):
     from autoprog_amd._lib import lib, LIB_PATH
-    assert lib.ap_abi_version() == 4
+    assert lib.ap_abi_version() == 5
     assert LIB_PATH.endswith("libautoprog_hip.so")
 
 
