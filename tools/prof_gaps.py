@@ -2,7 +2,8 @@
 """GPU idle analysis of a rocprofv3 kernel trace: union of busy intervals over all streams inside the window that
 starts after the N-th k_soft_ce launch; reports busy/idle time and the largest idle gaps with the kernels around them.
 
-  python tools/prof_gaps.py <kernel_trace.csv> [N=6]"""
+  python tools/prof_gaps.py <kernel_trace.csv> [N=6] [M=0]      M > 0: the window ends with the (N + M)-th k_soft_ce launch's step
+  (bench.py --steps 7 --warmup 3: N = 6, M = 14 keeps the seven timed steps and drops the synchronised probe steps behind them)"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 nth = int(sys.argv[2]) if len(sys.argv) > 2 else 6
@@ -13,7 +14,18 @@ for r in rows:
         seen += 1
         if seen == nth:
             t0 = int(r["End_Timestamp"]); break
-iv = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:50], r.get("Queue_Id", r.get("Stream_Id", "?"))) for r in rows if int(r["Start_Timestamp"]) >= t0]
+mth = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+t1 = 1 << 62
+if mth:
+    seen = 0
+    for r in rows:                      # the window ends where the step AFTER the last kept one starts (its first k_soft_ce is launch N + M + 1: cut at
+        if "k_soft_ce" in r["Kernel_Name"]:            # the optimizer kernel in front of it)
+            seen += 1
+            if seen == nth + mth + 1:
+                t1 = int(r["Start_Timestamp"]); break
+    last_opt = max((int(r["End_Timestamp"]) for r in rows if "k_adamw" in r["Kernel_Name"] and int(r["End_Timestamp"]) < t1), default=t1)
+    t1 = last_opt
+iv = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:50], r.get("Queue_Id", r.get("Stream_Id", "?"))) for r in rows if t0 <= int(r["Start_Timestamp"]) < t1]
 span = iv[-1][1] - iv[0][0]
 busy = 0; cur_s, cur_e = iv[0][0], iv[0][1]; gaps = []
 last_name = iv[0][2]
