@@ -28,13 +28,22 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _req(t, dtype, name):
+def _req_fail(t, dtype, name):
     if not (torch.is_tensor(t) and t.is_cuda):
         raise AutoProgHipError("%s must be a CUDA tensor (the HIP path has no CPU fallback)" % name)
     if t.dtype != dtype:
         raise AutoProgHipError("%s must be %s, got %s" % (name, dtype, t.dtype))
-    if not t.is_contiguous():
-        raise AutoProgHipError("%s must be contiguous" % name)
+    raise AutoProgHipError("%s must be contiguous" % name)
+
+
+def _req(t, dtype, name):
+    """every tensor that goes to the library: CUDA, the kernel's dtype, contiguous (one expression on the hot path: ~1900 calls per step)"""
+    try:
+        ok = t.dtype is dtype and t.is_cuda and t.is_contiguous()
+    except AttributeError:
+        ok = False
+    if not ok:
+        _req_fail(t, dtype, name)
     return t
 
 
@@ -112,6 +121,9 @@ def layernorm_fwd(x, gamma, beta, eps, fp8=None):
     return y, mean, rstd
 
 
+_ln_ws = {}          # (rows, C) -> ap_layernorm_bwd_workspace bytes (a pure function of the shape: one foreign call per shape, not per launch)
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, defer=None):
     """dx = dres + dLN/dx ; dgamma/dbeta (fp32) are accumulated in place.  defer: a list -- the dgamma/dbeta reduction is not
     launched but appended to it (layernorm_bwd_reduce_batched reduces the LayerNorms of a block in one launch)."""
@@ -119,7 +131,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, defer=None):
     C = x.shape[-1]
     rows = x.numel() // C
     dx = torch.empty_like(x)
-    ws_bytes = lib.ap_layernorm_bwd_workspace(rows, C)
+    ws_bytes = _ln_ws.get((rows, C))
+    if ws_bytes is None:
+        ws_bytes = _ln_ws[(rows, C)] = lib.ap_layernorm_bwd_workspace(rows, C)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     if defer is not None and rows > 0:
         n = ctypes.c_int(0)
@@ -159,18 +173,22 @@ def gemm_nt(a, b, n=None, k=None, bias=None, gelu=False, preact_out=None, dgelu_
         out = torch.empty((M, ldc), dtype=BF16, device=a.device)
     else:
         ldc = out.shape[1]
-    epi = GemmEpilogue()
-    epi.bias = bias.data_ptr() if bias is not None else None
-    epi.gelu = (2 if preact_grad else 1) if gelu else 0
-    epi.preact_out = preact_out.data_ptr() if preact_out is not None else None
-    epi.dgelu_of = dgelu_of.data_ptr() if dgelu_of is not None else None
-    epi.mul_by = mul_by.data_ptr() if mul_by is not None else None
-    epi.row_scale = row_scale.data_ptr() if row_scale is not None else None
-    epi.rows_per_scale = int(rows_per_scale)
-    epi.residual = residual.data_ptr() if residual is not None else None
-    epi.ldr = residual.shape[1] if residual is not None else 0
+    if bias is None and not gelu and dgelu_of is None and mul_by is None and row_scale is None and residual is None:
+        epi_ref = None                                            # plain product: the library takes a null epilogue
+    else:
+        epi = GemmEpilogue()
+        epi.bias = bias.data_ptr() if bias is not None else None
+        epi.gelu = (2 if preact_grad else 1) if gelu else 0
+        epi.preact_out = preact_out.data_ptr() if preact_out is not None else None
+        epi.dgelu_of = dgelu_of.data_ptr() if dgelu_of is not None else None
+        epi.mul_by = mul_by.data_ptr() if mul_by is not None else None
+        epi.row_scale = row_scale.data_ptr() if row_scale is not None else None
+        epi.rows_per_scale = int(rows_per_scale)
+        epi.residual = residual.data_ptr() if residual is not None else None
+        epi.ldr = residual.shape[1] if residual is not None else 0
+        epi_ref = ctypes.byref(epi)
     check(lib.ap_gemm_nt(a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1], out.data_ptr(), ldc, M, n, k,
-                         ctypes.byref(epi), _stream()), "ap_gemm_nt")
+                         epi_ref, _stream()), "ap_gemm_nt")
     return out
 
 
