@@ -78,6 +78,7 @@ _SIGNATURES = {
     "ap_row_scale": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "ap_add_bcast": (_I, [_P, _P, _P, _L, _L, _P]),
     "ap_sum_reps_acc": (_I, [_P, _L, _L, _I, _P]),
+    "ap_resample_grid": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ap_bn_relu_workspace": (ctypes.c_size_t, [_L, _I]),
     "ap_bn_relu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, _P]),
     "ap_bn_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, _P]),

@@ -64,6 +64,33 @@ __global__ void k_row_scale(const bf16_t* __restrict__ x, const float* __restric
         st16(y + 8 * i, pack8(f));
     }
 }
+// out[oy, ox, c] (+)= sum_iy wy[oy, iy] * sum_ix wx[ox, ix] * in[iy, ix, c]: a separable resampling of a small fp32 NHWC grid by dense tap
+// matrices -- the bicubic interpolation of the position embedding (reference models/volo.py:580-596: F.interpolate(mode="bicubic") of
+// a [1, C, h, w] grid on EVERY forward at a resolution other than the model's) and, with the transposed matrices and acc = 1, its backward
+// into the embedding's gradient.  A tap row has at most four non-zeros (clamped border taps coincide): zeros are skipped, so a thread
+// does <= 16 multiply-adds.  (torch's upsample_bicubic2d and its backward took 80 us EACH on these 8 x 8 ... 14 x 14 grids: 10 % of an
+// AutoProg stage-1 step.)
+__global__ void __launch_bounds__(256)
+k_resample_grid(const float* __restrict__ in, int hi, int wi, const float* __restrict__ wy, const float* __restrict__ wx,
+                float* __restrict__ out, int ho, int wo, int C, int acc) {
+    const int64_t total = (int64_t)ho * wo * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const int ox = (int)((idx / C) % wo), oy = (int)(idx / ((int64_t)C * wo));
+        float s = 0.f;
+        for (int iy = 0; iy < hi; ++iy) {
+            const float a = wy[oy * hi + iy];
+            if (a == 0.f) continue;
+            float r = 0.f;
+            for (int ix = 0; ix < wi; ++ix) {
+                const float b = wx[ox * wi + ix];
+                if (b != 0.f) r = fmaf(b, in[((int64_t)iy * wi + ix) * C + c], r);
+            }
+            s = fmaf(a, r, s);
+        }
+        out[idx] = acc ? out[idx] + s : s;
+    }
+}
 __global__ void k_add_bcast(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
                             int64_t nv, int64_t bv) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -480,6 +507,15 @@ int ap_add_bcast(const ap_bf16* a, const ap_bf16* b, ap_bf16* y, int64_t n, int6
     if (n == 0) return AP_OK;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_add_bcast, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, a, b, y, n / 8, b_elems / 8);
+    return ap_check_launch();
+}
+int ap_resample_grid(const float* in, int hi, int wi, const float* wy, const float* wx, float* out, int ho, int wo, int C, int accumulate,
+                     ap_stream_t stream) {
+    if (!in || !wy || !wx || !out) return AP_ERR_NULL;
+    if (hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0 || C <= 0 || in == out) return AP_ERR_SHAPE;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_resample_grid, dim3(grid_for((int64_t)ho * wo * C)), dim3(256), 0, (hipStream_t)stream, in, hi, wi, wy, wx, out, ho, wo, C,
+                       accumulate ? 1 : 0);
     return ap_check_launch();
 }
 int ap_sum_reps_acc(const ap_bf16* x, float* out, int64_t n, int reps, ap_stream_t stream) {

@@ -811,6 +811,67 @@ class MixSwapFn(torch.autograd.Function):
         return ops.mix_token_swap(dy.contiguous(), *ctx.box), None, None, None, None
 
 
+_BICUBIC_TAPS = {}
+
+
+def bicubic_tap_matrix(n_in, n_out, scale_factor):
+    """dense [n_out, n_in] fp32 matrix of torch.nn.functional.interpolate(..., scale_factor=s, mode="bicubic", align_corners=False) along one
+    axis, in the arithmetic of aten's upsample_bicubic2d: source coordinate (o + 0.5) / s - 0.5 (the GIVEN scale factor, not n_out / n_in:
+    the reference passes (h0 + 0.1) / h, models/volo.py:590-594), cubic convolution with A = -0.75, source indices clamped to the grid."""
+    import numpy as np
+    f32 = np.float32
+    A = f32(-0.75)
+    r = f32(1.0 / float(scale_factor))
+    W = np.zeros((n_out, n_in), dtype=np.float32)
+
+    def conv1(x):            # |x| <= 1
+        return ((A + f32(2)) * x - (A + f32(3))) * x * x + f32(1)
+
+    def conv2(x):            # 1 < |x| < 2
+        return ((A * x - f32(5) * A) * x + f32(8) * A) * x - f32(4) * A
+    for o in range(n_out):
+        real = r * (f32(o) + f32(0.5)) - f32(0.5)
+        i0 = int(np.floor(real))
+        t = f32(real - f32(i0))
+        coeff = (conv2(t + f32(1)), conv1(t), conv1(f32(1) - t), conv2(f32(2) - t))
+        for k in range(4):
+            W[o, min(max(i0 - 1 + k, 0), n_in - 1)] += coeff[k]
+    return W
+
+
+def _pos_taps(h, w, h0, w0, device):
+    key = (h, w, h0, w0, str(device))
+    ent = _BICUBIC_TAPS.get(key)
+    if ent is None:
+        wy = torch.from_numpy(bicubic_tap_matrix(h, h0, (h0 + 0.1) / h))
+        wx = torch.from_numpy(bicubic_tap_matrix(w, w0, (w0 + 0.1) / w))
+        ent = tuple(t.to(device).contiguous() for t in (wy, wx, wy.t().contiguous(), wx.t().contiguous()))
+        _BICUBIC_TAPS[key] = ent
+    return ent
+
+
+class PosEmbedInterpFn(torch.autograd.Function):
+    """VOLO.interpolate_pos_encoding (models/volo.py:580-596): pos_embed [1, h, w, C] -> [1, h0, w0, C] by bicubic interpolation, as one
+    small HIP kernel per direction on the embedding's own NHWC layout (ops.resample_grid with the tap matrices of the torch call; the
+    backward multiplies by their transposes and adds straight into the parameter's gradient)."""
+
+    @staticmethod
+    def forward(ctx, pos, h0, w0):
+        _, h, w, C = pos.shape
+        wy, wx, wyt, wxt = _pos_taps(h, w, h0, w0, pos.device)
+        ctx.save_for_backward(pos, wyt, wxt)
+        return ops.resample_grid(pos.detach().reshape(h, w, C).contiguous(), wy, wx).view(1, h0, w0, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, wyt, wxt = ctx.saved_tensors
+        _, h0, w0, C = g.shape
+        bufs, sunk = _param_grad_buffers((pos,))
+        ops.resample_grid(g.reshape(h0, w0, C).contiguous().float(), wyt, wxt, out=bufs[0].view(pos.shape[1], pos.shape[2], C), accumulate=True)
+        (dp,) = _finish_param_grads((pos,), bufs, sunk)
+        return dp, None, None
+
+
 class AddPosFn(torch.autograd.Function):
     """x [B,h,w,C] bf16 + pos [1,h,w,C] fp32 (models/volo.py:627-629)."""
 

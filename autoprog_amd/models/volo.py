@@ -573,6 +573,9 @@ class VOLO(nn.Module):
         h, w = self.pos_embed.shape[1], self.pos_embed.shape[2]
         if h == h0 and w == w0:
             return self.pos_embed
+        if self.pos_embed.is_cuda and self.pos_embed.dtype == torch.float32:
+            # the same bicubic taps as F.interpolate(scale_factor=((h0 + 0.1) / h, (w0 + 0.1) / w)), one small HIP kernel per direction
+            return AF.PosEmbedInterpFn.apply(self.pos_embed, h0, w0)
         pos = F.interpolate(self.pos_embed.permute(0, 3, 1, 2), scale_factor=((h0 + 0.1) / h, (w0 + 0.1) / w), mode="bicubic")
         assert int(w0 + 0.1) == pos.shape[-1] and int(h0 + 0.1) == pos.shape[-2]
         return pos.permute(0, 2, 3, 1)

@@ -529,6 +529,24 @@ def add_bcast(a, b):
     return y
 
 
+def resample_grid(x, wy, wx, out=None, accumulate=False):
+    """x fp32 [hi, wi, C], wy fp32 [ho, hi], wx fp32 [wo, wi] -> out fp32 [ho, wo, C] (+)= the separable resampling (ap_resample_grid)"""
+    _req(x, torch.float32, "x"); _req(wy, torch.float32, "wy"); _req(wx, torch.float32, "wx")
+    hi, wi, C = x.shape
+    ho, wo = wy.shape[0], wx.shape[0]
+    if wy.shape[1] != hi or wx.shape[1] != wi:
+        raise AutoProgHipError("resample_grid: tap matrices do not match the grid")
+    if out is None:
+        out = torch.empty((ho, wo, C), dtype=torch.float32, device=x.device)
+    else:
+        _req(out, torch.float32, "out")
+        if out.numel() != ho * wo * C:
+            raise AutoProgHipError("resample_grid: output shape")
+    check(lib.ap_resample_grid(x.data_ptr(), hi, wi, wy.data_ptr(), wx.data_ptr(), out.data_ptr(), ho, wo, C, 1 if accumulate else 0, _stream()),
+          "ap_resample_grid")
+    return out
+
+
 def sum_reps_acc(x, out, reps):
     _req(x, BF16, "x"); _req(out, torch.float32, "out")
     check(lib.ap_sum_reps_acc(x.data_ptr(), out.data_ptr(), out.numel(), int(reps), _stream()), "ap_sum_reps_acc")

@@ -249,6 +249,12 @@ int ap_row_scale(const ap_bf16* x, const float* scale, ap_bf16* y, int64_t M, in
 int ap_add_bcast(const ap_bf16* a, const ap_bf16* b, ap_bf16* y, int64_t n, int64_t b_elems, ap_stream_t stream);
 /* out[i] += sum over reps of x[r*n + i]  (fp32 accumulate; gradient of a broadcast add) */
 int ap_sum_reps_acc(const ap_bf16* x, float* out, int64_t n, int reps, ap_stream_t stream);
+/* out[oy, ox, c] (+)= sum_iy wy[oy*hi + iy] * sum_ix wx[ox*wi + ix] * in[(iy*wi + ix)*C + c]   (fp32 NHWC grids, dense tap matrices wy [ho, hi],
+ * wx [wo, wi]): VOLO.interpolate_pos_encoding (models/volo.py:580-596 -- F.interpolate(pos_embed, scale_factor, mode="bicubic") on every
+ * forward whose token grid differs from the embedding's) with the bicubic taps of that call as the matrices; with the transposed
+ * matrices and accumulate = 1 its backward, added into the embedding's gradient.  (ABI version 5) */
+int ap_resample_grid(const float* in, int hi, int wi, const float* wy, const float* wx, float* out, int ho, int wo, int C, int accumulate,
+                     ap_stream_t stream);
 
 /* ---- fused BatchNorm2d + ReLU of the conv stem on NHWC bf16 rows [T = B*H*W, C] (models/volo.py:355-367;
  * SURVEY.md row N3).  training != 0: batch statistics (biased variance), running stats updated with

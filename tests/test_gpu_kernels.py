@@ -616,6 +616,35 @@ def test_experimental_kernel_paths_stay_parity_green(env):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
 
 
+@pytest.mark.parametrize("h,w,h0,w0,C", [(14, 14, 8, 8, 384), (14, 14, 10, 10, 384), (14, 14, 12, 12, 384), (14, 14, 20, 17, 64), (28, 28, 14, 14, 768), (7, 9, 9, 5, 40)])
+def test_pos_embed_bicubic_interpolation_vs_torch(ops, h, w, h0, w0, C):
+    """functional.PosEmbedInterpFn / ap_resample_grid (VOLO.interpolate_pos_encoding, models/volo.py:580-596) against autograd through
+    torch.nn.functional.interpolate(..., mode="bicubic") in fp64 on the CPU: interpolated grid and the gradient of the embedding"""
+    import torch.nn.functional as F
+    from autoprog_amd import functional as AF
+    g = torch.Generator().manual_seed(h * 100 + h0)
+    pos = torch.randn(1, h, w, C, generator=g)
+    dy = torch.randn(1, h0, w0, C, generator=g)
+    p64 = pos.double().requires_grad_(True)
+    ref = F.interpolate(p64.permute(0, 3, 1, 2), scale_factor=((h0 + 0.1) / h, (w0 + 0.1) / w), mode="bicubic").permute(0, 2, 3, 1)
+    ref.backward(dy.double())
+    pg = pos.cuda().requires_grad_(True)
+    out = AF.PosEmbedInterpFn.apply(pg, h0, w0)
+    assert out.shape == (1, h0, w0, C) and out.dtype == torch.float32
+    out.backward(dy.cuda())
+    assert rel(out, ref.detach()) < 1e-5, rel(out, ref.detach())
+    assert rel(pg.grad, p64.grad) < 1e-5, rel(pg.grad, p64.grad)
+    # accumulate = 1 adds to what is there; raw-ABI argument checks
+    before = pg.grad.clone()
+    out2 = AF.PosEmbedInterpFn.apply(pg, h0, w0)
+    out2.backward(dy.cuda())
+    assert rel(pg.grad, 2 * before.cpu()) < 1e-6
+    from autoprog_amd._lib import lib
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.ap_resample_grid(None, h, w, None, None, None, h0, w0, C, 0, st) == -4
+    assert lib.ap_resample_grid(out.data_ptr(), 0, w, out.data_ptr(), out.data_ptr(), pg.data_ptr(), h0, w0, C, 0, st) == -1
+
+
 def test_c_abi_error_codes_and_empty_inputs(ops):
     """the raw C ABI: negative codes instead of exceptions or crashes for null pointers (-4), shape / stride violations (-1),
     configurations the gfx950 kernels do not cover (-2); empty problems are accepted where the header says so"""

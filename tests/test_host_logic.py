@@ -181,3 +181,22 @@ def test_driver_batch_splits_follow_the_reference_rule():
         assert drv.splits_for(l, r) == reference(4, (l * r * r) / (12 * 224 * 224)), (l, r)
     assert drv.splits_for(12, 224) == 4 and drv.splits_for(6, 128) == 1
     assert AutoProgDriver(None, None, None, None, None, [64], [3], [0.0], [0], 1).splits_for(3, 64) == 1      # default: no splits
+
+
+def test_bicubic_tap_matrices_equal_torch_interpolate():
+    """functional.bicubic_tap_matrix (the tap matrices ap_resample_grid multiplies the position embedding by) against
+    torch.nn.functional.interpolate(scale_factor=(h0 + 0.1) / h, mode="bicubic") -- the call of VOLO.interpolate_pos_encoding
+    (models/volo.py:580-596) -- down- and upsampling, square and not: float32-level agreement with the fp64 and the fp32 torch result"""
+    import torch.nn.functional as F
+    from autoprog_amd.functional import bicubic_tap_matrix
+    g = torch.Generator().manual_seed(0)
+    for (h, h0) in [(14, 8), (14, 10), (14, 12), (14, 14), (14, 20), (14, 28), (28, 14), (7, 9), (12, 5)]:
+        for (w, w0) in [(14, 8), (14, 12), (14, 21), (9, 14)]:
+            pos = torch.randn(1, 6, h, w, dtype=torch.float64, generator=g)
+            ref = F.interpolate(pos, scale_factor=((h0 + 0.1) / h, (w0 + 0.1) / w), mode="bicubic")
+            assert tuple(ref.shape[-2:]) == (h0, w0)
+            wy = torch.from_numpy(bicubic_tap_matrix(h, h0, (h0 + 0.1) / h)).double()
+            wx = torch.from_numpy(bicubic_tap_matrix(w, w0, (w0 + 0.1) / w)).double()
+            assert wy.shape == (h0, h) and int((wy != 0).sum(1).max()) <= 4
+            got = torch.einsum("oi,pj,ncij->ncop", wy, wx, pos)
+            assert float((got - ref).abs().max() / ref.abs().max()) < 5e-6, (h, h0, w, w0)
