@@ -810,7 +810,18 @@ static int use_8p(int M, int N, int K, int ldc, const EpiArgs& ep) {          //
     if (mode == 0 || (K & 63) || K < 128 || M < 4096 || (N & 7) || (ldc & 7) || (ep.residual && (ep.ldr & 7))) return 0;
     if (ep.dgelu_of && (mode < 2 || ep.residual)) return 0;
     if (ep.mul_by && ep.residual) return 0;
-    const int bn = N >= 1024 ? 256 : (N % 192 == 0 ? 192 : (N % 256 == 0 ? 256 : 0));
+    int bn = N >= 1024 ? 256 : (N % 192 == 0 ? 192 : (N % 256 == 0 ? 256 : 0));
+    if (N >= 1024 && N % 192 == 0) {
+        // both widths tile N: the persistent grid walks ceil(tiles / #CU) rounds of tiles, a 256-wide tile costs ~1.3 of a 192-wide one.
+        // N = 1152 (4.5 -> 5 column tiles of 256): 25088 rows 2 x 1.3 against 3 rounds -> 256; the AutoProg stages' 8192 / 18432 rows
+        // (128 / 192 px) one round against one, two against two -> 192 (12.2 against 13.8 us, 21.3 against 25.5); 12800 rows (160 px) one
+        // round of 250 tiles against two of 300 -> 256 (16.3 against 21.5): tools/sweep_nt.py, AP_GEMM_NT_TILE = 20 / 21.
+        static int ncu = 0;
+        if (ncu == 0) { hipDeviceProp_t pr; int dev = 0; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+        const int64_t mt = (M + 255) / 256;
+        const int64_t r192 = (mt * (N / 192) + ncu - 1) / ncu, r256 = (mt * ((N + 255) / 256) + ncu - 1) / ncu;
+        if (r192 * 10 < r256 * 13) bn = 192;
+    }
     return N < 192 ? 0 : bn;
 }
 
