@@ -117,6 +117,10 @@ class VisionTransformer(nn.Module):
         if g == g0:
             return self.pos_embed
         D = self.pos_embed.shape[-1]
+        if self.pos_embed.is_cuda and self.pos_embed.dtype == torch.float32:
+            # the same bicubic taps on the HIP resampling kernel (functional.PosEmbedInterpFn), forward and backward
+            grid = AF.PosEmbedInterpFn.apply(self.pos_embed[:, n_extra:].reshape(1, g0, g0, D), g, g)
+            return torch.cat([self.pos_embed[:, :n_extra], grid.reshape(1, g * g, D)], dim=1)
         grid = self.pos_embed[:, n_extra:].reshape(1, g0, g0, D).permute(0, 3, 1, 2)
         grid = F.interpolate(grid, scale_factor=((g + 0.1) / g0, (g + 0.1) / g0), mode="bicubic")
         assert grid.shape[-1] == g and grid.shape[-2] == g
