@@ -198,7 +198,11 @@ class wgrad_batch:
 # param.grad in place, and the sink hears param_ready() at the flush instead of at the end of the block.
 # AP_WGRAD_WINDOW: tiles per launch (0 = one launch per block, the behaviour before).
 WGRAD_WINDOW = int(os.environ.get("AP_WGRAD_WINDOW", "256"))
-_window = {"problems": [], "ln": [], "params": [], "tiles": 0, "armed": None, "outs": set()}
+# The window holds UNITS -- one weight-gradient problem or one LayerNorm rider each, with the parameters whose gradient that unit
+# completes -- and launches the longest prefix that fits the tile kernel's table (WGRAD_WINDOW tiles = one per CU): a launch ends in
+# the middle of a block when that fills it.  VOLO-D5's blocks are 64 + 64 + 16 + 48 = 192 tiles: a block per launch left a quarter of
+# the chip idle, block-and-a-third launches fill it (three launches of 256 for four blocks); D1's 40-tile blocks pack 252 instead of 240.
+_window = {"units": [], "tiles": 0, "armed": None, "outs": set()}
 
 # Two private hooks of the autograd engine make the window self-flushing: queue_callback (run at the end of the backward pass the
 # caller is inside) and _current_graph_task_id (which backward pass that is).  Both are probed once; without them the window still
@@ -217,17 +221,31 @@ def _tiles_192(prob):
     return (n1 // 192) * (n2 // 192)
 
 
-def _window_outputs(problems, ln):
-    """addresses a launch of these problems writes: weight / bias gradients and the LayerNorm dgamma / dbeta rows"""
-    outs = set()
+def _window_units(problems, ln, params):
+    """the block's problems and LayerNorm riders as units [kind, item, tiles, parameters completed, addresses written]"""
+    owner = {}
+    for p in params:
+        if p is not None and p.grad is not None:
+            owner.setdefault(p.grad.data_ptr(), []).append(p)
+    units, claimed = [], set()
+
+    def take(ptrs):
+        ps = []
+        for a in ptrs:
+            for p in owner.get(a, ()):
+                if id(p) not in claimed:
+                    claimed.add(id(p))
+                    ps.append(p)
+        return ps
     for q in problems:
-        outs.add(q[2].data_ptr())
-        if q[5] is not None:
-            outs.add(q[5].data_ptr())
-    for (_ws, _n, _c, dgamma, dbeta) in ln:
-        outs.add(dgamma.data_ptr())
-        outs.add(dbeta.data_ptr())
-    return outs
+        ptrs = [q[2].data_ptr()] + ([q[5].data_ptr()] if q[5] is not None else [])
+        units.append(["p", q, _tiles_192(q), take(ptrs), set(ptrs)])
+    for item in ln:
+        ptrs = [item[3].data_ptr(), item[4].data_ptr()]
+        units.append(["l", item, 0, take(ptrs), set(ptrs)])
+    if units:                         # a parameter no unit writes (there is none in the shipped blocks) leaves with the block's last unit
+        units[-1][3] += [p for p in params if p is not None and id(p) not in claimed]
+    return units
 
 
 def _window_add(problems, ln, params):
@@ -250,41 +268,73 @@ def _window_add(problems, ln, params):
             except RuntimeError:
                 return False
         w["armed"] = gid
-    tiles = sum(_tiles_192(q) for q in problems)
-    outs = _window_outputs(problems, ln)
+    units = _window_units(problems, ln, params)
+    outs = set()
+    for u in units:
+        outs |= u[4]
     # a parameter that is ALREADY in the window (a block applied twice before one backward, shared weights): its LayerNorm riders
     # add with plain read-modify-writes and tn8_plan only sees duplicates inside one call -- launch what is held first, so the
     # two uses are ordered by the stream like the one-launch-per-block path orders them.
-    if w["problems"] and (w["tiles"] + tiles > WGRAD_WINDOW or len(w["problems"]) + len(problems) > TN_MAX_GROUP
-                          or len(w["ln"]) + len(ln) > LN_MAX_BATCH or (outs & w["outs"])):
+    if w["units"] and (outs & w["outs"]):
         _window_launch()
     if hasattr(_grad_sink, "hold"):
         _grad_sink.hold(params)       # (autograd fires their post-accumulate hooks when the block's backward returns)
-    w["problems"] += problems
-    w["ln"] += ln
-    w["params"] += [p for p in params if p is not None]
-    w["tiles"] += tiles
+    w["units"] += units
+    w["tiles"] += sum(u[2] for u in units)
     w["outs"] |= outs
+    while w["tiles"] >= WGRAD_WINDOW or _window_counts_full(TN_MAX_GROUP, LN_MAX_BATCH):
+        _window_launch_prefix()       # a full table's worth is there: it leaves, the rest of the block waits for the next one
     # data parallel: when everything a gradient bucket still waits for sits in this window, launching now lets the bucket's
     # all-reduce start under the rest of the backward pass (only once the launch is at least 60 % of a full window: a short
     # launch cuts its problems along the token axis again)
     if (w["tiles"] * 10 >= WGRAD_WINDOW * 6 and hasattr(_grad_sink, "completes_a_bucket") and _grad_sink.needs_stream_join()
-            and _grad_sink.completes_a_bucket(w["params"])):
+            and _grad_sink.completes_a_bucket([p for u in w["units"] for p in u[3]])):
         _window_launch()
     return True
 
 
-def _window_launch():
+def _window_counts_full(max_problems, max_ln):
+    """more problems / riders held than ONE launch takes: a prefix has to go whatever its tile count"""
+    u = _window["units"]
+    return sum(1 for x in u if x[0] == "p") > max_problems or sum(1 for x in u if x[0] == "l") > max_ln
+
+
+def _window_launch_prefix():
+    """launch the longest prefix of the held units that one launch of the tile kernel takes: at most WGRAD_WINDOW tiles (at least one
+    unit), TN_MAX_GROUP problems, LN_MAX_BATCH riders; the parameters those units complete are handed to the gradient sink"""
+    from ._lib import TN_MAX_GROUP, LN_MAX_BATCH
     w = _window
-    problems, ln, params = w["problems"], w["ln"], w["params"]
-    w["problems"], w["ln"], w["params"], w["tiles"], w["outs"] = [], [], [], 0, set()
+    units = w["units"]
+    n = tiles = nprob = nln = 0
+    while n < len(units):
+        kind, _item, t = units[n][0], units[n][1], units[n][2]
+        if n and (tiles + t > WGRAD_WINDOW or (kind == "p" and nprob == TN_MAX_GROUP) or (kind == "l" and nln == LN_MAX_BATCH)):
+            break
+        tiles += t
+        nprob += kind == "p"
+        nln += kind == "l"
+        n += 1
+    taken, w["units"] = units[:n], units[n:]
+    w["tiles"] -= tiles
+    w["outs"] = set()
+    for u in w["units"]:
+        w["outs"] |= u[4]
+    problems = [u[1] for u in taken if u[0] == "p"]
+    ln = [u[1] for u in taken if u[0] == "l"]
     if problems:
         ops.gemm_tn_acc_grouped(problems, ln=ln)
     elif ln:
         ops.layernorm_bwd_reduce_batched(ln)
     if _grad_sink is not None:
-        for p in params:
-            _grad_sink.param_ready(p)
+        for u in taken:
+            for p in u[3]:
+                _grad_sink.param_ready(p)
+
+
+def _window_launch():
+    """everything the window holds, in as many launches as it takes"""
+    while _window["units"]:
+        _window_launch_prefix()
 
 
 def flush_wgrad_window():
@@ -295,7 +345,7 @@ def flush_wgrad_window():
 
 def reset_wgrad_window():
     """drop what a backward pass that raised left behind"""
-    _window.update(problems=[], ln=[], params=[], tiles=0, armed=None, outs=set())
+    _window.update(units=[], tiles=0, armed=None, outs=set())
 
 
 fuse_ln_reduce = os.environ.get("AP_FUSE_LN_REDUCE", "1") != "0"

@@ -410,7 +410,7 @@ def _window_worker(rank, world, port, q):
             raise AssertionError("backward did not raise")
         except RuntimeError as e:
             assert "boom" in str(e)
-        assert AF._window["problems"], "the failed pass should have left its problems in the window"
+        assert AF._window["units"], "the failed pass should have left its problems in the window"
         log = run()
         for a, b in zip([p.grad for p in params], reference()):
             assert torch.allclose(a, b, rtol=2e-2, atol=2e-4), (rank, "after a failed pass")

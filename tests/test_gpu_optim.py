@@ -347,7 +347,7 @@ def test_weight_gradient_window_matches_one_launch_per_block(monkeypatch):
             launches = [c for c in calls if c[0] > 1]
             if window:
                 assert len(launches) < n_block_launches and sum(c[0] for c in calls) == n_problems and sum(c[1] for c in calls) == n_ln
-                assert not AF._window["problems"] and not AF._window["armed"]
+                assert not AF._window["units"] and not AF._window["armed"]
             else:
                 n_block_launches, n_problems, n_ln = len(launches), sum(c[0] for c in calls), sum(c[1] for c in calls)
                 assert n_block_launches >= 3
