@@ -811,7 +811,7 @@ static int use_8p(int M, int N, int K, int ldc, const EpiArgs& ep) {          //
     if (ep.dgelu_of && (mode < 2 || ep.residual)) return 0;
     if (ep.mul_by && ep.residual) return 0;
     int bn = N >= 1024 ? 256 : (N % 192 == 0 ? 192 : (N % 256 == 0 ? 256 : 0));
-    if (N >= 1024 && N % 192 == 0) {
+    if (N >= 384 && N % 192 == 0) {
         // both widths tile N: the persistent grid walks ceil(tiles / #CU) rounds of tiles, a 256-wide tile costs ~1.3 of a 192-wide one.
         // N = 1152 (4.5 -> 5 column tiles of 256): 25088 rows 2 x 1.3 against 3 rounds -> 256; the AutoProg stages' 8192 / 18432 rows
         // (128 / 192 px) one round against one, two against two -> 192 (12.2 against 13.8 us, 21.3 against 25.5); 12800 rows (160 px) one
@@ -820,7 +820,9 @@ static int use_8p(int M, int N, int K, int ldc, const EpiArgs& ep) {          //
         if (ncu == 0) { hipDeviceProp_t pr; int dev = 0; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
         const int64_t mt = (M + 255) / 256;
         const int64_t r192 = (mt * (N / 192) + ncu - 1) / ncu, r256 = (mt * ((N + 255) / 256) + ncu - 1) / ncu;
-        if (r192 * 10 < r256 * 13) bn = 192;
+        bn = (r192 * 10 < r256 * 13) ? 192 : 256;
+        // (N = 768, the D5 widths, at 50176 rows = batch 64: 784 tiles of 192 are 3.06 -> FOUR rounds, 588 of 256 three: 64.2 against 67.1 us
+        // at K = 768, 231 against 241 - 257 at K = 3072; at 48608 rows three rounds of 192: 54.0 against 63.1.  N = 384 / 576 stay on 192.)
     }
     return N < 192 ? 0 : bn;
 }

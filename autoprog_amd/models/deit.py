@@ -117,7 +117,7 @@ class VisionTransformer(nn.Module):
         if g == g0:
             return self.pos_embed
         D = self.pos_embed.shape[-1]
-        if self.pos_embed.is_cuda and self.pos_embed.dtype == torch.float32:
+        if self.pos_embed.is_cuda and self.pos_embed.dtype == torch.float32 and max(g, g0) <= 64:
             # the same bicubic taps on the HIP resampling kernel (functional.PosEmbedInterpFn), forward and backward
             grid = AF.PosEmbedInterpFn.apply(self.pos_embed[:, n_extra:].reshape(1, g0, g0, D), g, g)
             return torch.cat([self.pos_embed[:, :n_extra], grid.reshape(1, g * g, D)], dim=1)

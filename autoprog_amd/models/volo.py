@@ -573,7 +573,7 @@ class VOLO(nn.Module):
         h, w = self.pos_embed.shape[1], self.pos_embed.shape[2]
         if h == h0 and w == w0:
             return self.pos_embed
-        if self.pos_embed.is_cuda and self.pos_embed.dtype == torch.float32:
+        if self.pos_embed.is_cuda and self.pos_embed.dtype == torch.float32 and max(h, w, h0, w0) <= 64:
             # the same bicubic taps as F.interpolate(scale_factor=((h0 + 0.1) / h, (w0 + 0.1) / w)), one small HIP kernel per direction
             return AF.PosEmbedInterpFn.apply(self.pos_embed, h0, w0)
         pos = F.interpolate(self.pos_embed.permute(0, 3, 1, 2), scale_factor=((h0 + 0.1) / h, (w0 + 0.1) / w), mode="bicubic")

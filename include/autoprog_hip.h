@@ -252,7 +252,7 @@ int ap_sum_reps_acc(const ap_bf16* x, float* out, int64_t n, int reps, ap_stream
 /* out[oy, ox, c] (+)= sum_iy wy[oy*hi + iy] * sum_ix wx[ox*wi + ix] * in[(iy*wi + ix)*C + c]   (fp32 NHWC grids, dense tap matrices wy [ho, hi],
  * wx [wo, wi]): VOLO.interpolate_pos_encoding (models/volo.py:580-596 -- F.interpolate(pos_embed, scale_factor, mode="bicubic") on every
  * forward whose token grid differs from the embedding's) with the bicubic taps of that call as the matrices; with the transposed
- * matrices and accumulate = 1 its backward, added into the embedding's gradient.  (ABI version 5) */
+ * matrices and accumulate = 1 its backward, added into the embedding's gradient.  hi, wi <= 64 (AP_ERR_UNSUPPORTED beyond).  (ABI version 5) */
 int ap_resample_grid(const float* in, int hi, int wi, const float* wy, const float* wx, float* out, int ho, int wo, int C, int accumulate,
                      ap_stream_t stream);
 
