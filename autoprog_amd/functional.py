@@ -1133,7 +1133,9 @@ class PatchConvFn(torch.autograd.Function):
         xc = x.contiguous()
         B, H, W, C = xc.shape
         N = weight.shape[0]
-        wmat = weight.detach().permute(0, 2, 3, 1).reshape(N, k * k * C).to(BF16)            # columns ordered (dy, dx, c)
+        wmat = torch.empty((N, k, k, C), dtype=BF16, device=weight.device)
+        wmat.copy_(weight.detach().permute(0, 2, 3, 1))                                      # re-layout + cast in ONE copy kernel
+        wmat = wmat.view(N, k * k * C)                                                       # columns ordered (dy, dx, c)
         y = ops.gemm_nt_patch_fwd(xc, wmat, bias, k)
         ctx.save_for_backward(xc, weight, bias, wmat)
         ctx.k = k
