@@ -4,10 +4,11 @@
 //
 // Forward is an implicit GEMM: M = B*H*W pixels, N = 64 output channels, K = 9 taps x 64 input channels, with NO im2col
 // buffer -- a tap is an address offset into the input patch held in LDS.
-//   workgroup   : 256 threads (4 waves), PERSISTENT over the 32 x 16 pixel output tiles of the batch
+//   workgroup   : 512 threads (8 waves: two per SIMD; the 4-wave shape of rounds 2 - 3 described below is NW = 4, AP_CONV_WAVES=4),
+//                 PERSISTENT over the 32 x 16 pixel output tiles of the batch
 //   LDS         : all 9 x 64 x 64 weights (72 KB, loaded once per workgroup) + the 34 x 18 pixel input patch of the
 //                 current tile (76.5 KB); 16-byte chunks XOR-swizzled so that the MFMA fragment reads are conflict free
-//   wave        : tile rows w, w+4, ... (8 rows of 16 pixels) x all 64 output channels: 8 x 4 accumulator tiles; per
+//   wave        : (NW = 4) tile rows w, w+4, ... (8 rows of 16 pixels) x all 64 output channels: 8 x 4 accumulator tiles; per
 //                 (tap, 32-channel K step) it reads 4 weight fragments + 8 pixel fragments for 32 MFMAs (96 B/clk of LDS
 //                 traffic per CU at full MFMA rate, against a 128 B/clk LDS)
 //   pipelining  : the next tile's patch is loaded into registers (20 x 16 B per thread) before the current tile is
@@ -76,10 +77,17 @@ __device__ __forceinline__ u32x4 bn_in_apply(const u32x4& v, const float* sc, co
 // and stores chunk s of the PREVIOUS tile's output (16 chunks per thread, kept packed in registers) -- with one workgroup per
 // CU, a load phase, a compute phase and a store phase of their own would run one after the other on every CU at once
 // (measured: 151 us with the phases apart, 84 us for the MFMAs alone).
-template <bool STATS, int ABL = 0, bool PRE_BN = false>
-__global__ void __launch_bounds__(256)
+//
+// NW = waves per workgroup (4 or 8; AP_CONV_WAVES).  With four waves a SIMD holds ONE wave: every LDS wait, every address computation
+// and every barrier of that wave leaves the SIMD's matrix pipe idle.  Eight waves (two per SIMD, 256 registers each -- the budget of
+// a wave does not shrink) take tile rows w, w + 8, ...: 4 x 4 accumulator tiles, half the staging and output registers per wave, the
+// weight fragments read by twice as many waves (0.5 instead of 0.375 KB of LDS reads per MFMA).
+template <bool STATS, int ABL = 0, bool PRE_BN = false, int NW = 4>
+__global__ void __launch_bounds__(64 * NW)
 k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_t* __restrict__ y, int H, int W,
               int tiles_x, int tiles_y, int ntiles, float* __restrict__ stats, BnIn bn = BnIn{nullptr, nullptr, nullptr, nullptr}) {
+    constexpr int NTH = 64 * NW, RPW = CV_TR / NW, NPRE = (CV_NCHUNK + NTH - 1) / NTH, PSTEP = NTH / 8;     // threads, tile rows per wave, patch chunks per thread, pixels per staging sweep
+    constexpr int NOUT = 2 * RPW, SL = NOUT / 4;                                                        // output chunks per lane; first step of the next tile's loads
     extern __shared__ __attribute__((aligned(16))) bf16_t cv_smem[];
     bf16_t* Wl = cv_smem;                       // [9][64 co][64 ci], chunk ^ key_b(co)
     bf16_t* P = cv_smem + CV_WELEMS;            // [612 px][64 ci + 8 pad]
@@ -94,7 +102,7 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
         wbase[q][0] = r * CV_C + ((g ^ key_b(r)) << 3);
         wbase[q][1] = r * CV_C + (((4 + g) ^ key_b(r)) << 3);
     }
-    for (int idx = tid; idx < CV_WELEMS / 8; idx += 256) {
+    for (int idx = tid; idx < CV_WELEMS / 8; idx += NTH) {
         const int row = idx >> 3, c = idx & 7;
         st16(Wl + row * CV_C + ((c ^ key_b(row & (CV_C - 1))) << 3), ld16(wp + (int64_t)idx * 8));
     }
@@ -105,7 +113,7 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
     };
     // patch chunk i of this thread: pixel (tid >> 3) + 32 i, chunk tid & 7 -- its position in the patch is the same for every
     // tile: one packed (py, px) word per chunk
-    u32x4 pre[CV_NPRE];
+    u32x4 pre[NPRE];
     const int c8 = (tid & 7) * 8;
     float bsc[8], bsh[8];                        // PRE_BN: scale / shift of this thread's 8 channels (its chunk index is the same for every chunk)
     if constexpr (PRE_BN) bn_in_consts(bn, c8, bsc, bsh);
@@ -115,13 +123,13 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
     // when the chunk is written to LDS: a predicated load (zero-initialise, then an exec-masked load into the same registers)
     // made the compiler drain vmcnt(0) in every step.
     auto pvalid = [&](int i, int ty0, int tx0) {
-        const int pix = tl + 32 * i;                                 // < 640
+        const int pix = tl + PSTEP * i;                              // < 640
         const int py = (pix * 3641) >> 16, px = pix - py * CV_PW;    // pix / 18 (exact below 1170)
         const unsigned gy = (unsigned)(ty0 - 1 + py), gx = (unsigned)(tx0 - 1 + px);
         return pix < CV_NPIX && gy < (unsigned)H && gx < (unsigned)W;
     };
     auto gload1 = [&](int i, const bf16_t* img, int ty0, int tx0) {
-        const int pix = tl + 32 * i;
+        const int pix = tl + PSTEP * i;
         const int py = (pix * 3641) >> 16, px = pix - py * CV_PW;
         const int gy = min(max(ty0 - 1 + py, 0), H - 1), gx = min(max(tx0 - 1 + px, 0), W - 1);
         pre[i] = ld16(img + (unsigned)((gy * W + gx) * CV_C + c8));  // uniform base + 32-bit lane offset
@@ -133,7 +141,7 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
 #pragma unroll
         for (int k = 0; k < 8; ++k) { ssum[pr][k] = 0.f; ssq[pr][k] = 0.f; }
 
-    u32x4 outp[16];                              // the previous tile's output, packed bf16: chunk 2 i + pr
+    u32x4 outp[NOUT];                            // the previous tile's output, packed bf16: chunk 2 i + pr
     const bf16_t* out_prev = nullptr;            // UNIFORM: the previous tile's first pixel; null: nothing pending
     int nrow_prev = 0;
     bool col_ok_prev = false;
@@ -141,7 +149,7 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
     auto store1 = [&](int s) {                   // chunk s = 2 i + pr of the pending output
         const int i = s >> 1, pr = s & 1;
         if (out_prev != nullptr && i < nrow_prev && col_ok_prev && (!(ABL & 1) || outp[s][0] == 0x12345678u))
-            st16(const_cast<bf16_t*>(out_prev) + ((int64_t)(4 * i) * W * CV_C + 32 * pr) + out_lane, outp[s]);
+            st16(const_cast<bf16_t*>(out_prev) + ((int64_t)(NW * i) * W * CV_C + 32 * pr) + out_lane, outp[s]);
     };
 
     int t = blockIdx.x;
@@ -150,16 +158,16 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
         tile_origin(t, b, ty0, tx0);
         const bf16_t* org = patch_org(b, ty0, tx0);
 #pragma unroll
-        for (int i = 0; i < CV_NPRE; ++i) gload1(i, org, ty0, tx0);
+        for (int i = 0; i < NPRE; ++i) gload1(i, org, ty0, tx0);
     }
     for (; t < ntiles; t += gridDim.x) {
         int bc, ty0c, tx0c;
         tile_origin(t, bc, ty0c, tx0c);
 #pragma unroll
-        for (int i = 0; i < CV_NPRE; ++i) {
-            const int idx = tid + 256 * i;
+        for (int i = 0; i < NPRE; ++i) {
+            const int idx = tid + NTH * i;
             if (idx < CV_NCHUNK && (!(ABL & 2) || t == (int)blockIdx.x))
-                st16(P + ((tid >> 3) + 32 * i) * CV_PSTR + c8, pvalid(i, ty0c, tx0c) ? (PRE_BN ? bn_in_apply(pre[i], bsc, bsh) : pre[i]) : zero4);
+                st16(P + ((tid >> 3) + PSTEP * i) * CV_PSTR + c8, pvalid(i, ty0c, tx0c) ? (PRE_BN ? bn_in_apply(pre[i], bsc, bsh) : pre[i]) : zero4);
         }
         __syncthreads();
         asm volatile("" : "+v"(tl));
@@ -171,13 +179,13 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
 
         int b, ty0, tx0;
         tile_origin(t, b, ty0, tx0);
-        f32x4 acc[8][4];
+        f32x4 acc[RPW][4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < RPW; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[i][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // rows of this wave: r = wave + 4 i; rows below the image are skipped (wave-uniform)
-        const int nrow = (H - ty0 - wave + 3) >> 2;                   // number of i with ty0 + wave + 4 i < H
+        // rows of this wave: r = wave + NW i; rows below the image are skipped (wave-uniform)
+        const int nrow = (H - ty0 - wave + NW - 1) / NW;              // number of i with ty0 + wave + NW i < H
         // fragments of one step: 4 weight fragments (double-buffered by hand) + 8 pixel fragments, each refilled for the next step
         // right behind the 4 MFMAs that read it (one wave per SIMD -- nothing else hides the LDS latency).  Kept as u32x4: bf16x8
         // values crossing the pipeline stages get legalised element-wise.  Every LDS address is a per-lane base + a constant.
@@ -189,34 +197,34 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
         auto aload = [&](u32x4& fa, int i, int s) {
             if ((ABL & 4) && s) return;
             const int tap = s >> 1, dy = tap / 3, dx = tap - 3 * dy;
-            fa = ld16(P + abase + (4 * i + dy) * CV_PW * CV_PSTR + dx * CV_PSTR + (s & 1) * 32);
+            fa = ld16(P + abase + (NW * i + dy) * CV_PW * CV_PSTR + dx * CV_PSTR + (s & 1) * 32);
         };
         // the memory work of step s.  Program order: the previous tile's 16 output chunks first (steps 0-3), then the 20 chunk
         // loads of the next tile (steps 4-8): vmcnt counts loads and stores in one in-order counter, so the wait for the loads at
         // the top of the next tile also covers everything issued before them -- stores issued AFTER a load would sit in front of
         // that wait -- and the last load still has ten steps (~3 us) to land.  (One load + one store in every step: 200 us.)
         auto side = [&](int s) {
-            if (s < 4) {
+            if (s < SL) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) store1(4 * s + k);
-            } else if (s < 9 && have_next) {
+            } else if (s < SL + (NPRE + 3) / 4 && have_next) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) gload1(4 * (s - 4) + k, orgn, ty0n, tx0n);
+                for (int k = 0; k < 4; ++k) if (4 * (s - SL) + k < NPRE) gload1(4 * (s - SL) + k, orgn, ty0n, tx0n);
             }
         };
         auto compute = [&](auto full) {
-            u32x4 fb[2][4], fa[8];
+            u32x4 fb[2][4], fa[RPW];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) fa[i] = zero4;
+            for (int i = 0; i < RPW; ++i) fa[i] = zero4;
             bload(fb[0], 0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) if (full.value || i < nrow) aload(fa[i], i, 0);
+            for (int i = 0; i < RPW; ++i) if (full.value || i < nrow) aload(fa[i], i, 0);
 #pragma unroll
             for (int s = 0; s < 18; ++s) {
                 if (s + 1 < 18) bload(fb[(s + 1) & 1], s + 1);
                 side(s);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < RPW; ++i) {
                     if (full.value || i < nrow) {
                         if (!(ABL & 8)) {
 #pragma unroll
@@ -229,13 +237,13 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
                 __builtin_amdgcn_sched_barrier(0);            // keep the hand-made pipeline: without fences the scheduler hoists
             }                                                 // dozens of LDS reads and spills (516 us instead of 170)
         };
-        if (nrow >= 8) compute(std::true_type{}); else compute(std::false_type{});
+        if (nrow >= RPW) compute(std::true_type{}); else compute(std::false_type{});
         // pack: lane (fr, g) holds, per fragment pair pr, channels 32 pr + 8 g .. +7 of pixel (row ty0 + wave + 4 i, column tx0 + fr)
         out_prev = y + (((int64_t)b * H + ty0) * W + tx0) * CV_C;
         nrow_prev = nrow;
         col_ok_prev = tx0 + fr < W;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < RPW; ++i) {
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
                 float v[8];
@@ -255,10 +263,10 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
         __syncthreads();                       // every wave is done with the patch before the next one overwrites it
     }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) store1(s);    // the last tile's output
+    for (int s = 0; s < NOUT; ++s) store1(s);  // the last tile's output
     if constexpr (STATS) {
         // lanes with the same g hold the same channels: butterfly over fr, then the 4 waves meet in LDS (the patch is free)
-        float* red = reinterpret_cast<float*>(P);                    // [4 waves][2][64]
+        float* red = reinterpret_cast<float*>(P);                    // [NW waves][2][64]
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
@@ -276,8 +284,12 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
                 }
         }
         __syncthreads();
-        if (tid < 2 * CV_C)                    // this workgroup's partial row [2][64]: plain store, summed (in fp64) by the BatchNorm finalize
-            stats[(int64_t)blockIdx.x * 2 * CV_C + tid] = red[tid] + red[2 * CV_C + tid] + red[4 * CV_C + tid] + red[6 * CV_C + tid];
+        if (tid < 2 * CV_C) {                  // this workgroup's partial row [2][64]: plain store, summed (in fp64) by the BatchNorm finalize
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += red[w * 2 * CV_C + tid];
+            stats[(int64_t)blockIdx.x * 2 * CV_C + tid] = t;
+        }
     }
 }
 
@@ -413,31 +425,36 @@ k_conv3x3_c64_wgrad(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
 // and the fragments of K step k+1 are read from LDS while the MFMAs of step k issue.  The two-workgroup kernel cannot afford either
 // next to its 144 accumulators and spends 74 % of its wave time waiting.  208 -> 151 us at B = 128, 112 x 112 (16-row tiles; 32-row
 // tiles spill and take 177); half the slabs, too.
-template <int TR, bool PRE_BN = false>
-__global__ void __launch_bounds__(256)
+// NW = 8 (AP_CONV_WAVES, the default): two waves per SIMD.  Wave (cg, ch) = (wave & 3, wave >> 2) takes input channels 16 cg .. +15 and
+// output channels 32 ch .. +31: 9 x 2 accumulator tiles, its 2 dy^T fragments + the 9 shifted input fragments per K step for 18 MFMAs.
+template <int TR, bool PRE_BN = false, int NW = 4>
+__global__ void __launch_bounds__(64 * NW)
 k_conv3x3_c64_wgrad_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ slab, int H, int W,
                       int tiles_x, int tiles_y, int ntiles, BnIn bn = BnIn{nullptr, nullptr, nullptr, nullptr}) {
+    constexpr int NTH = 64 * NW, PSTEP = NTH / 8, COT = NW == 8 ? 2 : 4;      // threads, pixels per staging sweep, 16-channel output tiles per wave
     constexpr int DPIX = TR * CW_T, APIX = (TR + 2) * CW_PW;
-    constexpr int ND = DPIX * 8 / 256, NA = (APIX * 8 + 255) / 256;
+    constexpr int ND = DPIX * 8 / NTH, NA = (APIX * 8 + NTH - 1) / NTH;
+    static_assert(DPIX * 8 % NTH == 0, "dy tile chunks per thread");
     extern __shared__ __attribute__((aligned(16))) bf16_t cw_smem[];
     bf16_t* D = cw_smem;                        // [TR*16 px][64 co]
     bf16_t* A = cw_smem + DPIX * CV_C;          // [(TR+2)*18 px][64 ci]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4, q = fr >> 2, p = fr & 3;
+    const int cg = wave & 3, ch = NW == 8 ? (wave >> 2) : 0;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const int c8 = (tid & 7) * 8, cidx = tid & 7;
     float bsc[8], bsh[8];                       // PRE_BN: x is the pre-BatchNorm tensor, the operand is relu(bn(x)) (see BnIn)
     if constexpr (PRE_BN) bn_in_consts(bn, c8, bsc, bsh);
-    int dbase[4][2], abase[3][2];
+    int dbase[COT][2], abase[3][2];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
         const int col = 8 * (g & 1) + q + 4 * hf;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            dbase[t][hf] = ((g >> 1) * CW_T + col) * CV_C + (((2 * t + (p >> 1)) ^ cw_key(col)) << 3) + (p & 1) * 4;
+        for (int t = 0; t < COT; ++t)
+            dbase[t][hf] = ((g >> 1) * CW_T + col) * CV_C + (((2 * (COT * ch + t) + (p >> 1)) ^ cw_key(col)) << 3) + (p & 1) * 4;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int pc = col + dx;
-            abase[dx][hf] = ((g >> 1) * CW_PW + pc) * CV_C + (((2 * wave + (p >> 1)) ^ cw_key(pc)) << 3) + (p & 1) * 4;
+            abase[dx][hf] = ((g >> 1) * CW_PW + pc) * CV_C + (((2 * cg + (p >> 1)) ^ cw_key(pc)) << 3) + (p & 1) * 4;
         }
     }
     typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -446,11 +463,11 @@ k_conv3x3_c64_wgrad_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ d
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base1));
         return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
-    f32x4 acc[9][4];
+    f32x4 acc[9][COT];
 #pragma unroll
     for (int a = 0; a < 9; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < COT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     u32x4 rd[ND], ra[NA];
     auto origin = [&](int t, int& b, int& ty0, int& tx0) {
@@ -465,13 +482,13 @@ k_conv3x3_c64_wgrad_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ d
         const bf16_t* dimg = dy + (int64_t)b * H * W * CV_C;
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-            const int px = tl + 32 * i, r = px >> 4, c = px & 15;
+            const int px = tl + PSTEP * i, r = px >> 4, c = px & 15;
             const int gy = min(ty0 + r, H - 1), gx = min(tx0 + c, W - 1);
             rd[i] = ld16(dimg + (unsigned)((gy * W + gx) * CV_C + c8));
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int px = min(tl + 32 * i, APIX - 1), r = (px * 3641) >> 16, c = px - r * CW_PW;     // px / 18 (exact below 1170)
+            const int px = min(tl + PSTEP * i, APIX - 1), r = (px * 3641) >> 16, c = px - r * CW_PW;     // px / 18 (exact below 1170)
             const int gy = min(max(ty0 - 1 + r, 0), H - 1), gx = min(max(tx0 - 1 + c, 0), W - 1);
             ra[i] = ld16(ximg + (unsigned)((gy * W + gx) * CV_C + c8));
         }
@@ -483,24 +500,24 @@ k_conv3x3_c64_wgrad_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ d
         origin(t, b, ty0, tx0);
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-            const int px = (tid >> 3) + 32 * i, r = px >> 4, c = px & 15;
+            const int px = (tid >> 3) + PSTEP * i, r = px >> 4, c = px & 15;
             st16(D + px * CV_C + ((cidx ^ cw_key(c)) << 3), ((ty0 + r < H) && (tx0 + c < W)) ? rd[i] : zero4);
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int px = (tid >> 3) + 32 * i, r = (px * 3641) >> 16, c = px - r * CW_PW;
+            const int px = (tid >> 3) + PSTEP * i, r = (px * 3641) >> 16, c = px - r * CW_PW;
             const unsigned gy = (unsigned)(ty0 - 1 + r), gx = (unsigned)(tx0 - 1 + c);
             if (px < APIX) st16(A + px * CV_C + ((cidx ^ cw_key(c)) << 3), (gy < (unsigned)H && gx < (unsigned)W) ? (PRE_BN ? bn_in_apply(ra[i], bsc, bsh) : ra[i]) : zero4);
         }
         __syncthreads();
         asm volatile("" : "+v"(tl));
         if (t + (int)gridDim.x < ntiles) gload(t + gridDim.x);          // in flight during the MFMA steps below
-        // K steps (tile rows 2k, 2k+1 = 32 pixels), fully unrolled with the fragments of step k+1 read from LDS while the 36 MFMAs of
-        // step k issue (one wave per SIMD: nothing else hides the LDS latency); fences keep the two-stage pipeline as written
-        bf16x8 df[2][4], af[2][9];
+        // K steps (tile rows 2k, 2k+1 = 32 pixels), fully unrolled with the fragments of step k+1 read from LDS while the MFMAs of
+        // step k issue; fences keep the two-stage pipeline as written
+        bf16x8 df[2][COT], af[2][9];
         auto fload = [&](int k, bf16x8* dfr, bf16x8* afr) {
 #pragma unroll
-            for (int tq = 0; tq < 4; ++tq) dfr[tq] = trfrag(D + dbase[tq][0] + 2 * k * CW_T * CV_C, D + dbase[tq][1] + 2 * k * CW_T * CV_C);
+            for (int tq = 0; tq < COT; ++tq) dfr[tq] = trfrag(D + dbase[tq][0] + 2 * k * CW_T * CV_C, D + dbase[tq][1] + 2 * k * CW_T * CV_C);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int dyy = tap / 3, dxx = tap - 3 * dyy;
@@ -514,7 +531,7 @@ k_conv3x3_c64_wgrad_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ d
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-                for (int tq = 0; tq < 4; ++tq) acc[tap][tq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[k & 1][tq], af[k & 1][tap], acc[tap][tq], 0, 0, 0);
+                for (int tq = 0; tq < COT; ++tq) acc[tap][tq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[k & 1][tq], af[k & 1][tap], acc[tap][tq], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -523,10 +540,10 @@ k_conv3x3_c64_wgrad_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ d
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int tq = 0; tq < 4; ++tq)
+        for (int tq = 0; tq < COT; ++tq)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                mine[(tap * CV_C + 16 * tq + 4 * g + r) * CV_C + 16 * wave + fr] = acc[tap][tq][r];
+                mine[(tap * CV_C + 16 * (COT * ch + tq) + 4 * g + r) * CV_C + 16 * cg + fr] = acc[tap][tq][r];
 }
 
 // dW[co][ci][tap] (fp32 OIHW) += sum over the workgroup slabs, in a fixed order.  Block = 256 consecutive slab elements x 16 waves;
@@ -607,6 +624,24 @@ int ap_conv3x3_c64_bn(const ap_bf16* x, const ap_bn_input* bn_in, const ap_bf16*
         attr_done = 1;
     }
     const int grid = cv_grid(ntiles);
+    static int waves = 0;
+    if (waves == 0) { const char* e = getenv("AP_CONV_WAVES"); waves = (e && atoi(e) == 4) ? 4 : 8; }
+    if (waves == 8) {
+        static int attr8 = 0;
+        if (!attr8) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64<false, 0, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES) != hipSuccess) return AP_ERR_LAUNCH;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64<true, 0, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES) != hipSuccess) return AP_ERR_LAUNCH;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64<false, 0, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES) != hipSuccess) return AP_ERR_LAUNCH;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64<true, 0, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES) != hipSuccess) return AP_ERR_LAUNCH;
+            attr8 = 1;
+        }
+        const BnIn bn = bn_in ? BnIn{bn_in->mean, bn_in->rstd, bn_in->gamma, bn_in->beta} : BnIn{nullptr, nullptr, nullptr, nullptr};
+        if (bn_in && stats) hipLaunchKernelGGL((k_conv3x3_c64<true, 0, true, 8>), dim3(grid), dim3(512), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats, bn);
+        else if (bn_in) hipLaunchKernelGGL((k_conv3x3_c64<false, 0, true, 8>), dim3(grid), dim3(512), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats, bn);
+        else if (stats) hipLaunchKernelGGL((k_conv3x3_c64<true, 0, false, 8>), dim3(grid), dim3(512), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats, bn);
+        else hipLaunchKernelGGL((k_conv3x3_c64<false, 0, false, 8>), dim3(grid), dim3(512), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats, bn);
+        return ap_check_launch();
+    }
     if (bn_in) {
         const BnIn bn = {bn_in->mean, bn_in->rstd, bn_in->gamma, bn_in->beta};
         if (stats) hipLaunchKernelGGL((k_conv3x3_c64<true, 0, true>), dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats, bn);
@@ -671,8 +706,19 @@ int ap_conv3x3_c64_wgrad_bn(const ap_bf16* x, const ap_bn_input* bn_in, const ap
         const int gp = ntiles < 256 ? ntiles : 256;
         if ((size_t)gp * CV_WELEMS * sizeof(float) > ws_bytes) return AP_ERR_SHAPE;
         grid = gp;
-        if (bn_in) {
-            const BnIn bn = {bn_in->mean, bn_in->rstd, bn_in->gamma, bn_in->beta};
+        static int waves = 0;
+        if (waves == 0) { const char* e = getenv("AP_CONV_WAVES"); waves = (e && atoi(e) == 4) ? 4 : 8; }
+        const BnIn bn = bn_in ? BnIn{bn_in->mean, bn_in->rstd, bn_in->gamma, bn_in->beta} : BnIn{nullptr, nullptr, nullptr, nullptr};
+        if (waves == 8) {
+            static int attr8 = 0;
+            if (!attr8) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64_wgrad_p<PTR, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS) != hipSuccess) return AP_ERR_LAUNCH;
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64_wgrad_p<PTR, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS) != hipSuccess) return AP_ERR_LAUNCH;
+                attr8 = 1;
+            }
+            if (bn_in) hipLaunchKernelGGL((k_conv3x3_c64_wgrad_p<PTR, true, 8>), dim3(grid), dim3(512), P_LDS, (hipStream_t)stream, x, dy, static_cast<float*>(workspace), H, W, tiles_x, tyy, ntiles, bn);
+            else hipLaunchKernelGGL((k_conv3x3_c64_wgrad_p<PTR, false, 8>), dim3(grid), dim3(512), P_LDS, (hipStream_t)stream, x, dy, static_cast<float*>(workspace), H, W, tiles_x, tyy, ntiles, bn);
+        } else if (bn_in) {
             hipLaunchKernelGGL((k_conv3x3_c64_wgrad_p<PTR, true>), dim3(grid), dim3(256), P_LDS, (hipStream_t)stream, x, dy, static_cast<float*>(workspace), H, W, tiles_x, tyy, ntiles, bn);
         } else
         hipLaunchKernelGGL((k_conv3x3_c64_wgrad_p<PTR>), dim3(grid), dim3(256), P_LDS, (hipStream_t)stream, x, dy, static_cast<float*>(workspace), H, W, tiles_x, tyy, ntiles);
