@@ -324,6 +324,91 @@ class _RoundOperand(torch.autograd.Function):
         return g
 
 
+class _RoundFwd(torch.autograd.Function):
+    """an activation stored in bf16 whose gradient is consumed unrounded by the next epilogue: rounded forward only"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _r16(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _GeluBf16Points(torch.autograd.Function):
+    """fc1's epilogue on the MI355X path: a = bf16(gelu(h)) of the ROUNDED pre-activation h, and bf16(gelu'(h)) is what is stored for
+    the backward, whose epilogue multiplies the fp32 accumulator of fc2's input gradient by it (csrc/gemm_epi.h, gelu = 2 / mul_by)"""
+
+    @staticmethod
+    def forward(ctx, h):
+        ctx.save_for_backward(h)
+        return _r16(gelu(h))
+
+    @staticmethod
+    def backward(ctx, g):
+        (h,) = ctx.saved_tensors
+        d = 0.5 * (1.0 + torch.erf(h / math.sqrt(2.0))) + h * torch.exp(-0.5 * h * h) / math.sqrt(2.0 * math.pi)
+        return g * _r16(d)
+
+
+class _MhsaBf16Points(torch.autograd.Function):
+    """softmax(q k^T s) v as csrc/mhsa.hip computes it: fp32 scores and softmax statistics from bf16 q, k; the probabilities rounded to
+    bf16 as the operand of the P V product but summed unrounded for the normalisation; bf16 output.  Backward: delta = rowsum(O dO) from
+    the bf16 tensors, P recomputed from the log-sum-exp, dV = bf16(P)^T dO, dS = P (dP - delta) rounded to bf16 as the operand of
+    dQ = dS K s and dK = dS^T Q s."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        hd = C // heads
+        q, k, v = qkv.reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        sc = hd ** -0.5
+        s = (q @ k.transpose(-1, -2)) * sc
+        m = s.max(-1, keepdim=True)[0]
+        pr = torch.exp(s - m)
+        l = pr.sum(-1, keepdim=True)
+        o = _r16((_r16(pr) @ v) / l)
+        ctx.save_for_backward(q, k, v, o, m + torch.log(l))
+        ctx.cfg = (B, N, C, heads, hd, sc)
+        return o.transpose(1, 2).reshape(B, N, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, o, lse = ctx.saved_tensors
+        B, N, C, heads, hd, sc = ctx.cfg
+        do = _r16(g).reshape(B, N, heads, hd).transpose(1, 2)
+        delta = (o * do).sum(-1, keepdim=True)
+        pr = torch.exp((q @ k.transpose(-1, -2)) * sc - lse)
+        dv = _r16(pr).transpose(-1, -2) @ do
+        ds = _r16(pr * (do @ v.transpose(-1, -2) - delta))
+        dq = (ds @ k) * sc
+        dk = (ds.transpose(-1, -2) @ q) * sc
+        dqkv = torch.stack([dq, dk, dv], 0).permute(1, 3, 0, 2, 4).reshape(B, N, 3 * C)
+        return dqkv, None
+
+
+def transformer_bf16_points(x, p: Params, pre: str, heads: int):
+    """Transformer.forward (models/volo.py:230-234, DropPath off) in the caller's precision with every tensor the MI355X block keeps in bf16
+    rounded where functional.TransformerBlockFn rounds it, forward and backward (LayerNorm outputs, qkv, attention probabilities /
+    output / dS, both residual sums, the pre-activation and its GELU, the stored gelu', every gradient tensor, the weights as matrix
+    operands): what is left against the HIP block is its kernels' own arithmetic.  x [B,N,C], bf16-valued."""
+    rb, rw = _RoundBoth.apply, _RoundOperand.apply
+    xn1 = rb(layernorm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"]))
+    qkv = rb(linear(xn1, rw(p[pre + "attn.qkv.weight"]), p.get(pre + "attn.qkv.bias")))
+    o = _MhsaBf16Points.apply(qkv, heads)
+    x1 = rb(linear(o, rw(p[pre + "attn.proj.weight"]), p[pre + "attn.proj.bias"]) + x)
+    xn2 = rb(layernorm(x1, p[pre + "norm2.weight"], p[pre + "norm2.bias"]))
+    h = rb(linear(xn2, rw(p[pre + "mlp.fc1.weight"]), p[pre + "mlp.fc1.bias"]))
+    a = _GeluBf16Points.apply(h)
+    return rb(linear(a, rw(p[pre + "mlp.fc2.weight"]), p[pre + "mlp.fc2.bias"]) + x1)
+
+
 def patch_embed(x, p: Params, train: bool, patch_size: int = 8, pre: str = "patch_embed.", bf16_points: bool = False):
     """PatchEmbed.forward, models/volo.py:376-380: conv7x7 s2 -> BN -> ReLU -> 2x(conv3x3 ->
     BN -> ReLU) -> conv(patch/2) stride patch/2 with bias.  Returns tokens [B,H,W,C].
