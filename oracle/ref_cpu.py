@@ -409,6 +409,60 @@ def transformer_bf16_points(x, p: Params, pre: str, heads: int):
     return rb(linear(a, rw(p[pre + "mlp.fc2.weight"]), p[pre + "mlp.fc2.bias"]) + x1)
 
 
+class _OutlookBf16Points(torch.autograd.Function):
+    """unfold -> softmax -> attn @ v -> fold (models/volo.py:83-98; kernel 3, padding 1, stride 2) as csrc/outlook.hip computes it:
+    fp32 softmax of the bf16 logits; the probabilities rounded to bf16 as the matrix operand; every WINDOW's product rounded to bf16
+    before the fold adds the (up to four) windows that cover a pixel in fp32; bf16 output.  Backward: dV = fold(bf16(P)^T dY per window,
+    rounded), dlogits = s P (dP - <P, dP>) with the UNROUNDED probabilities and dP = dY V^T over the window's 32 channels."""
+
+    @staticmethod
+    def forward(ctx, v, logits, heads):
+        B, H, W, C = v.shape
+        hd = C // heads
+        h, w = -(-H // 2), -(-W // 2)
+        L = h * w
+        vu = F.unfold(v.permute(0, 3, 1, 2), kernel_size=3, padding=1, stride=2)               # [B, C*9, L], channel = c*9 + q
+        vu = vu.reshape(B, heads, hd, 9, L).permute(0, 1, 4, 3, 2)                              # [B, heads, L, 9 q, hd]
+        a = logits[..., :heads * 81].reshape(B, L, heads, 9, 9).permute(0, 2, 1, 3, 4)          # [B, heads, L, 9 p, 9 q]
+        pr = torch.softmax(a * hd ** -0.5, dim=-1)
+        z = _r16(_r16(pr) @ vu)                                                                  # [B, heads, L, 9 p, hd]
+        y = F.fold(z.permute(0, 1, 4, 3, 2).reshape(B, C * 9, L), (H, W), kernel_size=3, padding=1, stride=2)
+        ctx.save_for_backward(vu, pr)
+        ctx.cfg = (B, H, W, C, heads, hd, L, logits.shape[-1])
+        return _r16(y).permute(0, 2, 3, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        vu, pr = ctx.saved_tensors
+        B, H, W, C, heads, hd, L, ldl = ctx.cfg
+        gu = F.unfold(_r16(g).permute(0, 3, 1, 2), kernel_size=3, padding=1, stride=2).reshape(B, heads, hd, 9, L).permute(0, 1, 4, 3, 2)
+        dvu = _r16(_r16(pr).transpose(-1, -2) @ gu)                                              # [B, heads, L, 9 q, hd]
+        dv = F.fold(dvu.permute(0, 1, 4, 3, 2).reshape(B, C * 9, L), (H, W), kernel_size=3, padding=1, stride=2).permute(0, 2, 3, 1)
+        dp = gu @ vu.transpose(-1, -2)                                                           # [B, heads, L, 9 p, 9 q]
+        da = hd ** -0.5 * pr * (dp - (pr * dp).sum(-1, keepdim=True))
+        dl = g.new_zeros(B, L, ldl)
+        dl[..., :heads * 81] = da.permute(0, 2, 1, 3, 4).reshape(B, L, heads * 81)
+        return dv, dl, None
+
+
+def outlooker_bf16_points(x, p: Params, pre: str, heads: int):
+    """Outlooker.forward (models/volo.py:140-144) with the rounding points of functional.OutlookerBlockFn (see transformer_bf16_points);
+    x [B,H,W,C], bf16-valued.  LayerNorm-1's output feeds the v projection and the 2x2 average pool: the v path's input gradient is a
+    bf16 tensor that the pool's gradient is added into (ap_avgpool2_bwd_acc), hence the second rounding node on that path."""
+    rb, rw = _RoundBoth.apply, _RoundOperand.apply
+    B, H, W, C = x.shape
+    xn1 = rb(layernorm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"]))
+    v = rb(linear(rb(xn1), rw(p[pre + "attn.v.weight"]), p.get(pre + "attn.v.bias")))
+    pooled = rb(avgpool_ceil(xn1, 2))
+    logits = rb(linear(pooled.reshape(B, -1, C), rw(p[pre + "attn.attn.weight"]), p[pre + "attn.attn.bias"]))
+    yo = _OutlookBf16Points.apply(v, logits, heads)
+    x1 = rb(linear(yo, rw(p[pre + "attn.proj.weight"]), p[pre + "attn.proj.bias"]) + x)
+    xn2 = rb(layernorm(x1, p[pre + "norm2.weight"], p[pre + "norm2.bias"]))
+    hh = rb(linear(xn2, rw(p[pre + "mlp.fc1.weight"]), p[pre + "mlp.fc1.bias"]))
+    a = _GeluBf16Points.apply(hh)
+    return rb(linear(a, rw(p[pre + "mlp.fc2.weight"]), p[pre + "mlp.fc2.bias"]) + x1)
+
+
 def patch_embed(x, p: Params, train: bool, patch_size: int = 8, pre: str = "patch_embed.", bf16_points: bool = False):
     """PatchEmbed.forward, models/volo.py:376-380: conv7x7 s2 -> BN -> ReLU -> 2x(conv3x3 ->
     BN -> ReLU) -> conv(patch/2) stride patch/2 with bias.  Returns tokens [B,H,W,C].

@@ -241,6 +241,49 @@ def test_transformer_block_kernels_vs_fp64_with_the_same_rounding_points():
         assert not bad, (tag, bad)
 
 
+def test_outlooker_block_kernels_vs_fp64_with_the_same_rounding_points():
+    """The outlooker block's kernels (LayerNorm, the v / logits / proj / MLP GEMMs, the 2 x 2 average pool and its backward, the outlook
+    attention core forward and its fused backward) against oracle/ref_cpu.py outlooker_bf16_points: the reference block in fp64 with the
+    rounding points of functional.OutlookerBlockFn -- among them the per-WINDOW rounding of the outlook products in front of the fold and
+    the unrounded probabilities in dlogits (csrc/outlook.hip).  The reference fixture's block (2 x 8 x 8 x 64) and a D1-shaped one
+    (8 x 28 x 28 x 192, 6 heads: persistent outlook kernels, 8-phase GEMMs).  Measured on MI355X: fixture output 3.6e-7, parameter gradients
+    <= 2.8e-6; the D1-shaped block: output 2.5e-4, parameter gradients 2e-4 - 1.1e-3; input gradients 1.7e-3 (bf16 tensor against an
+    unrounded leaf gradient).  Bound BLOCK_KERNEL_TOL = 5e-3."""
+    from autoprog_amd.models import volo as V
+    d = load("blocks")
+    cases = []
+    blk = V.Outlooker(64, kernel_size=3, padding=1, stride=2, num_heads=2, mlp_ratio=3.0)
+    blk.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sub(d, "outlooker.w").items()}, strict=True)
+    cases.append(("fixture", blk, 2, torch.from_numpy(d["outlooker.x"]), torch.from_numpy(d["outlooker.dy"])))
+    torch.manual_seed(31)
+    big = V.Outlooker(192, kernel_size=3, padding=1, stride=2, num_heads=6, mlp_ratio=3.0)
+    with torch.no_grad():
+        for n_, p_ in big.named_parameters():
+            if p_.dim() == 1 and "norm" in n_ and n_.endswith("weight"):
+                p_.uniform_(0.5, 1.5)
+            elif p_.dim() == 1:
+                p_.normal_(0, 0.1)
+    g = torch.Generator().manual_seed(32)
+    cases.append(("8x28x28x192", big, 6, torch.randn(8, 28, 28, 192, generator=g), torch.randn(8, 28, 28, 192, generator=g)))
+    for tag, mod, heads, x, dy in cases:
+        xb, dyb = x.to(torch.bfloat16), dy.to(torch.bfloat16).reshape(x.shape)
+        p64 = {k: v.detach().double().clone().requires_grad_(True) for k, v in mod.state_dict().items()}
+        x64 = xb.double().requires_grad_(True)
+        ref = R.outlooker_bf16_points(x64, p64, "", heads)
+        ref.backward(dyb.double())
+        mod = mod.cuda().train()
+        xg = xb.cuda().requires_grad_(True)
+        y = mod(xg)
+        y.backward(dyb.cuda())
+        e_y, e_x = rel(y, ref.detach()), rel(xg.grad, x64.grad)
+        errs = {n: rel(p_.grad, p64[n].grad) for n, p_ in mod.named_parameters()}
+        print("outlooker block kernels vs rounding-matched fp64 (%s): y %.2e dx %.2e; parameter gradients" % (tag, e_y, e_x),
+              {k: float("%.2e" % v) for k, v in sorted(errs.items(), key=lambda kv: -kv[1])})
+        assert e_y < BLOCK_KERNEL_TOL and e_x < BLOCK_KERNEL_TOL, (tag, e_y, e_x)
+        bad = {k: v for k, v in errs.items() if v > BLOCK_KERNEL_TOL}
+        assert not bad, (tag, bad)
+
+
 def test_hip_stem64_kernels_vs_fp64_with_the_same_rounding_points():
     """The stem KERNELS held to 5e-3 (measured 2.6e-3 at worst), independently of what bf16 activations cost under three training-mode BatchNorms (the test above
     can only hold them to an independent bf16 implementation's error, up to 0.16 per tensor): the oracle's PatchEmbed in fp64 with every
