@@ -463,6 +463,31 @@ def outlooker_bf16_points(x, p: Params, pre: str, heads: int):
     return rb(linear(a, rw(p[pre + "mlp.fc2.weight"]), p[pre + "mlp.fc2.bias"]) + x1)
 
 
+def class_block_bf16_points(x, p: Params, pre: str, heads: int):
+    """ClassBlock.forward (models/volo.py:304-308) with the rounding points of functional.ClassBlockFn; x [B,1+N,C], bf16-valued.  The
+    class attention itself runs in fp32 on bf16 q / k / v with fp32 probabilities (csrc/mhsa.hip k_class_attn_*): plain autograd between
+    rounding nodes.  LayerNorm-1 of the class token feeds q and kv: the kv path's input gradient is rounded before the q path's is added
+    to it in the q GEMM's residual epilogue, hence the second rounding node there."""
+    rb, rw = _RoundBoth.apply, _RoundOperand.apply
+    B, N1, C = x.shape
+    hd = C // heads
+    c0, t0 = x[:, :1], x[:, 1:]
+    n1w, n1b = p[pre + "norm1.weight"], p[pre + "norm1.bias"]
+    nc, nt = rb(layernorm(c0, n1w, n1b)), rb(layernorm(t0, n1w, n1b))
+    wkv, bkv = rw(p[pre + "attn.kv.weight"]), p.get(pre + "attn.kv.bias")
+    kv = torch.cat([rb(linear(rb(nc), wkv, bkv)), rb(linear(nt, wkv, bkv))], dim=1).reshape(B, N1, 2, heads, hd)
+    k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
+    q = rb(linear(nc, rw(p[pre + "attn.q.weight"]), p.get(pre + "attn.q.bias"))).reshape(B, heads, 1, hd)
+    att = torch.softmax((q * hd ** -0.5) @ k.transpose(-1, -2), dim=-1)
+    o = rb((att @ v).transpose(1, 2).reshape(B, 1, C))
+    c1 = rb(linear(o, rw(p[pre + "attn.proj.weight"]), p[pre + "attn.proj.bias"]) + c0)
+    n2 = rb(layernorm(c1, p[pre + "norm2.weight"], p[pre + "norm2.bias"]))
+    h = rb(linear(n2, rw(p[pre + "mlp.fc1.weight"]), p[pre + "mlp.fc1.bias"]))
+    a = _GeluBf16Points.apply(h)
+    c2 = rb(linear(a, rw(p[pre + "mlp.fc2.weight"]), p[pre + "mlp.fc2.bias"]) + c1)
+    return torch.cat([c2, t0], dim=1)
+
+
 def patch_embed(x, p: Params, train: bool, patch_size: int = 8, pre: str = "patch_embed.", bf16_points: bool = False):
     """PatchEmbed.forward, models/volo.py:376-380: conv7x7 s2 -> BN -> ReLU -> 2x(conv3x3 ->
     BN -> ReLU) -> conv(patch/2) stride patch/2 with bias.  Returns tokens [B,H,W,C].
