@@ -543,7 +543,7 @@ def mix_token_swap(x, box, scale: int):
 
 def volo_forward(p: Params, img, layers, embed_dims, num_heads, train: bool, mix=None,
                  skip: Optional[List[List[int]]] = None, dp_masks: Optional[dict] = None,
-                 drop_path_rate: float = 0.0, patch_size: int = 8, pooling_scale: int = 2, **_):
+                 drop_path_rate: float = 0.0, patch_size: int = 8, pooling_scale: int = 2, bf16_points: bool = False, **_):
     """VOLO.forward, models/volo.py:644-694, for the model_variant/volo_d* families
     (outlook stage -> downsample -> transformer stages -> 2 class blocks -> heads).
 
@@ -552,7 +552,55 @@ def volo_forward(p: Params, img, layers, embed_dims, num_heads, train: bool, mix
     dp_masks {(stage, idx): (mask1, mask2)} per-sample keep masks for DropPath; the keep
              probability follows models/volo.py:428-437.
     Returns (x_cls, x_aux, box) in train mode, fused logits in eval mode.
+    bf16_points (train mode, DropPath off): the whole network with the rounding points of the MI355X pipeline -- patch_embed(bf16_points),
+    outlooker_ / transformer_ / class_block_bf16_points, the downsample and head GEMMs, the position embedding added as a bf16 tensor, the
+    class token cast once, and one rounding of the token gradient per hop of the chain class block 1 <- class block 2 <- final norm
+    (functional.ClassBlockFn hands the tokens on; each hop's LayerNorm backward adds and rounds).
     """
+    if bf16_points:
+        assert train and not dp_masks and drop_path_rate == 0.0, "bf16_points: training forward without DropPath"
+        rb, rw, rf = _RoundBoth.apply, _RoundOperand.apply, _RoundFwd.apply
+        x = patch_embed(img, p, True, patch_size, bf16_points=True)
+        box = (0, 0, 0, 0)
+        if mix is not None:
+            box = tuple(int(v) for v in mix[1])
+            x = mix_token_swap(x, box, pooling_scale)
+        skip = skip or [[], [], [], []]
+        net_idx = 0
+        for s, depth in enumerate(layers):
+            if net_idx == 2:
+                x = rb(x + rf(interpolate_pos_encoding(p["pos_embed"], x.shape[1], x.shape[2])))
+            for i in range(depth):
+                if i in skip[s]:
+                    continue
+                pre = "network.%d.%d." % (net_idx, i)
+                if s == 0:
+                    x = outlooker_bf16_points(x, p, pre, num_heads[0])
+                else:
+                    B, H, W, C = x.shape
+                    x = transformer_bf16_points(x.reshape(B, H * W, C), p, pre, num_heads[s]).reshape(B, H, W, C)
+            net_idx += 1
+            if s == 0:
+                pre = "network.%d." % net_idx
+                B, H, W, C = x.shape
+                w = p[pre + "proj.weight"]
+                patches = x.reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 4 * C)
+                x = rb(patches @ rw(w.permute(0, 2, 3, 1).reshape(w.shape[0], 4 * C)).t() + p[pre + "proj.bias"])
+                net_idx += 1
+        B, H, W, C = x.shape
+        tok = x.reshape(B, H * W, C)
+        cls = rf(p["cls_token"]).expand(B, -1, -1)
+        for j in range(2):
+            cls = class_block_bf16_points(torch.cat([cls, tok], dim=1), p, "post_network.%d." % j, num_heads[-1])[:, :1]
+            tok = rb(tok)                           # the next consumer's token gradient is a bf16 tensor when it comes back through this hop
+        ncls = rb(layernorm(cls, p["norm.weight"], p["norm.bias"]))
+        ntok = rb(layernorm(tok, p["norm.weight"], p["norm.bias"]))
+        x_cls = rb(linear(ncls[:, 0], rw(p["head.weight"]), p["head.bias"]))
+        x_aux = rb(linear(ntok, rw(p["aux_head.weight"]), p["aux_head.bias"]))
+        if mix is not None:
+            nc = x_aux.shape[-1]
+            x_aux = mix_token_swap(x_aux.reshape(B, H, W, nc), box, 1).reshape(B, H * W, nc)
+        return x_cls, x_aux, box
     x = patch_embed(img, p, train, patch_size)
     box = (0, 0, 0, 0)
     if train and mix is not None:
