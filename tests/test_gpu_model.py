@@ -643,6 +643,32 @@ def test_late_state_vs_reference_golden():
     assert one < 0.1, one
     bad = {k: v for k, v in errs.items() if v > (0.5 if k.startswith("patch_embed.conv") else 0.25)}
     assert not bad, bad
+    # The same step against the oracle WITH the pipeline's bf16 rounding points (volo_forward(bf16_points=True)): the yardstick the
+    # CPU-autocast run could not be.  Measured: that oracle -- exact arithmetic between the same roundings -- is itself 7.3e-2 away from
+    # the fp64 reference as one gradient vector; the HIP kernels 7.8e-2 from the reference and 8.1e-2 from that oracle (logits 2.4e-3 /
+    # 8.2e-3, loss 3.29842 / 3.29851): in this memorising state ANY two evaluations that round to bf16 part by ~8 %, the gradients
+    # being small differences of large terms -- the kernels sit where an exact implementation of the 16-bit recipe sits.
+    p64 = {k: v.double().clone() for k, v in sd.items()}
+    for v in p64.values():
+        if v.dtype.is_floating_point:
+            v.requires_grad_(True)
+    box = tuple(int(v) for v in d["box"])
+    ref2 = R.volo_forward(p64, x.double().cpu(), train=True, mix=(1.0, box), bf16_points=True, **R.variant_arch("volo_h4_l6"))
+    loss2 = R.token_label_ce(ref2, target.double().cpu(), 0.5, 1.0)
+    loss2.backward()
+    e2 = (rel(out[0], ref2[0]), rel(out[1], ref2[1]))
+    errs2 = {k: rel(named[k].grad, p64[k].grad) for k in names}
+    vc = torch.cat([p64[k].grad.flatten() for k in names])
+    one2 = float((va - vc).norm() / vc.norm())
+    recipe = float((vc - vb).norm() / vb.norm())
+    print("late state vs the rounding-matched oracle: logits %.4f / %.4f, loss %.5f (oracle %.5f), gradients: one vector %.4f, median %.4f, worst %s; "
+          "the rounding-matched oracle against the fp64 reference, one vector: %.4f"
+          % (e2[0], e2[1], float(loss), float(loss2), one2, float(np.median(list(errs2.values()))),
+             [(k, round(v, 4)) for k, v in sorted(errs2.items(), key=lambda kv: -kv[1])[:4]], recipe))
+    assert max(e2) < LATE_POINTS_OUT_TOL and one2 < LATE_POINTS_GRAD_TOL, (e2, one2)
+
+
+LATE_POINTS_OUT_TOL, LATE_POINTS_GRAD_TOL = 2e-2, 0.1
 
 
 def test_hip_stem_eval_and_elastic_resolution_vs_oracle():
