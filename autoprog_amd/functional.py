@@ -893,6 +893,8 @@ def _pos_taps(h, w, h0, w0, device):
     key = (h, w, h0, w0, str(device))
     ent = _BICUBIC_TAPS.get(key)
     if ent is None:
+        if len(_BICUBIC_TAPS) > 64:                  # (a search over many resolutions: four small matrices per entry)
+            _BICUBIC_TAPS.clear()
         wy = torch.from_numpy(bicubic_tap_matrix(h, h0, (h0 + 0.1) / h))
         wx = torch.from_numpy(bicubic_tap_matrix(w, w0, (w0 + 0.1) / w))
         ent = tuple(t.to(device).contiguous() for t in (wy, wx, wy.t().contiguous(), wx.t().contiguous()))
