@@ -393,17 +393,17 @@ class _MhsaBf16Points(torch.autograd.Function):
         return dqkv, None
 
 
-def transformer_bf16_points(x, p: Params, pre: str, heads: int):
+def transformer_bf16_points(x, p: Params, pre: str, heads: int, eps: float = 1e-5):
     """Transformer.forward (models/volo.py:230-234, DropPath off) in the caller's precision with every tensor the MI355X block keeps in bf16
     rounded where functional.TransformerBlockFn rounds it, forward and backward (LayerNorm outputs, qkv, attention probabilities /
     output / dS, both residual sums, the pre-activation and its GELU, the stored gelu', every gradient tensor, the weights as matrix
     operands): what is left against the HIP block is its kernels' own arithmetic.  x [B,N,C], bf16-valued."""
     rb, rw = _RoundBoth.apply, _RoundOperand.apply
-    xn1 = rb(layernorm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"]))
+    xn1 = rb(layernorm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps))
     qkv = rb(linear(xn1, rw(p[pre + "attn.qkv.weight"]), p.get(pre + "attn.qkv.bias")))
     o = _MhsaBf16Points.apply(qkv, heads)
     x1 = rb(linear(o, rw(p[pre + "attn.proj.weight"]), p[pre + "attn.proj.bias"]) + x)
-    xn2 = rb(layernorm(x1, p[pre + "norm2.weight"], p[pre + "norm2.bias"]))
+    xn2 = rb(layernorm(x1, p[pre + "norm2.weight"], p[pre + "norm2.bias"], eps))
     h = rb(linear(xn2, rw(p[pre + "mlp.fc1.weight"]), p[pre + "mlp.fc1.bias"]))
     a = _GeluBf16Points.apply(h)
     return rb(linear(a, rw(p[pre + "mlp.fc2.weight"]), p[pre + "mlp.fc2.bias"]) + x1)
@@ -709,8 +709,33 @@ def vit_block(x, p: Params, pre: str, heads: int, eps=1e-6, dp_masks=None, keep=
 
 
 def vit_forward(p: Params, img, depth: int, heads: int, patch: int = 16, distilled: bool = False,
-                train: bool = True, skip: Sequence[int] = ()):
-    """timm 0.4.5 VisionTransformer.forward (+ DistilledVisionTransformer, models/deit.py:32-59)."""
+                train: bool = True, skip: Sequence[int] = (), bf16_points: bool = False):
+    """timm 0.4.5 VisionTransformer.forward (+ DistilledVisionTransformer, models/deit.py:32-59).
+    bf16_points: the same network with the MI355X pipeline's rounding points (see transformer_bf16_points): bf16 patches and patch
+    projection, class / distillation tokens cast once, the position embedding added as a bf16 tensor, bf16 final norm and heads."""
+    if bf16_points:
+        rb, rw, rf = _RoundBoth.apply, _RoundOperand.apply, _RoundFwd.apply
+        w = p["patch_embed.proj.weight"]
+        B, Cin, H, W = img.shape
+        hh, ww = H // patch, W // patch
+        patches = img[:, :, :hh * patch, :ww * patch].reshape(B, Cin, hh, patch, ww, patch).permute(0, 2, 4, 1, 3, 5).reshape(B, hh * ww, Cin * patch * patch)
+        x = rb(linear(_r16(patches), rw(w.reshape(w.shape[0], -1)), p["patch_embed.proj.bias"]))
+        toks = [rf(p["cls_token"]).expand(B, -1, -1)] + ([rf(p["dist_token"]).expand(B, -1, -1)] if distilled else [])
+        pos, n_extra = p["pos_embed"], len(toks)
+        g0, g = int(round((pos.shape[1] - n_extra) ** 0.5)), int(round(x.shape[1] ** 0.5))
+        if g != g0:
+            grid = interpolate_pos_encoding(pos[:, n_extra:].reshape(1, g0, g0, -1), g, g)
+            pos = torch.cat([pos[:, :n_extra], grid.reshape(1, g * g, -1)], dim=1)
+        x = rb(torch.cat(toks + [x], dim=1) + rf(pos))
+        for i in range(depth):
+            if i not in skip:
+                x = transformer_bf16_points(x, p, "blocks.%d." % i, heads, eps=1e-6)
+        x = rb(layernorm(x, p["norm.weight"], p["norm.bias"], 1e-6))
+        y = rb(linear(x[:, 0], rw(p["head.weight"]), p["head.bias"]))
+        if not distilled:
+            return y
+        yd = rb(linear(x[:, 1], rw(p["head_dist.weight"]), p["head_dist.bias"]))
+        return (y, yd) if train else (y + yd) / 2
     w = p["patch_embed.proj.weight"]
     x = F.conv2d(img, w, p["patch_embed.proj.bias"], stride=patch).flatten(2).transpose(1, 2)
     B = x.shape[0]

@@ -370,6 +370,40 @@ def test_deit_tiny_depth4_vs_oracle():
     assert rel(ys, yrs) < 2e-2
 
 
+def test_deit_kernels_vs_fp64_with_the_same_rounding_points():
+    """DeiT (timm VisionTransformer as models/deit.py registers it) against the oracle's ViT with the pipeline's bf16 rounding points
+    (vit_forward(bf16_points=True)): DeiT-Tiny width, depth 4, 224 px, batch 4, soft-target CE -- outputs, loss, every parameter
+    gradient.  Stage by stage (each fed from the oracle's tensor) the forward agrees to 2e-5 (patch projection), 6e-5 - 2.4e-4 (blocks) and
+    exactly (position embedding, final norm, head); end to end on this default-initialised network (logits near zero) the output is
+    6.5e-3 away, the loss 1.7e-5 relative, the gradients 6.2e-3 in the median and 8.9e-3 at worst.  Bound DEIT_KERNEL_TOL = 2e-2
+    (the plain-oracle tests above: 2e-2 / 6e-2)."""
+    from autoprog_amd.models import create_model
+    from autoprog_amd.loss import SoftTargetCrossEntropy
+    torch.manual_seed(0)
+    model = create_model("model_variant", variant="deit_h3_l4").cuda().train()
+    B = 4
+    x = torch.randn(B, 3, 224, 224, device="cuda")
+    target = torch.softmax(torch.randn(B, 1000, device="cuda") * 3, dim=-1)
+    y = model(x)
+    loss = SoftTargetCrossEntropy()(y, target)
+    loss.backward()
+    p = {k: v.detach().double().cpu().requires_grad_(True) for k, v in model.state_dict().items()}
+    yr = R.vit_forward(p, x.double().cpu(), depth=4, heads=3, bf16_points=True)
+    lr = R.soft_target_ce(yr, target.double().cpu())
+    lr.backward()
+    e_y = rel(y, yr)
+    e_l = abs(float(loss.detach()) - float(lr.detach())) / float(lr.detach())
+    errs = {n: rel(q.grad, p[n].grad) for n, q in model.named_parameters() if float(p[n].grad.norm()) > 1e-12}
+    print("DeiT vs rounding-matched fp64: output %.2e, loss rel %.2e, gradients: median %.2e max %.2e (%s)"
+          % (e_y, e_l, float(np.median(list(errs.values()))), max(errs.values()), max(errs, key=errs.get)))
+    assert e_y < DEIT_KERNEL_TOL and e_l < 1e-4, (e_y, e_l)
+    bad = {k: v for k, v in errs.items() if v > DEIT_KERNEL_TOL}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+
+
+DEIT_KERNEL_TOL = 2e-2
+
+
 def test_deit_distilled_contract():
     """DistilledVisionTransformer (models/deit.py:20-59): 198 tokens, train returns (x, x_dist), eval their mean; gradients
     reach the distillation token, its position embedding and head_dist."""
