@@ -18,6 +18,13 @@ port of facebook/deit, the family models/deit.py registers) on the same weights 
 (``test_vit_and_distilled_deit_against_the_transformers_library``).
 
 All ``file:line`` citations are relative to the reference tree.
+
+``*_bf16_points`` / ``bf16_points=True`` (round 4): the same functions with every tensor that the MI355X pipeline keeps in bf16 rounded
+to bf16 at the same place, forward and backward (custom autograd nodes where a kernel rounds inside an operation: attention
+probabilities / dS, the outlook core's per-window products, the stored gelu').  They are NOT a second reference: with the rounding
+nodes removed they are the functions above, which the golden vectors pin.  The GPU tests use them to separate what the 16-bit recipe
+costs (HIP path against the plain oracle: percent level) from what the kernels add (HIP path against these: 1e-7 ... 3e-3 per block,
+the fixtures' transformer and class blocks bit-identical in the forward).
 """
 from __future__ import annotations
 
