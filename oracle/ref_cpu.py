@@ -312,11 +312,11 @@ class _RoundBoth(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        return x.to(torch.bfloat16).to(x.dtype)
+        return _r16(x)
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).to(g.dtype)
+        return _r16(g)
 
 
 class _RoundOperand(torch.autograd.Function):
@@ -324,7 +324,7 @@ class _RoundOperand(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w):
-        return w.to(torch.bfloat16).to(w.dtype)
+        return _r16(w)
 
     @staticmethod
     def backward(ctx, g):
@@ -336,15 +336,18 @@ class _RoundFwd(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        return x.to(torch.bfloat16).to(x.dtype)
+        return _r16(x)
 
     @staticmethod
     def backward(ctx, g):
         return g
 
 
+BF16_POINTS_ROUND = True      # tests/test_oracle_golden.py switches it off to show that the *_bf16_points functions ARE the pinned ones plus rounding
+
+
 def _r16(t):
-    return t.to(torch.bfloat16).to(t.dtype)
+    return t.to(torch.bfloat16).to(t.dtype) if BF16_POINTS_ROUND else t
 
 
 class _GeluBf16Points(torch.autograd.Function):
@@ -505,7 +508,7 @@ def patch_embed(x, p: Params, train: bool, patch_size: int = 8, pre: str = "patc
     rb = _RoundBoth.apply if bf16_points else (lambda t: t)
     rw = _RoundOperand.apply if bf16_points else (lambda t: t)
     if bf16_points:
-        x = x.to(torch.bfloat16).to(x.dtype)
+        x = _r16(x)
     strides = [(2, 3), (1, 1), (1, 1)]
     for i, (s, pad) in zip((0, 3, 6), strides):
         x = rb(F.conv2d(x, rw(p[pre + "conv.%d.weight" % i]), None, stride=s, padding=pad))

@@ -414,3 +414,53 @@ def test_vit_and_distilled_deit_against_the_transformers_library():
     assert rel_err(p["blocks.1.attn.qkv.weight"].grad[:C], hg[qn]) < 1e-9
     f2 = next(n for n in hg if n.endswith(("layers.2.mlp.fc2.weight", "layer.2.output.dense.weight")))
     assert rel_err(p["blocks.2.mlp.fc2.weight"].grad, hg[f2]) < 1e-9
+
+
+def test_bf16_points_functions_are_the_pinned_functions_plus_rounding(monkeypatch):
+    """oracle/ref_cpu.py *_bf16_points (the rounding-matched statements the GPU tests hold the kernels to) with their rounding switched
+    off (BF16_POINTS_ROUND = False) must BE the functions the golden vectors pin: outputs and every gradient equal to 1e-10 in fp64 --
+    the custom autograd nodes (attention with dS, the outlook core by unfold / fold, the stored gelu') against plain autograd of the
+    closed forms -- for each block type, the whole VOLO training forward and the ViT."""
+    from autoprog_amd.models import create_model
+    monkeypatch.setattr(R, "BF16_POINTS_ROUND", False)
+    torch.manual_seed(0)
+
+    def params_of(model):
+        return {k: (v.detach().double() + 0.05 * torch.randn(v.shape, dtype=torch.float64)).requires_grad_(True) if v.dtype.is_floating_point
+                else v.detach().clone() for k, v in model.state_dict().items()}
+
+    def compare(run_plain, run_points, p):
+        outs = []
+        for run in (run_plain, run_points):
+            for v in p.values():
+                if v.dtype.is_floating_point:
+                    v.grad = None
+            y = run()
+            ys = y if isinstance(y, (tuple, list)) else (y,)
+            sum((t * torch.linspace(0.5, 1.5, t.numel(), dtype=torch.float64).reshape(t.shape)).sum() for t in ys if torch.is_tensor(t)).backward()
+            outs.append(([t.detach().clone() for t in ys if torch.is_tensor(t)],
+                         {k: v.grad.clone() for k, v in p.items() if v.dtype.is_floating_point and v.grad is not None}))
+        (ya, ga), (yb, gb) = outs
+        for a, b in zip(ya, yb):
+            assert rel_err(b, a) < 1e-10
+        assert set(ga) == set(gb)
+        for k in ga:
+            assert rel_err(gb[k], ga[k]) < 1e-9, k
+
+    m = create_model("model_variant", variant="volo_h4_l6", num_classes=24, img_size=64)
+    p = params_of(m)
+    arch = R.variant_arch("volo_h4_l6")
+    img = torch.randn(2, 3, 64, 64, dtype=torch.float64)
+    mix = (0.7, (1, 0, 3, 2))
+    compare(lambda: R.volo_forward(p, img, train=True, mix=mix, **arch)[:2],
+            lambda: R.volo_forward(p, img, train=True, mix=mix, bf16_points=True, **arch)[:2], p)
+    x = torch.randn(2, 7, 9, 64, dtype=torch.float64)                 # odd grid: clipped pooling windows, ragged outlook windows
+    compare(lambda: R.outlooker(x, p, "network.0.0.", 2), lambda: R.outlooker_bf16_points(x, p, "network.0.0.", 2), p)
+    t = torch.randn(2, 3, 5, 128, dtype=torch.float64)
+    compare(lambda: R.transformer(t, p, "network.2.0.", 4), lambda: R.transformer_bf16_points(t.reshape(2, 15, 128), p, "network.2.0.", 4).reshape(2, 3, 5, 128), p)
+    c = torch.randn(2, 16, 128, dtype=torch.float64)
+    compare(lambda: R.class_block(c, p, "post_network.0.", 4)[:, :1], lambda: R.class_block_bf16_points(c, p, "post_network.0.", 4)[:, :1], p)
+    d = create_model("model_variant", variant="deit_h3_l2", num_classes=16)
+    pd = params_of(d)
+    im = torch.randn(2, 3, 224, 224, dtype=torch.float64)
+    compare(lambda: R.vit_forward(pd, im, depth=2, heads=3), lambda: R.vit_forward(pd, im, depth=2, heads=3, bf16_points=True), pd)
