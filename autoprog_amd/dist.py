@@ -95,8 +95,11 @@ class GradientBucketReducer:
             self._on_grad(p)
 
     def set_accumulate_steps(self, k):
-        """between updates only (the driver changes the split count with the stage, main_prog.py:842)"""
-        assert self._micro == 0 or self._micro >= self.accumulate_steps, "set_accumulate_steps() inside an update"
+        """between updates only (the driver changes the split count with the stage, main_prog.py:842): after the finish() that
+        closed an update, or after zero_grad() -- which abandons whatever update was open"""
+        if not (self._micro == 0 or self._micro >= self.accumulate_steps):
+            raise RuntimeError("set_accumulate_steps() inside an update: %d of %d micro-batches closed (zero_grad() starts over)"
+                               % (self._micro, self.accumulate_steps))
         self.accumulate_steps = max(1, int(k))
         self._micro = 0
 

@@ -262,7 +262,9 @@ def _window_add(problems, ln, params):
         # callbacks then): those gradients are void, and the operands they pin are released here.
         if w["armed"] is not None:
             reset_wgrad_window()
-        if _HAS_ENGINE_CALLBACK and gid != -1:
+        if _HAS_ENGINE_CALLBACK:
+            if gid == -1:
+                return False          # a block backward called outside an engine pass: nothing would flush the window -- the block launches its own
             try:                      # inside a backward pass: the engine calls back when it is over
                 _ENGINE.queue_callback(flush_wgrad_window)
             except RuntimeError:

@@ -173,6 +173,8 @@ def gemm_nt(a, b, n=None, k=None, bias=None, gelu=False, preact_out=None, dgelu_
         out = torch.empty((M, ldc), dtype=BF16, device=a.device)
     else:
         ldc = out.shape[1]
+    if preact_out is not None and not gelu:
+        raise AutoProgHipError("gemm_nt: preact_out is the GELU launches' side output (pass gelu=True)")
     if bias is None and not gelu and dgelu_of is None and mul_by is None and row_scale is None and residual is None:
         epi_ref = None                                            # plain product: the library takes a null epilogue
     else:

@@ -22,17 +22,27 @@ from . import search as S
 from .helpers import ActiveLayerMask
 
 
+def _sync():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 class AutoProgDriver:
     def __init__(self, model, loss_fn, optimizer, reducer, get_batch, r_list, l_list, dp_list, grow_epochs, steps_per_epoch,
                  search_epochs=2, auto_grow=True, probe_batches=4, time_steps=4, seed=0, log=None, original_batch_splits=1,
-                 r_max=None):
+                 r_max=None, dist_bn=""):
         """model: supernet sized for l_list[-1] (e.g. volo_h12_l18); optimizer: FlatAdamWEma over it; reducer: its
         GradientBucketReducer; r_list / l_list / dp_list / grow_epochs: the stage schedule (prog/progressive.py:4-31);
         get_batch(r): a training batch (images at ANY size -- the stem resizes to r -- and a token-label target for r // 16).
         original_batch_splits: the reference's --batch-splits-list[-1] (main_prog.py:567): micro-batches per update at the LARGEST
         (l, r); a stage runs `get_divisor(original_batch_splits, l r^2 / (l_max r_max^2))` of them (main_prog.py:570, 842) -- the
-        driver then calls get_batch(r, splits) and expects a micro-batch of batch_size // splits images (get_batch(r) when 1)."""
+        driver then calls get_batch(r, splits) and expects a micro-batch of batch_size // splits images (get_batch(r) when 1).
+        A search runs every candidate at `original_batch_splits` (main_prog.py:807-810: batch_size = original_batch_size //
+        original_batch_splits for the whole search), timing and probes included.
+        dist_bn: "reduce" | "broadcast" | "" -- the reference's --dist-bn: after every epoch the BatchNorm running statistics are
+        averaged over the ranks or taken from rank 0 (main_prog.py:883-887)."""
         self.original_batch_splits = int(original_batch_splits)
+        self.dist_bn = dist_bn
         self.r_max = r_max if r_max is not None else max(r_list)
         self.batch_splits = 1
         self.model, self.loss_fn, self.opt, self.reducer, self.get_batch = model, loss_fn, optimizer, reducer, get_batch
@@ -91,11 +101,8 @@ class AutoProgDriver:
         the gradient exchange and the optimizer on the last one (`update`, main_prog.py:971,1026).  -> mean loss (device scalar)"""
         self._activate(l, r, dp)
         k = self.splits_for(l, r) if splits is None else splits
-        if hasattr(self.reducer, "set_accumulate_steps"):
-            self.reducer.set_accumulate_steps(k)
-        elif k != 1:
-            raise ValueError("batch splits need a reducer with accumulate_steps")
-        self.reducer.zero_grad()
+        self.reducer.zero_grad()                  # (closes whatever update was open: the split count may change now)
+        self._set_splits(k)
         total = None
         for _ in range(k):
             images, target = self.get_batch(r) if k == 1 else self.get_batch(r, k)
@@ -106,6 +113,17 @@ class AutoProgDriver:
         self.opt.step()
         return total if k == 1 else total / k
 
+    def _set_splits(self, k):
+        if hasattr(self.reducer, "set_accumulate_steps"):
+            self.reducer.set_accumulate_steps(k)
+        elif k != 1:
+            raise ValueError("batch splits need a reducer with accumulate_steps")
+
+    def _search_batch(self, r):
+        """a batch of the size the reference's search runs on: one micro-batch of `original_batch_splits` (main_prog.py:807-810)"""
+        k = self.original_batch_splits
+        return self.get_batch(r) if k <= 1 else self.get_batch(r, k)
+
     # ------------------------------------------------------------------ search (main_prog.py:1558-1821)
     def _probe(self, cands, ema_index=0):
         """train-mode, no-grad loss of EMA copy `ema_index` on `probe_batches` batches per candidate (the reference's taylor0)"""
@@ -115,7 +133,7 @@ class AutoProgDriver:
                 self._activate(l, r, 0.0)
                 tot = None
                 for _ in range(self.probe_batches):
-                    images, target = self.get_batch(r)
+                    images, target = self._search_batch(r)
                     loss = self.loss_fn(self.model(images), target).float()
                     tot = loss if tot is None else tot + loss
                 out[(r, l)] = tot / self.probe_batches
@@ -123,20 +141,24 @@ class AutoProgDriver:
         return dict(zip(cands, self._rank_mean(vals)))
 
     def _time(self, cands):
-        """mean forward+backward seconds per candidate, measured once at search start (main_prog.py:1886-1902)"""
+        """mean forward+backward seconds per candidate, measured once at search start (main_prog.py:1886-1902), on the search's
+        micro-batch.  Every timed pass is an update of ONE micro-batch whatever split count the last training step left in the
+        reducer: each candidate's time then includes the gradient exchange, and the reducer is left between updates."""
         out = {}
+        self.reducer.zero_grad()
+        self._set_splits(1)
         for (r, l) in cands:
             self._activate(l, r, self.current_dp)
-            images, target = self.get_batch(r)
+            images, target = self._search_batch(r)
             for i in range(self.time_steps + 1):
                 if i == 1:
-                    torch.cuda.synchronize()
+                    _sync()
                     t0 = time.perf_counter()
                 self.reducer.zero_grad()
                 self.loss_fn(self.model(images), target).backward()
                 self.reducer.finish()
                 self.reducer.take_pending_scale()
-            torch.cuda.synchronize()
+            _sync()
             out[(r, l)] = (time.perf_counter() - t0) / self.time_steps
         return dict(zip(cands, self._rank_mean([out[c] for c in cands])))
 
@@ -160,7 +182,7 @@ class AutoProgDriver:
                 losses.append(self._probe(cands))
                 for _ in range(per):
                     r, l = self.rng.choice(rs), self.rng.choice(ls)   # one config per step, identical on every rank (seeded)
-                    self._train_step(l, r, dp_final)
+                    self._train_step(l, r, dp_final, splits=self.original_batch_splits)     # main_prog.py:807: the search's split count
         losses.append(self._probe(cands))
         mean_loss = {"r%d_l%d" % c: sum(p[c] for p in losses) / len(losses) for c in cands}
         step_time = {"r%d_l%d" % c: times[c] for c in cands}
@@ -197,4 +219,12 @@ class AutoProgDriver:
             self.history.append(dict(epoch=epoch, kind="train", r=self.current_r, l=self.current_l, dp=self.current_dp,
                                      loss=tot / self.steps_per_epoch))
             self.log("epoch %d: r=%d l=%d loss %.4f" % (epoch, self.current_r, self.current_l, tot / self.steps_per_epoch))
+            self._distribute_bn()
         return self.history
+
+    def _distribute_bn(self):
+        """main_prog.py:883-887: `if args.distributed and args.dist_bn in ('broadcast', 'reduce')` after every training epoch"""
+        world = getattr(self.reducer, "world", 1)
+        if world > 1 and self.dist_bn in ("broadcast", "reduce"):
+            from ..dist import distribute_bn
+            distribute_bn(self.model, world, reduce=self.dist_bn == "reduce", group=self.reducer.group)

@@ -183,6 +183,83 @@ def test_driver_batch_splits_follow_the_reference_rule():
     assert AutoProgDriver(None, None, None, None, None, [64], [3], [0.0], [0], 1).splits_for(3, 64) == 1      # default: no splits
 
 
+def test_driver_search_after_a_stage_with_batch_splits():
+    """a search that follows a training stage run at k >= 2 micro-batches per update.  `_time` used to close its passes as
+    accumulating micro-batches (no exchange, `_micro` left at 1) and the first training step of the search then died in
+    set_accumulate_steps.  Real GradientBucketReducer + the real driver on a CPU stand-in model: the timed passes are updates of one
+    micro-batch, every batch of the search has the reference's search size (original_batch_splits, main_prog.py:807-810), and the
+    reducer ends between updates."""
+    import contextlib
+    from autoprog_amd.dist import GradientBucketReducer
+    from autoprog_amd.prog.driver import AutoProgDriver
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = torch.nn.Linear(8, 4)
+            self.configs = []
+
+        def set_sample_config(self, cfg):
+            self.configs.append((cfg["layer_num"], cfg["input_size"]))
+
+        def set_drop_path_rate(self, rate):
+            pass
+
+        def forward(self, x):
+            return self.fc(x)
+
+    class Opt:
+        def __init__(self, red):
+            self.red, self.steps = red, 0
+
+        def step(self):
+            assert self.red.is_update_step
+            self.red.take_pending_scale()
+            self.steps += 1
+
+        def grow(self, *a, **k):
+            pass
+
+        def ema_weights(self, i):
+            return contextlib.nullcontext()
+
+    torch.manual_seed(0)
+    model = Net()
+    red = GradientBucketReducer(list(model.parameters()), world_size=1)
+    opt = Opt(red)
+    asked = []
+
+    def get_batch(r, k=1):
+        asked.append((r, k))
+        return torch.randn(8 // k, 8), torch.randn(8 // k, 4)
+    closed = []
+    real_finish = red.finish
+    red.finish = lambda: (real_finish(), closed.append(red.is_update_step))[0]
+    drv = AutoProgDriver(model, lambda out, t: ((out - t) ** 2).mean(), opt, red, get_batch, r_list=[64, 80, 96], l_list=[3, 4, 6],
+                         dp_list=[0.0, 0.0, 0.0], grow_epochs=[0, 2, 4], steps_per_epoch=2, search_epochs=1, probe_batches=1, time_steps=1,
+                         original_batch_splits=4)
+    drv._transition(6, 96, 0.0)
+    assert drv.batch_splits == 4
+    drv._train_step(6, 96, 0.0)                                   # an update of four micro-batches
+    assert asked == [(96, 4)] * 4 and closed == [False, False, False, True] and opt.steps == 1
+    asked.clear(); closed.clear()
+    drv._transition(3, 64, 0.0)
+    r, l = drv.search(1, 2)                                       # died with "set_accumulate_steps() inside an update" before the fix
+    assert (r, l) in [(rr, ll) for rr in (64, 80) for ll in (4, 6)]
+    assert asked and all(k == 4 for _, k in asked), asked          # timing, probes and training steps of a search: the search's micro-batch
+    n_time = 4 * 2                                                # four candidates x (1 warm-up + 1 timed) passes
+    assert closed[:n_time] == [True] * n_time                     # each timed pass is a whole update (exchange included)
+    train = closed[n_time:]
+    assert len(train) == 2 * 4 and train == [False, False, False, True] * 2
+    assert red._micro in (0, red.accumulate_steps)
+    red.zero_grad()
+    red.set_accumulate_steps(1)                                   # zero_grad() abandons an open update: the split count may change
+    red.set_accumulate_steps(3)
+    red.finish()
+    with pytest.raises(RuntimeError):
+        red.set_accumulate_steps(2)                               # one of three micro-batches closed: inside an update
+
+
 def test_bicubic_tap_matrices_equal_torch_interpolate():
     """functional.bicubic_tap_matrix (the tap matrices ap_resample_grid multiplies the position embedding by) against
     torch.nn.functional.interpolate(scale_factor=(h0 + 0.1) / h, mode="bicubic") -- the call of VOLO.interpolate_pos_encoding
