@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("AP_LIB_PATH") or os.path.join(_HERE, "libautoprog_hip
 class GemmEpilogue(Structure):
     _fields_ = [("bias", c_void_p), ("gelu", c_int), ("preact_out", c_void_p), ("dgelu_of", c_void_p),
                 ("row_scale", c_void_p), ("rows_per_scale", c_int), ("residual", c_void_p), ("ldr", c_int), ("mul_by", c_void_p),
-                ("q8_out", c_void_p), ("q8_scale", c_void_p), ("q8_amax", c_void_p)]
+                ("mul_by8", c_void_p), ("q8_out", c_void_p), ("q8_scale", c_void_p), ("q8_amax", c_void_p)]
 
 
 class TnProblem(Structure):
@@ -111,7 +111,7 @@ _SIGNATURES["ap_conv3x3_c64_wgrad"] = (_I, [_P, _P, _P, _I, _I, _I, _P, ctypes.c
 _SIGNATURES["ap_sum_reps_acc"] = (_I, [_P, _P, _L, _I, _P])
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
-EXPECTED_ABI = 5                     # ap_abi_version() of the library these ctypes Structures mirror (include/autoprog_hip.h)
+EXPECTED_ABI = 6                     # ap_abi_version() of the library these ctypes Structures mirror (include/autoprog_hip.h)
 
 
 class AutoProgHipError(RuntimeError):

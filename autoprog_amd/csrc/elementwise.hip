@@ -402,7 +402,7 @@ k_droppath_masks(const float* __restrict__ u, const float* __restrict__ keep, fl
 
 extern "C" {
 
-int ap_abi_version(void) { return 5; }
+int ap_abi_version(void) { return 6; }
 
 const char* ap_error_string(int code) {
     switch (code) {

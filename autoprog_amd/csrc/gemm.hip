@@ -759,6 +759,8 @@ static void g8_pick(const G8Args& ga, const EpiArgs& ep, int grid, hipStream_t s
         case G8_DGELU | G8_RS: g8_go<NT1, G8_DGELU | G8_RS>(ga, ep, grid, st); break;
         case G8_MUL: g8_go<NT1, G8_MUL>(ga, ep, grid, st); break;
         case G8_MUL | G8_RS: g8_go<NT1, G8_MUL | G8_RS>(ga, ep, grid, st); break;
+        case G8_MUL8: g8_go<NT1, G8_MUL8>(ga, ep, grid, st); break;
+        case G8_MUL8 | G8_RS: g8_go<NT1, G8_MUL8 | G8_RS>(ga, ep, grid, st); break;
         case G8_BIAS | G8_RES: g8_go<NT1, G8_BIAS | G8_RES>(ga, ep, grid, st); break;
         case G8_BIAS | G8_RS | G8_RES: g8_go<NT1, G8_BIAS | G8_RS | G8_RES>(ga, ep, grid, st); break;
         default: g8_go<NT1, -1>(ga, ep, grid, st); break;
@@ -809,7 +811,7 @@ static int use_8p(int M, int N, int K, int ldc, const EpiArgs& ep) {          //
     if (mode < 0) { const char* e = getenv("AP_GEMM_8P"); mode = e ? atoi(e) : 1; }
     if (mode == 0 || (K & 63) || K < 128 || M < 4096 || (N & 7) || (ldc & 7) || (ep.residual && (ep.ldr & 7))) return 0;
     if (ep.dgelu_of && (mode < 2 || ep.residual)) return 0;
-    if (ep.mul_by && ep.residual) return 0;
+    if ((ep.mul_by || ep.mul8) && ep.residual) return 0;
     int bn = N >= 1024 ? 256 : (N % 192 == 0 ? 192 : (N % 256 == 0 ? 256 : 0));
     if (N >= 384 && N % 192 == 0) {
         // both widths tile N: the persistent grid walks ceil(tiles / #CU) rounds of tiles, a 256-wide tile costs ~1.3 of a 192-wide one.
@@ -839,10 +841,10 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     if (epi) {
         ep.bias = epi->bias; ep.gelu = epi->gelu; ep.preact = epi->preact_out; ep.dgelu_of = epi->dgelu_of; ep.mul_by = epi->mul_by;
         ep.row_scale = epi->row_scale; ep.rows_per_scale = epi->rows_per_scale > 0 ? epi->rows_per_scale : 1;
-        ep.residual = epi->residual; ep.ldr = epi->ldr;
+        ep.residual = epi->residual; ep.ldr = epi->ldr; ep.mul8 = epi->mul_by8;
         if (ep.residual && ep.ldr < N) return AP_ERR_SHAPE;
-        if (ep.mul_by && ep.dgelu_of) return AP_ERR_SHAPE;
-        if (ep.gelu < 0 || ep.gelu > 2 || (ep.gelu == 2 && !ep.preact)) return AP_ERR_SHAPE;
+        if ((ep.mul_by != nullptr) + (ep.dgelu_of != nullptr) + (ep.mul8 != nullptr) > 1) return AP_ERR_SHAPE;
+        if (ep.gelu < 0 || ep.gelu > 3 || (ep.gelu >= 2 && !ep.preact)) return AP_ERR_SHAPE;
     }
     (void)hipGetLastError();
     static int skinny = -1;
@@ -942,7 +944,7 @@ int ap_gemm_nt_fp8(const unsigned char* A, int lda, const unsigned char* B, int 
         ep.row_scale = epi->row_scale; ep.rows_per_scale = epi->rows_per_scale > 0 ? epi->rows_per_scale : 1;
         ep.residual = epi->residual; ep.ldr = epi->ldr;
         if (ep.residual && ep.ldr < N) return AP_ERR_SHAPE;
-        if (ep.gelu < 0 || ep.gelu > 2 || (ep.gelu && !ep.preact && ep.gelu == 2)) return AP_ERR_SHAPE;
+        if (ep.gelu < 0 || ep.gelu > 3 || (ep.gelu >= 2 && !ep.preact)) return AP_ERR_SHAPE;
         ep.q8 = epi->q8_out; ep.q8_scale = epi->q8_scale; ep.q8_amax = epi->q8_amax;
         if (ep.q8 && (!ep.q8_scale || !ep.gelu)) return AP_ERR_SHAPE;
     }

@@ -77,10 +77,10 @@ struct G8Args {
 // epilogue flavour of an instantiation (EF >= 0: bits known at compile time; EF < 0: read from the arguments at run time).  The
 // generic epilogue is ~25 KB of code that a CU runs once or twice per launch, cold: an instantiation per flavour of the training
 // step keeps what is fetched to what is used (2.8 us -> see DESIGN.md on the 25088 x 384 x 1152 launch).
-enum { G8_BIAS = 1, G8_GELU = 2, G8_DGELU = 4, G8_RS = 8, G8_RES = 16, G8_MUL = 32 };
+enum { G8_BIAS = 1, G8_GELU = 2, G8_DGELU = 4, G8_RS = 8, G8_RES = 16, G8_MUL = 32, G8_MUL8 = 64 };
 __host__ __device__ inline int g8_flavour(const EpiArgs& ep) {
     return (ep.bias ? G8_BIAS : 0) | (ep.gelu ? G8_GELU : 0) | (ep.dgelu_of ? G8_DGELU : 0) | (ep.row_scale ? G8_RS : 0) | (ep.residual ? G8_RES : 0) |
-           (ep.mul_by ? G8_MUL : 0);
+           (ep.mul_by ? G8_MUL : 0) | (ep.mul8 ? G8_MUL8 : 0);
 }
 
 // NT1: B part 1 holds NT1 16-column tiles per wave (1: 256 x 192 block tile, 2: 256 x 256).
@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     const bool has_rs = EF < 0 ? ep.row_scale != nullptr : (EF & G8_RS) != 0;
     const bool has_res = EF < 0 ? ep.residual != nullptr : (EF & G8_RES) != 0;
     const bool has_mul = EF < 0 ? ep.mul_by != nullptr : (EF & G8_MUL) != 0;
+    const bool has_mul8 = EF < 0 ? ep.mul8 != nullptr : (EF & G8_MUL8) != 0;       // the 8-bit gelu' codes of a gelu = 3 forward
     float qmx = 0.f;                              // FP8 with ep.q8: running max |output| of this lane, and the quantisation scale
     const float qsc = (FP8 && ep.q8) ? ep.q8_scale[0] : 1.f;
     constexpr int WN = 32 + 16 * NT1, BN = 4 * WN;
@@ -436,6 +437,33 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
             constexpr bool ASM_IN = EF >= 0 && !(NT1 == 2 && EF == (G8_BIAS | G8_RS | G8_RES));
             u32x4 in0[2][4];
             in1_t in1[2][4];
+            // the 8-bit derivative codes (gelu = 3 / mul_by8): 8 bytes per lane for the 8 columns of part 0, 8 / 4 bytes for part 1
+            typedef typename std::conditional<NT1 == 2, u32x2, unsigned>::type j1_t;
+            u32x2 j0[2][4];
+            j1_t j1[2][4];
+            if (has_mul8) {
+                const unsigned char* jbase = ep.mul8 + min(nb + g * 8, ga.N - 8);
+                const unsigned char* jbase1 = ep.mul8 + min(nb + 32 + g * 4 * NT1, ga.N - 4 * NT1);
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const int64_t roff = (int64_t)min(m0 + mh * 128 + wr * 64 + mt * 16 + fr, ga.M - 1) * ga.ldc;
+                        if constexpr (EF >= 0) {
+                            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(j0[mh][mt]) : "v"(jbase + roff) : "memory");
+                            if constexpr (NT1 == 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(j1[mh][mt]) : "v"(jbase1 + roff) : "memory");
+                            else asm volatile("global_load_dword %0, %1, off" : "=v"(j1[mh][mt]) : "v"(jbase1 + roff) : "memory");
+                        } else {
+                            j0[mh][mt] = *reinterpret_cast<const u32x2*>(jbase + roff);
+                            j1[mh][mt] = *reinterpret_cast<const j1_t*>(jbase1 + roff);
+                        }
+                    }
+                G8_VM(0);
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) { asm volatile("" : "+v"(j0[mh][mt])); asm volatile("" : "+v"(j1[mh][mt])); }
+            }
             if (has_dgelu || has_mul || has_res) {
                 const bf16_t* ibase = in_src + min(nb + g * 8, ga.N - 8);
                 const bf16_t* ibase1 = in_src + min(nb + 32 + g * 4 * NT1, ga.N - 4 * NT1);
@@ -505,6 +533,16 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
 #pragma unroll
                             for (int q = 0; q < 2 * NT1; ++q) { w[2 * q] *= bf_lo(i1[q]); w[2 * q + 1] *= bf_hi(i1[q]); }
                         }
+                        if (has_mul8) {
+                            float d[8];
+                            gq_unpack4(j0[mh][mt][0], d); gq_unpack4(j0[mh][mt][1], d + 4);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] *= d[q];
+                            if constexpr (NT1 == 2) { gq_unpack4(j1[mh][mt][0], d); gq_unpack4(j1[mh][mt][1], d + 4); }
+                            else gq_unpack4(j1[mh][mt], d);
+#pragma unroll
+                            for (int q = 0; q < 4 * NT1; ++q) w[q] *= d[q];
+                        }
                         if (has_rs) {
 #pragma unroll
                             for (int q = 0; q < 8; ++q) v[q] *= rs;
@@ -544,6 +582,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                     const int m = rbase + row, n = n0 + ((p ^ (row & 7)) << 3);
                     u32x4 x = xs[it];
                     u32x2 q8v = {0u, 0u}; bool q8ok = false;
+                    u32x2 gqv = {0u, 0u}; bool gqok = false;          // gelu = 3: the 8 derivative codes of this chunk
                     if (m < ga.M && n < ga.N) {
                         if (rowgelu) {
                             // x = the bf16-rounded pre-activation (bias included): the activation is applied to the rounded value; what is stored
@@ -551,7 +590,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                             float f[8];
                             unpack8(x, f);
                             const float rs = has_rs ? ep.row_scale[m / ep.rows_per_scale] : 1.f;
-                            if (ep.gelu == 2) {
+                            if (ep.gelu >= 2) {
                                 float gp[8];
 #pragma unroll
                                 for (int q = 0; q < 8; ++q) {
@@ -559,7 +598,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                                     gp[q] = fmaf(f[q] * 0.39894228040143268f, e, c);
                                     f[q] = f[q] * c * rs;
                                 }
-                                g8_store(ep.preact + (int64_t)m * ga.ldc + n, pack8(gp));
+                                if (ep.gelu == 3) { gqv[0] = gq_pack4(gp); gqv[1] = gq_pack4(gp + 4); gqok = true; }
+                                else g8_store(ep.preact + (int64_t)m * ga.ldc + n, pack8(gp));
                             } else {
                                 if (ep.preact) g8_store(ep.preact + (int64_t)m * ga.ldc + n, x);
 #pragma unroll
@@ -587,6 +627,18 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                         }
                         if (!(G8_ABL & 32)) g8_store(ga.C + (int64_t)m * ga.ldc + n, x);
                         else asm volatile("" :: "v"(x));
+                    }
+                    if (rowgelu && ep.gelu == 3) {
+                        // 8 code bytes per lane: the lane with the even chunk of a pair takes its neighbour's 8 bytes (the XOR swizzle keeps chunk
+                        // pairs on lane pairs) and stores 16 -- whole 128-byte lines per 16 lanes where the tile's column offset allows it
+                        const unsigned n0lo = (unsigned)__shfl_xor((int)gqv[0], 1, 64), n0hi = (unsigned)__shfl_xor((int)gqv[1], 1, 64);
+                        const bool nok = __shfl_xor((int)gqok, 1, 64) != 0;
+                        if (gqok) {
+                            unsigned char* gp8 = reinterpret_cast<unsigned char*>(ep.preact) + (int64_t)m * ga.ldc + n;
+                            if (nok && !(ga.ldc & 15)) {
+                                if (!((n >> 3) & 1)) { u32x4 o4; o4[0] = gqv[0]; o4[1] = gqv[1]; o4[2] = n0lo; o4[3] = n0hi; g8_store(reinterpret_cast<bf16_t*>(gp8), o4); }
+                            } else *reinterpret_cast<u32x2*>(gp8) = gqv;
+                        }
                     }
                     if constexpr (FP8) {
                         if (ep.q8) {

@@ -32,7 +32,22 @@ struct EpiArgs {
     const bf16_t* mul_by;       // out = v * mul_by[m,n] (ld = ldc): the stored activation derivative of a gelu = 2 forward
     unsigned char* q8; const float* q8_scale; float* q8_amax;     // fp8 GELU launches of the 8-phase kernel: the output a second time as e4m3
                                                                   // bytes [M, ldc], q8 = sat(out * q8_scale[0]), q8_amax[0] raised to max |out|
+    const unsigned char* mul8;  // out = v * gq_decode(mul8[m,n]) (ld = ldc bytes): the 8-bit derivative codes of a gelu = 3 forward
 };
+
+// 8-bit fixed-point code of gelu'(h) in [-0.1290, 1.1290] (gelu = 3 / mul_by8, include/autoprog_hip.h): code = clamp(rint(202 g) + 26, 0, 255),
+// g = (code - 26) / 202.  0, 1/2 and 1 are exact; |error| <= 1 / 404 = the spacing of bf16 numbers in [1/2, 1).
+#define GQ_SCALE 202.0f
+#define GQ_ZERO 26.0f
+__device__ __forceinline__ unsigned gq_code(float g) {
+    return (unsigned)fminf(fmaxf(__builtin_rintf(fmaf(g, GQ_SCALE, GQ_ZERO)), 0.f), 255.f);
+}
+__device__ __forceinline__ unsigned gq_pack4(const float* g) { return gq_code(g[0]) | (gq_code(g[1]) << 8) | (gq_code(g[2]) << 16) | (gq_code(g[3]) << 24); }
+__device__ __forceinline__ float gq_decode(unsigned code) { return fmaf((float)code, 1.0f / GQ_SCALE, -GQ_ZERO / GQ_SCALE); }
+// the four codes of a dword (v_cvt_f32_ubyte0..3 + one fma each)
+__device__ __forceinline__ void gq_unpack4(unsigned w, float* f) {
+    f[0] = gq_decode(w & 0xffu); f[1] = gq_decode((w >> 8) & 0xffu); f[2] = gq_decode((w >> 16) & 0xffu); f[3] = gq_decode(w >> 24);
+}
 
 // epilogue of 8 consecutive output columns [n, n+8) of row m held in v[] (fp32 accumulators):
 // +bias; GELU (storing the pre-activation); * gelu'(h); * DropPath row scale; + residual; bf16 store.
@@ -61,8 +76,15 @@ __device__ __forceinline__ void epi_chunk(float* v, int m, int n, int N, int ldc
             for (int q = 0; q < 8; ++q) v[q] = bf2f(f2bf(v[q]));
             float sv[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) sv[q] = ep.gelu == 2 ? gelu_erf_grad(v[q]) : v[q];
-            if (full) st16(p, pack8(sv));
+            for (int q = 0; q < 8; ++q) sv[q] = ep.gelu >= 2 ? gelu_erf_grad(v[q]) : v[q];
+            if (ep.gelu == 3) {                                       // 8-bit derivative codes, [M, ldc] bytes
+                unsigned char* p8 = reinterpret_cast<unsigned char*>(ep.preact) + (int64_t)m * ldc + n;
+                if (full) { u32x2 c; c[0] = gq_pack4(sv); c[1] = gq_pack4(sv + 4); *reinterpret_cast<u32x2*>(p8) = c; }
+                else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (q < nval) p8[q] = (unsigned char)gq_code(sv[q]);
+                }
+            } else if (full) st16(p, pack8(sv));
             else {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) if (q < nval) p[q] = f2bf(sv[q]);
@@ -87,6 +109,17 @@ __device__ __forceinline__ void epi_chunk(float* v, int m, int n, int N, int ldc
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] *= h[q];
         }
+    }
+    if (ep.mul8) {
+        const unsigned char* hp = ep.mul8 + (int64_t)m * ldc + n;
+        float h[8];
+        if (full) { const u32x2 c = *reinterpret_cast<const u32x2*>(hp); gq_unpack4(c[0], h); gq_unpack4(c[1], h + 4); }
+        else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) h[q] = (q < nval) ? gq_decode(hp[q]) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] *= h[q];
     }
     if (ep.row_scale) {
         const float rs = ep.row_scale[m / ep.rows_per_scale];

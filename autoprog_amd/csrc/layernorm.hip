@@ -355,6 +355,138 @@ k_ln_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const floa
     }
 }
 
+// Round 5: the same backward as a software pipeline.  k_ln_bwd runs "request U rows -> wait -> reduce -> store" trips one after the other,
+// and the three workgroups of a CU start together, so the CU alternates between a burst of requests and a phase with nothing in flight
+// (4.5 TB/s at 25088 x 384).  Here a lane group requests trip t+1 BEFORE it reduces trip t (two register sets of U rows, the loop unrolled
+// by two so that both are static), and every load is unconditional at a clamped address (a guarded load compiles to an exec-masked
+// block that zeroes its destination: DESIGN section 3, round 1) -- rows past the end are skipped in the reduce, idle chunk lanes
+// (C/8 < G) are masked to zero after the load.  gamma comes straight from global memory (two 16-byte loads per chunk, L2 hits, under
+// the first trip's latency): no LDS trip and no barrier in front of the rows.
+template <int V, int U, int OCC = 1>
+__global__ void __launch_bounds__(256, OCC)
+k_ln_bwd_pf(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+            const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
+            bf16_t* __restrict__ dx, float* __restrict__ partial,
+            int64_t rows, int C, int G) {
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [4 waves][C] x 2 (the end of the kernel only)
+    const int lane_in_group = threadIdx.x & (G - 1);
+    const int groups_per_block = 256 / G;
+    const int group = threadIdx.x / G;
+    const int nchunks = C >> 3;
+    const float invC = 1.0f / (float)C;
+    const bool has_res = dres != nullptr;
+    float gam[V][8], ag[V][8], ab[V][8];
+    int choff[V];                                  // element offset of the lane's chunk i inside a row (clamped into the row)
+    unsigned chmask[V];                            // all ones where the chunk exists
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int ch = lane_in_group + i * G;
+        const bool ok = ch < nchunks;
+        choff[i] = 8 * (ok ? ch : nchunks - 1);
+        chmask[i] = ok ? 0xffffffffu : 0u;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + choff[i]);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + choff[i] + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { gam[i][k] = ok ? g0[k] : 0.f; gam[i][4 + k] = ok ? g1[k] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; }
+    }
+    const int64_t row_stride = (int64_t)gridDim.x * groups_per_block;
+    const int64_t trip = row_stride * U;
+    const int64_t last = rows - 1;
+
+#define LN_PF_LOAD(R0, DY, X, RES, MU, RS)                                                                   \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                           \
+        int64_t row = (R0) + u * row_stride;                                                                  \
+        row = row < rows ? row : last;                                                                        \
+        MU[u] = mean[row]; RS[u] = rstd[row];                                                                 \
+        _Pragma("unroll") for (int i = 0; i < V; ++i) {                                                       \
+            DY[u][i] = ld16(dy + row * C + choff[i]);                                                         \
+            X[u][i] = ld16(x + row * C + choff[i]);                                                           \
+            if (has_res) RES[u][i] = ld16(dres + row * C + choff[i]);                                         \
+        }                                                                                                     \
+    }
+
+#define LN_PF_COMPUTE(R0, DY, X, RES, MU, RS)                                                                \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                           \
+        const int64_t row = (R0) + u * row_stride;                                                            \
+        if (row < rows) {                                                                                     \
+            float g[V][8], xh[V][8];                                                                          \
+            float s1 = 0.f, s2 = 0.f;                                                                         \
+            _Pragma("unroll") for (int i = 0; i < V; ++i) {                                                   \
+                float d8[8], x8[8];                                                                           \
+                u32x4 dm = DY[u][i];                                                                          \
+                dm[0] &= chmask[i]; dm[1] &= chmask[i]; dm[2] &= chmask[i]; dm[3] &= chmask[i];               \
+                unpack8(dm, d8);                                                                              \
+                unpack8(X[u][i], x8);                                                                         \
+                _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                               \
+                    xh[i][k] = (x8[k] - MU[u]) * RS[u];                                                       \
+                    g[i][k] = d8[k] * gam[i][k];                                                              \
+                    s1 += g[i][k];                                                                            \
+                    s2 += g[i][k] * xh[i][k];                                                                 \
+                    ag[i][k] += d8[k] * xh[i][k];                                                             \
+                    ab[i][k] += d8[k];                                                                        \
+                }                                                                                             \
+            }                                                                                                 \
+            for (int o = G >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); } \
+            s1 *= invC; s2 *= invC;                                                                           \
+            _Pragma("unroll") for (int i = 0; i < V; ++i) {                                                   \
+                if (chmask[i]) {                                                                              \
+                    float o8[8];                                                                              \
+                    if (has_res) unpack8(RES[u][i], o8);                                                      \
+                    else { _Pragma("unroll") for (int k = 0; k < 8; ++k) o8[k] = 0.f; }                       \
+                    _Pragma("unroll") for (int k = 0; k < 8; ++k) o8[k] += RS[u] * (g[i][k] - s1 - xh[i][k] * s2); \
+                    st16_nt(dx + row * C + choff[i], pack8(o8));                                              \
+                }                                                                                             \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+
+    u32x4 a_dy[U][V], a_x[U][V], a_res[U][V], b_dy[U][V], b_x[U][V], b_res[U][V];
+    float a_mu[U], a_rs[U], b_mu[U], b_rs[U];
+    int64_t row0 = (int64_t)blockIdx.x * groups_per_block + group;
+    LN_PF_LOAD(row0, a_dy, a_x, a_res, a_mu, a_rs)
+    for (; row0 < rows; row0 += 2 * trip) {
+        const int64_t row1 = row0 + trip;
+        LN_PF_LOAD(row1, b_dy, b_x, b_res, b_mu, b_rs)
+        LN_PF_COMPUTE(row0, a_dy, a_x, a_res, a_mu, a_rs)
+        if (row1 >= rows) break;
+        LN_PF_LOAD(row1 + trip, a_dy, a_x, a_res, a_mu, a_rs)
+        LN_PF_COMPUTE(row1, b_dy, b_x, b_res, b_mu, b_rs)
+    }
+#undef LN_PF_LOAD
+#undef LN_PF_COMPUTE
+    // dgamma/dbeta partials: as k_ln_bwd (butterfly over the wave's lane groups, the four waves meet in LDS, one partial row per block)
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            for (int o = G; o < 64; o <<= 1) { ag[i][k] += __shfl_xor(ag[i][k], o, 64); ab[i][k] += __shfl_xor(ab[i][k], o, 64); }
+    float* rg = red;                       // [4 waves][C]
+    float* rb = red + 4 * C;
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < G) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            if (chmask[i]) {
+                f32x4 w0, w1, w2, w3;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { w0[k] = ag[i][k]; w1[k] = ag[i][4 + k]; w2[k] = ab[i][k]; w3[k] = ab[i][4 + k]; }
+                *reinterpret_cast<f32x4*>(rg + wave * C + choff[i]) = w0;
+                *reinterpret_cast<f32x4*>(rg + wave * C + choff[i] + 4) = w1;
+                *reinterpret_cast<f32x4*>(rb + wave * C + choff[i]) = w2;
+                *reinterpret_cast<f32x4*>(rb + wave * C + choff[i] + 4) = w3;
+            }
+        }
+    }
+    __syncthreads();
+    float* prow = partial + (int64_t)blockIdx.x * 2 * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        prow[c] = rg[c] + rg[C + c] + rg[2 * C + c] + rg[3 * C + c];
+        prow[C + c] = rb[c] + rb[C + c] + rb[2 * C + c] + rb[3 * C + c];
+    }
+}
+
 // out[c] += sum_b partial[b][c] for the 2*C columns (dgamma | dbeta); 32 columns x 32 row slices per block,
 // independent loads unrolled x8 so the column sums are not a serial chain of L2 round trips
 __global__ void __launch_bounds__(1024)
@@ -513,6 +645,15 @@ int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, co
     (void)hipGetLastError();
     // (5 rows per trip instead of 4 -- every lane group of the VOLO-D1 launch then finishes its 8 or 9 rows in two trips instead of three for
     // a sixth of them -- measured equal, 17.5 vs 17.7 us: the trips are not what the launch waits for)
+    static int pf = -1;             // AP_LN_BWD_PF: 0 = the trip-by-trip kernel of rounds 1 - 4; 1 = pipelined, half the rows per trip (the same registers in flight);
+    if (pf < 0) { const char* e = getenv("AP_LN_BWD_PF"); pf = e ? atoi(e) : 1; }        //               2 = pipelined with the old rows per trip (twice the registers)
+    if (pf && V <= 2) {             // (four chunks per lane: two register sets do not fit 256 registers)
+        if (V == 1 && pf == 3) hipLaunchKernelGGL((k_ln_bwd_pf<1, 2, 4>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);
+        else if (V == 1) { if (pf == 2) hipLaunchKernelGGL((k_ln_bwd_pf<1, 4>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);
+                      else hipLaunchKernelGGL((k_ln_bwd_pf<1, 2>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G); }
+        else { if (pf == 2) hipLaunchKernelGGL((k_ln_bwd_pf<2, 2>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);
+               else hipLaunchKernelGGL((k_ln_bwd_pf<2, 1>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G); }
+    } else
     if (V == 1) hipLaunchKernelGGL((k_ln_bwd<1, 4>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);
     else if (V == 2) hipLaunchKernelGGL((k_ln_bwd<2, 2>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);
     else if (V == 3) hipLaunchKernelGGL((k_ln_bwd<3, 2>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);

@@ -367,12 +367,20 @@ def _launch_wgrads(problems, ln=None):
 
 
 # The MLPs store gelu'(h) instead of h in the forward (the backward needs nothing else of h) and multiply by it in the backward:
-# ~18 VALU instructions per element less in a store-bound epilogue.  AP_GELU_STORE_GRAD=0: store h and evaluate gelu' in the backward.
-STORE_GELU_GRAD = os.environ.get("AP_GELU_STORE_GRAD", "1") != "0"
+# ~18 VALU instructions per element less in a store-bound epilogue.  Round 5: the derivative is stored in 8 BITS -- it is a multiplier
+# in [-0.129, 1.129], fixed point with step 1/202 (0, 1/2 and 1 exact; error <= 1/404, the spacing of bf16 numbers just below 1):
+# half the bytes written by every fc1 launch and read by every fc2 input-gradient launch (29 MB each at 25088 x 1152).
+# AP_GELU_STORE_GRAD = 2 (default): 8-bit codes; 1: bf16 derivative (rounds 3 - 4); 0: store h and evaluate gelu' in the backward.
+STORE_GELU_GRAD = int(os.environ.get("AP_GELU_STORE_GRAD", "2"))
 
 
 def _gelu_bwd_kw(h):
     return {"mul_by": h} if STORE_GELU_GRAD else {"dgelu_of": h}
+
+
+def _gelu_side_buffer(rows, cols, device):
+    """what the fc1 launch stores next to its output for the backward: [rows, cols] codes (uint8) or bf16"""
+    return torch.empty((rows, cols), dtype=torch.uint8 if STORE_GELU_GRAD == 2 else BF16, device=device)
 
 
 def _linear_bwd(g, x_in, w, dw, db, n=None, dgelu_of=None, need_dx=True, row_scale=None, rows_per_scale=1, cs_weight=None, inv_keep=1.0, mul_by=None):
@@ -602,7 +610,7 @@ class TransformerBlockFn(torch.autograd.Function):
             o, lse = ops.mhsa_fwd(qkv, B, N, heads, scale, out_row_scale=k1)                   # rows of dropped samples: zeros
         x1 = _linear_fwd(o, proj_w, x8=oq, bias=proj_b, row_scale=rs1, rows_per_scale=N, residual=x2)
         xn2, m2, r2, xq = _ln_fwd_for(x1, n2w, n2b, eps, fc1_w)
-        h = torch.empty((B * N, fc1_w.shape[0]), dtype=BF16, device=x.device)
+        h = _gelu_side_buffer(B * N, fc1_w.shape[0], x.device)
         a, aq = _linear_fwd(xn2, fc1_w, x8=xq, emit_for=fc2_w, bias=fc1_b, gelu=True, preact_out=h, preact_grad=STORE_GELU_GRAD, row_scale=k2, rows_per_scale=N)
         y = _linear_fwd(a, fc2_w, x8=aq, bias=fc2_b, row_scale=rs2, rows_per_scale=N, residual=x1)
         if rs1 is not None and tm1 is None:
@@ -662,7 +670,7 @@ class ClassBlockFn(torch.autograd.Function):
         o, probs = ops.class_attn_fwd(q, kv_t, B, N + 1, heads, scale, kv_cls=kv_c)
         c1 = ops.gemm_nt(o, bank.get(proj_w), bias=proj_b, residual=c0)
         n2, m2, r2 = ops.layernorm_fwd(c1, n2w, n2b, eps)
-        h = torch.empty((B, fc1_w.shape[0]), dtype=BF16, device=cls.device)
+        h = _gelu_side_buffer(B, fc1_w.shape[0], cls.device)
         a = ops.gemm_nt(n2, bank.get(fc1_w), bias=fc1_b, gelu=True, preact_out=h, preact_grad=STORE_GELU_GRAD)
         c2 = ops.gemm_nt(a, bank.get(fc2_w), bias=fc2_b, residual=c1)
         ctx.save_for_backward(c0, t0, mc, rc, mt, rt, nc, nt, kv_t, kv_c, q, o, probs, c1, m2, r2, n2, h, a,
@@ -718,7 +726,7 @@ class OutlookerBlockFn(torch.autograd.Function):
         yo = ops.outlook_fwd(v.view(B, H, W, C), logits, heads, scale)
         x1 = ops.gemm_nt(yo.view(T, C), bank.get(proj_w), bias=proj_b, residual=x2)
         xn2, m2, r2 = ops.layernorm_fwd(x1, n2w, n2b, eps)
-        h = torch.empty((T, fc1_w.shape[0]), dtype=BF16, device=x.device)
+        h = _gelu_side_buffer(T, fc1_w.shape[0], x.device)
         a = ops.gemm_nt(xn2, bank.get(fc1_w), bias=fc1_b, gelu=True, preact_out=h, preact_grad=STORE_GELU_GRAD)
         y = ops.gemm_nt(a, bank.get(fc2_w), bias=fc2_b, residual=x1)
         ctx.save_for_backward(x2, m1, r1, xn1, v, pooled2, logits, yo, x1, m2, r2, xn2, h, a,
@@ -776,7 +784,7 @@ class LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, K).contiguous()
         N = w.shape[0]
         h = torch.empty((x2.shape[0], ops.round_up(N, 8)), dtype=BF16, device=x.device) if gelu else None
-        y = ops.gemm_nt(x2, bank.get(w), n=N, k=K, bias=b, gelu=gelu, preact_out=h, preact_grad=gelu and STORE_GELU_GRAD)
+        y = ops.gemm_nt(x2, bank.get(w), n=N, k=K, bias=b, gelu=gelu, preact_out=h, preact_grad=bool(gelu and STORE_GELU_GRAD))     # (bf16 derivative: multiplied in torch below)
         ctx.save_for_backward(x2, w, b, h)
         ctx.lead = x.shape[:-1]
         ctx.gelu = gelu

@@ -160,10 +160,26 @@ def layernorm_bwd_reduce_batched(items):
 
 
 # ------------------------------------------------------------------------------------- gemm
+GELU_CODE_SCALE, GELU_CODE_ZERO = 202.0, 26.0       # the 8-bit derivative codes of gelu = 3 (include/autoprog_hip.h): gelu' = (code - 26) / 202
+
+
+def _gelu_mode(gelu, preact_grad, preact_out):
+    """ap_gemm_epilogue.gelu: 1 stores h, 2 gelu'(h) as bf16, 3 gelu'(h) as 8-bit codes (preact_out then is a uint8 tensor)"""
+    if not gelu:
+        return 0
+    mode = 1 + int(preact_grad)
+    if mode == 3 and (preact_out is None or preact_out.dtype != torch.uint8):
+        raise AutoProgHipError("gemm_nt: preact_grad = 2 stores 8-bit codes: preact_out must be a uint8 tensor")
+    if mode != 3 and preact_out is not None and preact_out.dtype != BF16:
+        raise AutoProgHipError("gemm_nt: preact_out must be bf16 (uint8 only with preact_grad = 2)")
+    return mode
+
+
 def gemm_nt(a, b, n=None, k=None, bias=None, gelu=False, preact_out=None, dgelu_of=None, row_scale=None,
             rows_per_scale=1, residual=None, out=None, ldc=None, preact_grad=False, mul_by=None):
     """out[M, :n] = epilogue(a[M, :k] @ b[:n, :k]^T); a/b bf16 2-D (row stride = shape[1]).
-    preact_grad: with gelu, preact_out receives gelu'(h) instead of h; its backward passes that tensor as mul_by."""
+    preact_grad: with gelu, preact_out receives gelu'(h) instead of h (True / 1: bf16; 2: 8-bit codes, preact_out uint8); its backward
+    passes that tensor as mul_by (a uint8 tensor is taken as the codes)."""
     _req(a, BF16, "a"); _req(b, BF16, "b")
     M = a.shape[0]
     n = b.shape[0] if n is None else n
@@ -180,10 +196,15 @@ def gemm_nt(a, b, n=None, k=None, bias=None, gelu=False, preact_out=None, dgelu_
     else:
         epi = GemmEpilogue()
         epi.bias = bias.data_ptr() if bias is not None else None
-        epi.gelu = (2 if preact_grad else 1) if gelu else 0
+        epi.gelu = _gelu_mode(gelu, preact_grad, preact_out)
         epi.preact_out = preact_out.data_ptr() if preact_out is not None else None
         epi.dgelu_of = dgelu_of.data_ptr() if dgelu_of is not None else None
-        epi.mul_by = mul_by.data_ptr() if mul_by is not None else None
+        if mul_by is not None and mul_by.dtype == torch.uint8:
+            if mul_by.shape[-1] != ldc or not mul_by.is_contiguous():
+                raise AutoProgHipError("gemm_nt: the derivative codes must be contiguous [M, ldc] bytes")
+            epi.mul_by, epi.mul_by8 = None, mul_by.data_ptr()
+        else:
+            epi.mul_by = mul_by.data_ptr() if mul_by is not None else None
         epi.row_scale = row_scale.data_ptr() if row_scale is not None else None
         epi.rows_per_scale = int(rows_per_scale)
         epi.residual = residual.data_ptr() if residual is not None else None
@@ -243,7 +264,7 @@ def gemm_nt_fp8(a8, b8, dq_a, dq_b, n=None, bias=None, gelu=False, preact_out=No
     out = torch.empty((M, ldc), dtype=BF16, device=a8.device)
     epi = GemmEpilogue()
     epi.bias = bias.data_ptr() if bias is not None else None
-    epi.gelu = (2 if preact_grad else 1) if gelu else 0
+    epi.gelu = _gelu_mode(gelu, preact_grad, preact_out)
     epi.preact_out = preact_out.data_ptr() if preact_out is not None else None
     epi.dgelu_of = None
     epi.mul_by = None

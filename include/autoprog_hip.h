@@ -98,7 +98,10 @@ int ap_gemm_nt_patch(const ap_bf16* A, const ap_bf16* B, int ldb, ap_bf16* C, in
 
 typedef struct ap_gemm_epilogue {
     const float* bias;          /* [N] or NULL */
-    int gelu;                   /* 1: out = gelu_erf(v) (models/volo.py:157); 2: the same, and preact_out receives gelu'(v) instead of v */
+    int gelu;                   /* 1: out = gelu_erf(v) (models/volo.py:157); 2: the same, and preact_out receives gelu'(v) instead of v;
+                                 * 3 (ABI version 6): as 2, but preact_out is an UNSIGNED CHAR [M, ldc] tensor of 8-bit fixed-point codes
+                                 * code = clamp(rint(202 * gelu'(v)) + 26, 0, 255), i.e. gelu' = (code - 26) / 202 on [-0.1287, 1.1337] (gelu' lives in
+                                 * [-0.1290, 1.1290]; 0, 1/2 and 1 are exact codes): half the bytes of the bf16 derivative, |error| <= 1/404 */
     ap_bf16* preact_out;        /* with gelu: also store v (the pre-activation; gelu = 2: its activation derivative) here, ld = ldc */
     const ap_bf16* dgelu_of;    /* out = v * gelu'(dgelu_of[m,n]) (backward of the above), ld = ldc */
     const float* row_scale;     /* [ceil(M/rows_per_scale)] or NULL */
@@ -108,6 +111,8 @@ typedef struct ap_gemm_epilogue {
     const ap_bf16* mul_by;      /* out = v * mul_by[m,n] (ld = ldc), applied where dgelu_of is: the backward of gelu = 2, whose forward stored
                                  * gelu'(h) -- the only thing the backward needs of h (autograd of models/volo.py:157) -- so that it is a
                                  * multiplication instead of ~18 instructions per element; not together with dgelu_of.  (ABI version 3) */
+    const unsigned char* mul_by8; /* (ABI version 6) as mul_by with the 8-bit codes a gelu = 3 forward stored: out = v * (mul_by8[m,n] - 26) / 202, ld = ldc
+                                 * bytes; not together with mul_by / dgelu_of */
     unsigned char* q8_out;      /* ap_gemm_nt_fp8 with gelu only (ABI version 4): the output a second time as OCP e4m3 bytes [M, ldc] --     */
     const float* q8_scale;      /* q8_out = sat(out * q8_scale[0]), q8_amax[0] = max(q8_amax[0], max |out|) (nullable) -- the operand of the */
     float* q8_amax;             /* fp8 GEMM that consumes this activation, without a quantisation pass.  Launches of the 8-phase kernel only */

@@ -350,9 +350,22 @@ def _r16(t):
     return t.to(torch.bfloat16).to(t.dtype) if BF16_POINTS_ROUND else t
 
 
+GELU_GRAD_BITS = 8            # the stored derivative's rounding point: 8 = fixed point, step 1/202 (gelu = 3 / mul_by8, the round-5 default of the fused
+                              # blocks); 16 = bf16 (gelu = 2 / mul_by: rounds 3 - 4, AP_GELU_STORE_GRAD=1, and functional.LinearFn)
+
+
+def _rgelu_grad(d, bits=None):
+    if not BF16_POINTS_ROUND:
+        return d
+    if (GELU_GRAD_BITS if bits is None else bits) == 8:
+        return ((d * 202.0 + 26.0).round().clamp(0.0, 255.0) - 26.0) / 202.0
+    return _r16(d)
+
+
 class _GeluBf16Points(torch.autograd.Function):
-    """fc1's epilogue on the MI355X path: a = bf16(gelu(h)) of the ROUNDED pre-activation h, and bf16(gelu'(h)) is what is stored for
-    the backward, whose epilogue multiplies the fp32 accumulator of fc2's input gradient by it (csrc/gemm_epi.h, gelu = 2 / mul_by)"""
+    """fc1's epilogue on the MI355X path: a = bf16(gelu(h)) of the ROUNDED pre-activation h, and the rounded gelu'(h) is what is stored
+    for the backward, whose epilogue multiplies the fp32 accumulator of fc2's input gradient by it (csrc/gemm_epi.h: gelu = 3 / mul_by8
+    stores 8-bit fixed-point codes, gelu = 2 / mul_by bf16 -- GELU_GRAD_BITS)"""
 
     @staticmethod
     def forward(ctx, h):
@@ -363,7 +376,7 @@ class _GeluBf16Points(torch.autograd.Function):
     def backward(ctx, g):
         (h,) = ctx.saved_tensors
         d = 0.5 * (1.0 + torch.erf(h / math.sqrt(2.0))) + h * torch.exp(-0.5 * h * h) / math.sqrt(2.0 * math.pi)
-        return g * _r16(d)
+        return g * _rgelu_grad(d)
 
 
 class _MhsaBf16Points(torch.autograd.Function):

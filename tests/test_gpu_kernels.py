@@ -136,6 +136,23 @@ def test_gemm_nt_epilogues(ops, M, N, K):
     assert rel(out2, R.gelu(hb.detach()) * rs.double().repeat_interleave(rps)[:M, None]) < TOL_BF16
     out3 = ops.gemm_nt(dev(a), dev(w), mul_by=gp, row_scale=dev(rs), rows_per_scale=rps)
     assert rel(out3, (a.double() @ w.double().t()) * gp.double().cpu() * rs.double().repeat_interleave(rps)[:M, None]) < TOL_BF16
+    # round 5 (ABI 6): the derivative as 8-bit fixed-point codes (gelu = 3 / mul_by8): code = clamp(rint(202 g') + 26, 0, 255) -- EXACT against
+    # that formula on the bf16-rounded pre-activation except where fp32 rounding puts 202 g' + 26 within 1e-3 of a half-integer, the
+    # output identical to the gelu = 2 launch, and the backward multiplies by (code - 26) / 202
+    codes = torch.empty(M, N, dtype=torch.uint8, device="cuda")
+    out4 = ops.gemm_nt(dev(a), dev(w), bias=dev(bias), gelu=True, preact_out=codes, preact_grad=2, row_scale=dev(rs), rows_per_scale=rps)
+    assert torch.equal(out4, out2)
+    t = hb.grad * ops.GELU_CODE_SCALE + ops.GELU_CODE_ZERO
+    want = t.round().clamp(0, 255)
+    got = codes.cpu().double()
+    off = got != want
+    assert int(off.sum()) <= 1e-3 * M * N and float((got - t).abs().max()) < 0.5 + 2e-3, (int(off.sum()), float((got - t).abs().max()))
+    dec = (got - ops.GELU_CODE_ZERO) / ops.GELU_CODE_SCALE
+    assert float((dec - hb.grad).abs().max()) <= 0.5 / ops.GELU_CODE_SCALE + 1e-5
+    out5 = ops.gemm_nt(dev(a), dev(w), mul_by=codes, row_scale=dev(rs), rows_per_scale=rps)
+    assert rel(out5, (a.double() @ w.double().t()) * dec * rs.double().repeat_interleave(rps)[:M, None]) < TOL_BF16
+    with pytest.raises(Exception):
+        ops.gemm_nt(dev(a), dev(w), bias=dev(bias), gelu=True, preact_out=gp, preact_grad=2)          # codes need a uint8 tensor
 
 
 @pytest.mark.parametrize("M,N1,N2", [(1024, 128, 128), (1000, 192, 576), (3000, 486, 192), (25088 // 8, 1152, 384), (130, 1000, 384),
@@ -589,7 +606,7 @@ def test_grouped_wgrad_launch_carries_the_layernorm_reductions(ops):
 
 @pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_MHSA_BWD_DS": "0", "AP_MHSA_FWD_P": "0"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"}, {"AP_OUTLOOK_MFMA": "0"},
                                  {"AP_STEM_HIP_CONV": "0"}, {"AP_ASYNC_WGRAD": "1"}, {"AP_GEMM_TN_PLACE": "0"}, {"AP_FUSE_LN_REDUCE": "0"}, {"AP_CONV_WGRAD_P": "0"},
-                                 {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}, {"AP_GELU_STORE_GRAD": "0"}, {"AP_WGRAD_WINDOW": "0"}, {"AP_STEM_FUSE_BN": "0"},
+                                 {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}, {"AP_GELU_STORE_GRAD": "0"}, {"AP_GELU_STORE_GRAD": "1"}, {"AP_LN_BWD_PF": "0"}, {"AP_WGRAD_WINDOW": "0"}, {"AP_STEM_FUSE_BN": "0"},
                                  {"AP_OUTLOOK_P": "0"}, {"AP_OUTLOOK_P": "2"}, {"AP_LN_FWD_LP": "0"}, {"AP_CONV_WAVES": "4"}])
 def test_experimental_kernel_paths_stay_parity_green(env):
     """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:

@@ -23,9 +23,29 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def build(variant, classes, img=64, dpr=0.0):
+def build(variant, classes, img=64, dpr=0.0, stem=16):
     from autoprog_amd.models import create_model
-    return create_model("model_variant", variant=variant, num_classes=classes, img_size=img, drop_path_rate=dpr, stem_hidden_dim=16)
+    return create_model("model_variant", variant=variant, num_classes=classes, img_size=img, drop_path_rate=dpr, stem_hidden_dim=stem)
+
+
+def forbid_torch_convolutions(monkeypatch):
+    """any torch convolution on a GPU tensor fails the test: the network under test must run its stem on csrc/conv7.hip / conv.hip and
+    the patch-addressed GEMMs (as test_hip_stem64_vs_reference_golden does for the stem alone)"""
+    import torch.nn.functional as F
+    real = F.conv2d
+
+    def guarded(inp, *a, **k):
+        if inp.is_cuda:
+            raise AssertionError("torch conv2d called on the GPU: this network's stem must run on the HIP convolution kernels")
+        return real(inp, *a, **k)
+    monkeypatch.setattr(F, "conv2d", guarded)
+    real_call = torch.nn.Conv2d.forward
+
+    def guarded_module(self, inp):
+        if inp.is_cuda:
+            raise AssertionError("nn.Conv2d.forward called on the GPU: this network's stem must run on the HIP convolution kernels")
+        return real_call(self, inp)
+    monkeypatch.setattr(torch.nn.Conv2d, "forward", guarded_module)
 
 
 def load_sd(model, d, prefix):
@@ -74,6 +94,55 @@ def test_volo_train_eval_vs_reference_golden(tag, variant, classes):
     with torch.no_grad():
         y = model(x)
     assert rel(y, d[tag + ".eval_y"]) < 3e-2
+
+
+def test_volo_on_the_shipped_stem_vs_reference_golden(monkeypatch):
+    """VERDICT r4, missing 3: a reference-generated WHOLE network on the stem the BASELINE configs ship (stem_hidden_dim = 64:
+    csrc/conv7.hip, csrc/conv.hip with BatchNorm in the staging, the patch-addressed projection) -- tests/golden/volo_full64.npz,
+    tools/gen_golden.py::gen_volo_full64: the reference's volo_h2_l3 at 64 px, batch 8 (8 x 32 x 32 samples per BatchNorm channel),
+    stress weights as volo_full.  No torch convolution may run.  Train outputs, loss, every parameter gradient, eval output."""
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    forbid_torch_convolutions(monkeypatch)
+    tag, classes = "h2_l3_s64", 16
+    d = load("volo_full64")
+    model = load_sd(build("volo_h2_l3", classes, stem=64), d, tag).cuda().train()
+    x = torch.from_numpy(d[tag + ".x"]).cuda()
+    target = torch.from_numpy(d[tag + ".target"]).cuda()
+    np.random.seed(int(d[tag + ".np_seed"]))
+    x_cls, x_aux, bb = model(x)
+    assert list(bb) == [int(v) for v in d[tag + ".bbox"]]
+    e_cls, e_aux = rel(x_cls, d[tag + ".x_cls"]), rel(x_aux, d[tag + ".x_aux"])
+    loss = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=classes)((x_cls, x_aux, bb), target)
+    loss.backward()
+    num = den = 0.0
+    worst = {}
+    for name, p in model.named_parameters():
+        g = torch.from_numpy(d[tag + ".g." + name]).double()
+        diff = p.grad.detach().double().cpu() - g
+        num += float(diff.pow(2).sum())
+        den += float(g.pow(2).sum())
+        if float(g.norm()) > 1e-6:
+            worst[name] = float(diff.norm() / g.norm())
+    glob = (num / den) ** 0.5
+    print("volo_full64: outputs %.4f / %.4f, loss %.5f (reference %.5f), global gradient rel-L2 %.4f; worst tensors %s"
+          % (e_cls, e_aux, float(loss), float(d[tag + ".loss"]), glob, sorted(((round(v, 3), k) for k, v in worst.items()), reverse=True)[:8]))
+    assert e_cls < 3e-2 and e_aux < 3e-2, (e_cls, e_aux)
+    assert abs(float(loss.detach()) - float(d[tag + ".loss"])) < 5e-3 * float(d[tag + ".loss"])
+    assert glob < FULL64_GLOBAL_TOL, glob
+    bad = {k: v for k, v in worst.items() if v > FULL64_TENSOR_TOL}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+    load_sd(model, d, tag)                  # the train forward above updated the BN running stats once more
+    model.eval()
+    with torch.no_grad():
+        y = model(x)
+    assert rel(y, d[tag + ".eval_y"]) < 3e-2
+
+
+# bounds of the 64-wide-stem network fixture = 1.5x the first GPU run of the test (round 5): outputs 1.3e-2 / 1.0e-2, loss 7.02132 against
+# 7.02070, all gradients as one vector 0.0296, worst tensors 0.133 / 0.118 (the first two BatchNorm biases), 0.110 / 0.101 / 0.094 (stem
+# convolution weights and the first BatchNorm weight), everything behind the stem <= 0.053.  (volo_full's h2_l3 on the 16-wide MIOpen stem
+# at batch 2: 0.058 as one vector, worst 0.187.)
+FULL64_GLOBAL_TOL, FULL64_TENSOR_TOL = 0.045, 0.2
 
 
 def test_supernet_subconfigs_vs_reference_golden():
@@ -635,19 +704,20 @@ def test_loss_curve_realistic_init_vs_reference():
     assert dev.max() < 0.1 * np.abs(d["losses_bf16_autocast"] - d["losses"]).max()
 
 
-def test_late_state_vs_reference_golden():
+def test_late_state_vs_reference_golden(monkeypatch):
     """Parity on a TRAINED network (VERDICT r3, Weak 2; tests/golden/late_state.npz, tools/gen_golden.py::gen_late_state): the
     reference's volo_h4_l6 after 300 fp64 AdamW steps on its batch (loss 5.4 -> 3.0), its weights as fp32, evaluated by the reference in
-    fp64 on a fresh mix-token draw.  The HIP model loads those weights and runs the same step.  Asserted (bounds from the first GPU
-    run of this test, stated next to the measured values): logits <= 2e-2 rel-L2, loss <= 1e-2 relative, all parameter gradients as ONE
-    vector <= 0.1 rel-L2, no tensor above 0.25 outside the 16-wide conv stem of this fixture (which runs through MIOpen in bf16
-    under a batch-of-8 BatchNorm) and 0.5 inside it.  The fixture also records the reference's own network under torch.autocast(bf16)
-    on these weights: logits off by 107 % / 135 %, loss 5.73 instead of 3.30, gradients off by a factor of 100 -- the CPU autocast
-    recipe (LayerNorm and softmax in bf16 as well) does not survive this state at all, so it is no yardstick here; the fp64 numbers are."""
+    fp64 on a fresh mix-token draw.  The HIP model loads those weights and runs the same step.  Round 5: the fixture's network has the
+    SHIPPED 64-wide stem (tools/gen_golden.py LATE_STEM; no torch convolution may run).  Asserted (bounds next to the measured values):
+    logits <= 2e-2 rel-L2, loss <= 1e-2 relative, all parameter gradients as ONE vector <= 0.1 rel-L2, no tensor above 0.2 -- the stem
+    included (rounds 3 - 4, 16-wide MIOpen stem: 0.25 / 0.5 inside the stem).  The fixture also records the reference's own network
+    under torch.autocast("cpu", bfloat16) on these weights: logits 2.1e-3 / 4.0e-3, gradients 7.4e-2 as one vector, median 5.9e-2, worst
+    0.119 -- with the 64-wide stem that recipe survives this state and IS a yardstick: the HIP kernels sit at 7.6e-2 / 6.0e-2 / 0.137."""
     from autoprog_amd.loss import TokenLabelCrossEntropy
+    forbid_torch_convolutions(monkeypatch)            # round 5: the fixture runs on the shipped 64-wide stem (tools/gen_golden.py LATE_STEM)
     d = load("late_state")
     classes = int(d["classes"])
-    model = build("volo_h4_l6", classes)
+    model = build("volo_h4_l6", classes, stem=64)
     sd = {k[2:]: torch.from_numpy(np.asarray(v)) for k, v in d.items() if k.startswith("w.")}
     model.load_state_dict(sd, strict=True)
     model = model.cuda().train()
@@ -671,16 +741,19 @@ def test_late_state_vs_reference_golden():
           % (e_cls, e_aux, float(loss), float(d["loss"]), one, float(np.median(list(errs.values()))), [(k, round(v, 4)) for k, v in worst]))
     assert e_cls < 2e-2 and e_aux < 2e-2, (e_cls, e_aux)
     assert abs(float(loss) - float(d["loss"])) < 1e-2 * float(d["loss"])
-    # measured (round 4): logits 2.1e-3 / 7.2e-3, loss 3.29842 against 3.29845, gradients: one vector 7.8e-2, median 5.7e-2, worst
-    # 0.20 (patch_embed.conv.4.bias), 0.16 (aux_head.weight) -- in this memorising state the gradients themselves are small
+    # measured (round 5, 64-wide HIP stem): logits 2.1e-3 / 4.9e-3, loss 3.29509 against 3.29513, gradients: one vector 7.6e-2, median
+    # 6.0e-2, worst 0.137 / 0.121 / 0.121 (stem convolution weights) -- in this memorising state the gradients themselves are small
     # differences of large terms, which is why they sit an order of magnitude above the first-step gradients of the same network
+    # (round 4, 16-wide MIOpen stem: 7.8e-2 / 5.7e-2 / 0.20)
     assert one < 0.1, one
-    bad = {k: v for k, v in errs.items() if v > (0.5 if k.startswith("patch_embed.conv") else 0.25)}
+    yard = float(d["yard_bf16_autocast_one_vector"])
+    assert one < 1.25 * yard, (one, yard)        # within a quarter of the reference's own bf16-autocast recipe on the same state
+    bad = {k: v for k, v in errs.items() if v > 0.2}
     assert not bad, bad
     # The same step against the oracle WITH the pipeline's bf16 rounding points (volo_forward(bf16_points=True)): the yardstick the
-    # CPU-autocast run could not be.  Measured: that oracle -- exact arithmetic between the same roundings -- is itself 7.3e-2 away from
-    # the fp64 reference as one gradient vector; the HIP kernels 7.8e-2 from the reference and 8.1e-2 from that oracle (logits 2.4e-3 /
-    # 8.2e-3, loss 3.29842 / 3.29851): in this memorising state ANY two evaluations that round to bf16 part by ~8 %, the gradients
+    # second yardstick.  Measured (round 5): that oracle -- exact arithmetic between the same roundings -- is itself 7.7e-2 away from
+    # the fp64 reference as one gradient vector; the HIP kernels 7.6e-2 from the reference and 6.5e-2 from that oracle (logits 2.0e-3 /
+    # 2.8e-3, loss 3.29509 / 3.29514): in this memorising state ANY two evaluations that round to bf16 part by ~7 %, the gradients
     # being small differences of large terms -- the kernels sit where an exact implementation of the 16-bit recipe sits.
     p64 = {k: v.double().clone() for k, v in sd.items()}
     for v in p64.values():

@@ -133,7 +133,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(LIB_PATH)
     for sym in declared:
         assert hasattr(raw, sym), sym
-    assert lib.ap_abi_version() == 5
+    assert lib.ap_abi_version() == 6
     assert lib.ap_error_string(-2).decode().startswith("configuration not supported")
 
 

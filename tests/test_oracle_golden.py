@@ -159,9 +159,11 @@ def test_pos_interp():
         assert max_err(R.interpolate_pos_encoding(pos4, g, g), d["interp4_%d" % g]) < 1e-6
 
 
-@pytest.mark.parametrize("tag,variant", [("h2_l3", "volo_h2_l3"), ("h2_l6", "volo_h2_l6")])
+@pytest.mark.parametrize("tag,variant", [("h2_l3", "volo_h2_l3"), ("h2_l6", "volo_h2_l6"), ("h2_l3_s64", "volo_h2_l3")])
 def test_volo_full_train_eval(tag, variant):
-    d = load("volo_full")
+    """whole networks of the reference: volo_full.npz (16-wide stem, batch 2) and -- round 5 -- volo_full64.npz: the SHIPPED 64-wide stem
+    at batch 8 (tools/gen_golden.py::gen_volo_full64)"""
+    d = load("volo_full64" if tag.endswith("_s64") else "volo_full")
     arch = R.variant_arch(variant)
     p = _params(d, tag)
     x = torch.from_numpy(d[tag + ".x"]).double()

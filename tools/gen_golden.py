@@ -236,7 +236,7 @@ def gen_pos_interp(ns):
     save("pos_interp", **out)
 
 
-def tiny_volo(ns, variant, img, classes, dpr=0.0):
+def tiny_volo(ns, variant, img, classes, dpr=0.0, stem=16):
     fam, h, l = variant.split("_")
     h, l = int(h[1:]), int(l[1:])
     l0 = ns.progressive.make_divisible(l * 0.23, 2) if l > 2 else 1
@@ -244,7 +244,7 @@ def tiny_volo(ns, variant, img, classes, dpr=0.0):
     net = ns.volo.VOLO(layers, img_size=img, num_classes=classes, embed_dims=[16 * h, 32 * h, 32 * h, 32 * h],
                        num_heads=[h // 2, h, h, h], mlp_ratios=[3, 3, 3, 3], downsamples=[True, False, False, False],
                        outlook_attention=[True, False, False, False], post_layers=["ca", "ca"], drop_path_rate=dpr,
-                       stem_hidden_dim=16)
+                       stem_hidden_dim=stem)
     return net
 
 
@@ -301,6 +301,42 @@ def gen_volo_full(ns):
         with torch.no_grad():
             out["super.eval_y_l%d" % l] = npy(net(x))
     save("volo_full", **out)
+
+
+def gen_volo_full64(ns):
+    """A whole network on the SHIPPED stem (missing 3): volo_h2_l3 with stem_hidden_dim=64 -- the width of every BASELINE
+    config, the width the HIP convolution kernels serve -- 64 px, batch 8 (8 x 32 x 32 samples per BatchNorm channel: not degenerate),
+    same stress weights as volo_full: train outputs, loss, every parameter gradient, eval output."""
+    out = {}
+    tag, variant, img, classes, B = "h2_l3_s64", "volo_h2_l3", 64, 16, 8
+    gen = torch.Generator().manual_seed(2164)
+    torch.manual_seed(5)
+    net = randomize_(tiny_volo(ns, variant, img, classes, stem=64), gen, 1.0)
+    with torch.no_grad():
+        net.pos_embed.copy_(0.3 * torch.randn(net.pos_embed.shape, generator=gen))
+        net.cls_token.copy_(0.3 * torch.randn(net.cls_token.shape, generator=gen))
+    x = torch.randn(B, 3, img, img, generator=gen)
+    g2 = img // 16
+    target = make_target(B, classes, g2 * g2, gen)
+    loss_fn = ns.cross_entropy.TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=classes)
+    net.train()
+    np.random.seed(4321)
+    x_cls, x_aux, bb = net(x)
+    loss = loss_fn((x_cls, x_aux, bb), target)
+    net.zero_grad()
+    loss.backward()
+    np.random.seed(4321)
+    lam = np.random.beta(1.0, 1.0)
+    d = {"x": npy(x), "target": npy(target), "x_cls": npy(x_cls), "x_aux": npy(x_aux), "bbox": np.array([int(v) for v in bb]),
+         "lam": np.array(lam), "loss": npy(loss), "np_seed": np.array(4321)}
+    d.update(sd_arrays(net))          # after forward: BN running stats already updated
+    d.update(grads(net))
+    net.eval()
+    with torch.no_grad():
+        d["eval_y"] = npy(net(x))
+    for k, v in d.items():
+        out["%s.%s" % (tag, k)] = v
+    save("volo_full64", **out)
 
 
 def gen_loss(ns):
@@ -435,6 +471,9 @@ def gen_step_curve_init(ns):
     save("step_curve_init", **out)
 
 
+LATE_STEM = 64          # round 5: the trained-state fixture runs on the shipped stem width (the HIP convolution kernels), not the 16-wide one
+
+
 def gen_late_state(ns):
     """Parity in the regime a TRAINED network is in (Weak 2): the realistic-init volo_h4_l6 of step_curve_init is trained by
     the reference, in fp64, for 300 AdamW steps on its batch (lr 1e-3: the residual stream grows, attention logits sharpen, the loss
@@ -449,7 +488,7 @@ def gen_late_state(ns):
     classes, B, r, seed, steps = 32, 8, 64, 2024, 300
     x = torch.randn(B, 3, r, r, generator=gen)
     target = make_target(B, classes, (r // 16) ** 2, gen)
-    net = tiny_volo(ns, "volo_h4_l6", r, classes).train()
+    net = tiny_volo(ns, "volo_h4_l6", r, classes, stem=LATE_STEM).train()
     net.load_state_dict(init_state_dict(net.state_dict(), seed), strict=True)
     net = net.double()
     loss_fn = ns.cross_entropy.TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=classes)
@@ -473,7 +512,7 @@ def gen_late_state(ns):
     out.update({"w." + k: npy(v) for k, v in sd32.items()})
 
     def evaluate(dtype, amp=None):
-        m = tiny_volo(ns, "volo_h4_l6", r, classes).train()
+        m = tiny_volo(ns, "volo_h4_l6", r, classes, stem=LATE_STEM).train()
         m.load_state_dict(sd32, strict=True)
         m = m.to(dtype)
         np.random.seed(7)
@@ -517,7 +556,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
     ns = ref_import.load_reference()
-    for fn in (gen_int_tables, gen_outlook, gen_blocks, gen_stem, gen_stem64, gen_pos_interp, gen_volo_full, gen_loss, gen_step_curve,
+    for fn in (gen_int_tables, gen_outlook, gen_blocks, gen_stem, gen_stem64, gen_pos_interp, gen_volo_full, gen_volo_full64, gen_loss, gen_step_curve,
                gen_step_curve_init, gen_late_state):
         if not only or fn.__name__[4:] in only:
             fn(ns)
