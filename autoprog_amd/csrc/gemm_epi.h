@@ -42,7 +42,16 @@ struct EpiArgs {
 __device__ __forceinline__ unsigned gq_code(float g) {
     return (unsigned)fminf(fmaxf(__builtin_rintf(fmaf(g, GQ_SCALE, GQ_ZERO)), 0.f), 255.f);
 }
-__device__ __forceinline__ unsigned gq_pack4(const float* g) { return gq_code(g[0]) | (gq_code(g[1]) << 8) | (gq_code(g[2]) << 16) | (gq_code(g[3]) << 24); }
+// four codes into a dword: v_cvt_pk_u8_f32 saturates to [0, 255] and places the byte; its input is already an integer (v_rndne_f32),
+// so the instruction's own rounding does not matter: fma + rndne + cvt_pk per element
+__device__ __forceinline__ unsigned gq_pack4(const float* g) {
+    unsigned w = 0;
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(g[0], GQ_SCALE, GQ_ZERO)), 0, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(g[1], GQ_SCALE, GQ_ZERO)), 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(g[2], GQ_SCALE, GQ_ZERO)), 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(g[3], GQ_SCALE, GQ_ZERO)), 3, w);
+    return w;
+}
 __device__ __forceinline__ float gq_decode(unsigned code) { return fmaf((float)code, 1.0f / GQ_SCALE, -GQ_ZERO / GQ_SCALE); }
 // the four codes of a dword (v_cvt_f32_ubyte0..3 + one fma each)
 __device__ __forceinline__ void gq_unpack4(unsigned w, float* f) {

@@ -8,6 +8,9 @@
 struct AdamArgs {
     float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt;   // bc1 = 1-beta1^t, bc2_sqrt = sqrt(1-beta2^t)
     float gscale;                                      // gradient pre-scale (1/world_size: the data-parallel mean)
+    const float* gnorm_sq;                             // device scalar: sum of squares of the UNSCALED slab (ap_sumsq_f32), or nullptr
+    float max_norm;                                    // clip_grad_norm_ bound on the scaled gradient (with gnorm_sq)
+    float clip_value;                                  // clip_grad_value_ bound on the scaled gradient elements (> 0), else 0
     int n_ema;
     float decay[4];
     float* ema[4];
@@ -19,10 +22,20 @@ k_adamw_ema(float* __restrict__ p, const float* __restrict__ g, float* __restric
     const int64_t nv = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const float step_size = a.lr / a.bc1;
+    // gradient clipping folded into the update (prog/scaler.py:60-68 -> timm dispatch_clip_grad, main_prog.py:1019-1027):
+    // mode 'norm' = torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (||g|| + 1e-6)) with ||g|| the norm of the MEAN gradient
+    // (gscale * the norm of the slab, which holds the all-reduced SUM under a deferred mean); mode 'value': clamp every element
+    float gs = a.gscale;
+    if (a.gnorm_sq) {
+        const float total = sqrtf(a.gnorm_sq[0]) * a.gscale;
+        gs *= fminf(1.0f, a.max_norm / (total + 1e-6f));
+    }
+    const float cv = a.clip_value;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         float4 gg = reinterpret_cast<const float4*>(g)[i];
-        gg.x *= a.gscale; gg.y *= a.gscale; gg.z *= a.gscale; gg.w *= a.gscale;
+        gg.x *= gs; gg.y *= gs; gg.z *= gs; gg.w *= gs;
+        if (cv > 0.f) { gg.x = fminf(fmaxf(gg.x, -cv), cv); gg.y = fminf(fmaxf(gg.y, -cv), cv); gg.z = fminf(fmaxf(gg.z, -cv), cv); gg.w = fminf(fmaxf(gg.w, -cv), cv); }
         float4 mm = reinterpret_cast<float4*>(m)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
         const uchar4 wm = reinterpret_cast<const uchar4*>(wd_mask)[i];
@@ -54,13 +67,60 @@ k_adamw_ema(float* __restrict__ p, const float* __restrict__ g, float* __restric
     }
 }
 
+// sum of squares of a flat fp32 slab in two deterministic passes: 1024 per-workgroup partials (fp64 inside a workgroup's tree),
+// then one workgroup adds them in order.  16 bytes per lane, every load of a thread's sweep independent.
+__global__ void __launch_bounds__(256)
+k_sumsq_partial(const float* __restrict__ x, int64_t n, double* __restrict__ partial) {
+    __shared__ double red[4];
+    const int64_t nv = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        s0 = fmaf(v.x, v.x, s0); s1 = fmaf(v.y, v.y, s1); s2 = fmaf(v.z, v.z, s2); s3 = fmaf(v.w, v.w, s3);
+    }
+    double s = (double)s0 + (double)s1 + (double)s2 + (double)s3;
+    if (blockIdx.x == 0 && threadIdx.x == 0) for (int64_t i = nv << 2; i < n; ++i) s += (double)x[i] * (double)x[i];     // (n % 4 tail)
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(256)
+k_sumsq_final(const double* __restrict__ partial, int count, float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = (float)red[0];
+}
+
+extern "C" size_t ap_sumsq_workspace(void) { return (size_t)1024 * sizeof(double); }
+
+extern "C" int ap_sumsq_f32(const float* x, int64_t n, float* out, void* workspace, size_t ws_bytes, ap_stream_t stream) {
+    if (!x || !out || !workspace) return AP_ERR_NULL;
+    if (n <= 0 || ws_bytes < ap_sumsq_workspace() || ((uintptr_t)x & 15)) return AP_ERR_SHAPE;
+    int64_t grid = (n / 4 + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_sumsq_partial, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, n, static_cast<double*>(workspace));
+    hipLaunchKernelGGL(k_sumsq_final, dim3(1), dim3(256), 0, (hipStream_t)stream, static_cast<const double*>(workspace), (int)grid, out);
+    return ap_check_launch();
+}
+
 extern "C" int ap_adamw_ema_step(float* p, const float* g, float* m, float* v, const unsigned char* wd_mask, int64_t n,
                                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                 const float* gnorm_sq, float max_norm, float clip_value,
                                  float* const* ema, const float* ema_decay, int n_ema, ap_bf16* p_bf16, ap_stream_t stream) {
     if (!p || !g || !m || !v || !wd_mask) return AP_ERR_NULL;
     if (n <= 0 || (n & 3) || n_ema < 0 || n_ema > 4 || step < 1) return AP_ERR_SHAPE;
+    if (gnorm_sq && !(max_norm > 0.f)) return AP_ERR_SHAPE;
     AdamArgs a;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.gscale = grad_scale;
+    a.gnorm_sq = gnorm_sq; a.max_norm = max_norm; a.clip_value = clip_value > 0.f ? clip_value : 0.f;
     a.bc1 = 1.0f - powf(beta1, (float)step);
     a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
     a.n_ema = n_ema;

@@ -126,19 +126,42 @@ class FlatAdamWEma:
             check(lib.ap_batched_transpose_bf16(self.p16.data_ptr(), self.p16_t.data_ptr(), self._tr_desc.data_ptr(), self._tr_count,
                                                 self._tr_tiles, ops._stream()), "ap_batched_transpose_bf16")
 
-    def step(self):
+    def step(self, clip_grad=None, clip_mode="norm"):
+        """one AdamW + EMA update from the gradient slab.  clip_grad / clip_mode: the reference's `--clip-grad` / `--clip-mode`
+        (main_prog.py:129-132; prog/scaler.py:60-68 calls timm's dispatch_clip_grad between backward and optimizer.step()):
+          'norm'  -- torch.nn.utils.clip_grad_norm_(parameters, clip_grad): ONE pass over the flat slab for the global norm
+                     (ap_sumsq_f32, a device scalar), the factor min(1, clip / (norm + 1e-6)) is applied inside the update kernel;
+          'value' -- clip_grad_value_: every gradient element clamped to [-clip, clip] inside the update kernel.
+        Both act on the MEAN gradient: with GradientBucketReducer(defer_mean=True) the slab still holds the all-reduced SUM and the
+        1/world factor is applied first -- clipping the slab from outside before step() would be off by `world`.
+        `last_grad_norm` (device scalar, 'norm' mode) is the norm of the mean gradient before clipping."""
         self.step_count += 1
         g = self.reducer.flat
         if self.g is None:                                   # slab length not a multiple of 4: padded copy
             gp = torch.zeros(self.n_pad, dtype=torch.float32, device=g.device)
             gp[:g.numel()] = g
             g = gp
+        gscale = float(self.reducer.take_pending_scale())
+        gnorm_ptr, max_norm, clip_value = None, 0.0, 0.0
+        if clip_grad is not None and float(clip_grad) > 0:
+            if clip_mode == "norm":
+                if getattr(self, "_sumsq_ws", None) is None:
+                    self._sumsq_ws = torch.empty(lib.ap_sumsq_workspace() // 8, dtype=torch.float64, device=g.device)
+                    self._gnorm_sq = torch.zeros(1, dtype=torch.float32, device=g.device)
+                check(lib.ap_sumsq_f32(g.data_ptr(), g.numel(), self._gnorm_sq.data_ptr(), self._sumsq_ws.data_ptr(), self._sumsq_ws.numel() * 8,
+                                       ops._stream()), "ap_sumsq_f32")
+                gnorm_ptr, max_norm = self._gnorm_sq.data_ptr(), float(clip_grad)
+                self.last_grad_norm = self._gnorm_sq.sqrt() * gscale
+            elif clip_mode == "value":
+                clip_value = float(clip_grad)
+            else:
+                raise NotImplementedError("FlatAdamWEma.step: clip_mode %r (the reference's default is 'norm'; 'agc' is not on the flat-slab path)" % (clip_mode,))
         lr, wd = float(self.param_groups[0]["lr"]), float(self.param_groups[0]["weight_decay"])
         if float(self.param_groups[1]["lr"]) != lr:
             raise ValueError("FlatAdamWEma: both parameter groups must share one learning rate (timm schedulers do)")
         check(lib.ap_adamw_ema_step(self.p.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.wd_mask.data_ptr(),
-                                    self.n_pad, lr, self.betas[0], self.betas[1], self.eps, wd, self.step_count, float(self.reducer.take_pending_scale()),
-                                    self._ema_ptrs, self._ema_decay, len(self.ema), self.p16.data_ptr(),
+                                    self.n_pad, lr, self.betas[0], self.betas[1], self.eps, wd, self.step_count, gscale,
+                                    gnorm_ptr, max_norm, clip_value, self._ema_ptrs, self._ema_decay, len(self.ema), self.p16.data_ptr(),
                                     ops._stream()), "ap_adamw_ema_step")
         self._refresh_transposes()
         from . import functional

@@ -324,9 +324,19 @@ int ap_conv7_s2d_wgrad(const ap_bf16* xs, const ap_bf16* dz, float* dw_oihw, int
  * + n_ema <= 4 ModelEmaV2 updates (main_prog.py:1030-1033) over one flat fp32 slab of n parameters
  * (n % 4 == 0).  wd_mask[i] != 0 selects decoupled weight decay for element i; `ema` / `ema_decay`
  * are HOST arrays of n_ema device pointers / decays; `step` is the 1-based update count. */
+/* sum of squares of a flat fp32 slab (16-byte aligned): out[0] = sum x[i]^2, deterministic (1024 ordered partials in `workspace` of
+ * ap_sumsq_workspace() bytes).  The global gradient norm of torch.nn.utils.clip_grad_norm_ (timm dispatch_clip_grad 'norm',
+ * prog/scaler.py:60-68, main_prog.py:129-132,1019-1027) is one pass over the gradient slab.  (ABI version 6) */
+size_t ap_sumsq_workspace(void);
+int ap_sumsq_f32(const float* x, int64_t n, float* out, void* workspace, size_t ws_bytes, ap_stream_t stream);
+/* gradient clipping is folded into the update (ABI version 6): gnorm_sq (nullable DEVICE scalar = ap_sumsq_f32 of g) with max_norm > 0
+ * scales the gradient by min(1, max_norm / (grad_scale * sqrt(gnorm_sq[0]) + 1e-6)) -- clip_grad_norm_ on the MEAN gradient, read on
+ * the device (no host round trip); clip_value > 0 clamps every element of the scaled gradient to [-clip_value, clip_value]
+ * (clip_grad_value_); 0 / NULL: no clipping */
 int ap_adamw_ema_step(float* p, const float* g, float* m, float* v, const unsigned char* wd_mask, int64_t n,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                       float grad_scale /* g is multiplied by this first: 1/world_size turns the all-reduced SUM into the mean */,
+                      const float* gnorm_sq, float max_norm, float clip_value,
                       float* const* ema, const float* ema_decay, int n_ema,
                       ap_bf16* p_bf16 /* nullable: bf16 copy of the updated parameters, same offsets */,
                       ap_stream_t stream);

@@ -44,7 +44,7 @@ def dev(t):
 # ------------------------------------------------------------------------------------------
 def test_abi_loaded(ops):
     from autoprog_amd._lib import lib, LIB_PATH
-    assert lib.ap_abi_version() == 5
+    assert lib.ap_abi_version() == 6
     assert LIB_PATH.endswith("libautoprog_hip.so")
 
 
@@ -146,9 +146,15 @@ def test_gemm_nt_epilogues(ops, M, N, K):
     want = t.round().clamp(0, 255)
     got = codes.cpu().double()
     off = got != want
-    assert int(off.sum()) <= 1e-3 * M * N and float((got - t).abs().max()) < 0.5 + 2e-3, (int(off.sum()), float((got - t).abs().max()))
+    # (the kernel rounds ITS fp32 pre-activation to bf16; the fp64 one of this test can fall on the other side of a tie for an element or
+    # two: there gelu' differs by up to one bf16 step of h -- below one code)
+    assert int(off.sum()) <= 1e-3 * M * N and float((got - t).abs().max()) < 1.0, (int(off.sum()), float((got - t).abs().max()))
     dec = (got - ops.GELU_CODE_ZERO) / ops.GELU_CODE_SCALE
-    assert float((dec - hb.grad).abs().max()) <= 0.5 / ops.GELU_CODE_SCALE + 1e-5
+    assert float((dec - hb.grad).abs().max()) <= 1.0 / ops.GELU_CODE_SCALE
+    near = ((got - t).abs() <= 0.5 + 2e-3).double().mean()
+    assert float(near) >= 1.0 - 1e-3, float(near)
+    # against the launch's OWN derivative (the gelu = 2 output, a bf16 rounding of the same fp32 value): within half a code + that rounding
+    assert float((got - (gp.double().cpu() * ops.GELU_CODE_SCALE + ops.GELU_CODE_ZERO)).abs().max()) <= 0.5 + ops.GELU_CODE_SCALE * 2.0 ** -8
     out5 = ops.gemm_nt(dev(a), dev(w), mul_by=codes, row_scale=dev(rs), rows_per_scale=rps)
     assert rel(out5, (a.double() @ w.double().t()) * dec * rs.double().repeat_interleave(rps)[:M, None]) < TOL_BF16
     with pytest.raises(Exception):

@@ -145,6 +145,45 @@ def test_deferred_mean_is_folded_into_the_update():
     assert torch.allclose(outs[0], outs[1], atol=1e-7)
 
 
+@pytest.mark.parametrize("mode,clip", [("norm", 0.05), ("norm", 1e3), ("value", 0.01)])
+def test_gradient_clipping_inside_the_flat_slab_step(mode, clip):
+    """FlatAdamWEma.step(clip_grad=, clip_mode=) (missing 5; reference: prog/scaler.py:60-68 -> timm dispatch_clip_grad,
+    main_prog.py:129-132,1019-1027) against torch.nn.utils.clip_grad_norm_ / clip_grad_value_ + torch.optim.AdamW on the same gradients,
+    three steps; with a DEFERRED data-parallel mean pending (the slab holds the all-reduced SUM of world = 4 ranks) the clipping acts on
+    the mean: equal to scaling the slab first.  'norm' with a bound far above the norm is the unclipped update."""
+    from autoprog_amd.dist import GradientBucketReducer
+    from autoprog_amd.optim import FlatAdamWEma
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(24, 32), torch.nn.GELU(), torch.nn.Linear(32, 16)).cuda()
+    ref = copy.deepcopy(net)
+    red = GradientBucketReducer(list(net.parameters()), world_size=1, defer_mean=True)
+    opt = FlatAdamWEma(net, red, lr=1e-2, weight_decay=0.05)
+    dec = [p for n, p in ref.named_parameters() if p.dim() > 1]
+    nodec = [p for n, p in ref.named_parameters() if p.dim() <= 1]
+    ropt = torch.optim.AdamW([{"params": dec, "weight_decay": 0.05}, {"params": nodec, "weight_decay": 0.0}], lr=1e-2)
+    world = 4
+    for step in range(3):
+        torch.manual_seed(10 + step)
+        x = torch.randn(8, 24, device="cuda")
+        red.zero_grad()
+        (net(x).pow(2).mean() * world).backward()            # the slab as an all-reduce over 4 ranks would leave it: the SUM
+        red._pending_scale = 1.0 / world                      # ... with the mean deferred to the update kernel (finish() sets this)
+        ropt.zero_grad()
+        ref(x).pow(2).mean().backward()
+        if mode == "norm":
+            total = torch.nn.utils.clip_grad_norm_(ref.parameters(), clip)
+        else:
+            torch.nn.utils.clip_grad_value_(ref.parameters(), clip)
+        ropt.step()
+        opt.step(clip_grad=clip, clip_mode=mode)
+        if mode == "norm":
+            assert abs(float(opt.last_grad_norm) - float(total)) < 1e-5 * max(1.0, float(total)), (float(opt.last_grad_norm), float(total))
+        for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+            assert torch.allclose(p.detach(), q.detach(), atol=2e-6, rtol=1e-5), (step, n, float((p - q).abs().max()))
+    with pytest.raises(NotImplementedError):
+        opt.step(clip_grad=0.1, clip_mode="agc")
+
+
 def test_stage_transition_on_live_slabs():
     """FlatAdamWEma.grow: depth grows 3 -> 5 on ONE volo_h2_l6 supernet.  The active sub-network
     afterwards equals what the reference's route builds (extract the previous stage's EMA state dicts, grow_clone_ema them into a
