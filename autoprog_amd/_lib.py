@@ -109,6 +109,13 @@ _SIGNATURES["ap_conv3x3_c64_pack"] = (_I, [_P, _P, _P, _P])
 _SIGNATURES["ap_conv3x3_c64"] = (_I, [_P, _P, _P, _I, _I, _I, _P, _P])
 _SIGNATURES["ap_conv3x3_c64_wgrad_workspace"] = (ctypes.c_size_t, [_I, _I, _I])
 _SIGNATURES["ap_conv3x3_c64_wgrad"] = (_I, [_P, _P, _P, _I, _I, _I, _P, ctypes.c_size_t, _P])
+_SIGNATURES["ap_conv7_s2d_ld"] = (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P])
+_SIGNATURES["ap_conv7_s2d_wgrad_ld"] = (_I, [_P, _P, _I, _P, _I, _I, _I, _P, ctypes.c_size_t, _P])
+_SIGNATURES["ap_conv3x3_c128_pack"] = (_I, [_P, _P, _P, _P])
+_SIGNATURES["ap_conv3x3_c128_stat_rows"] = (_I, [_I, _I, _I])
+_SIGNATURES["ap_conv3x3_c128"] = (_I, [_P, _P, _P, _I, _I, _I, _P, _P])
+_SIGNATURES["ap_conv3x3_c128_wgrad_workspace"] = (ctypes.c_size_t, [_I, _I, _I])
+_SIGNATURES["ap_conv3x3_c128_wgrad"] = (_I, [_P, _P, _P, _I, _I, _I, _P, ctypes.c_size_t, _P])
 # ap_sum_reps_acc(x, out, n, reps, stream)
 _SIGNATURES["ap_sum_reps_acc"] = (_I, [_P, _P, _L, _I, _P])
 

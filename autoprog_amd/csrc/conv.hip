@@ -430,7 +430,9 @@ k_conv3x3_c64_wgrad(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
 template <int TR, bool PRE_BN = false, int NW = 4>
 __global__ void __launch_bounds__(64 * NW)
 k_conv3x3_c64_wgrad_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ slab, int H, int W,
-                      int tiles_x, int tiles_y, int ntiles, BnIn bn = BnIn{nullptr, nullptr, nullptr, nullptr}) {
+                      int tiles_x, int tiles_y, int ntiles, BnIn bn = BnIn{nullptr, nullptr, nullptr, nullptr}, int xs = CV_C, int dys = CV_C) {
+    // xs / dys: pixel strides (elements) of x and dy -- 64 for the 64-channel tensors; 128 when the operands are 64-channel halves of
+    // 128-channel feature maps (ap_conv3x3_c128_wgrad: the pointers then carry the channel offset)
     constexpr int NTH = 64 * NW, PSTEP = NTH / 8, COT = NW == 8 ? 2 : 4;      // threads, pixels per staging sweep, 16-channel output tiles per wave
     constexpr int DPIX = TR * CW_T, APIX = (TR + 2) * CW_PW;
     constexpr int ND = DPIX * 8 / NTH, NA = (APIX * 8 + NTH - 1) / NTH;
@@ -478,19 +480,19 @@ k_conv3x3_c64_wgrad_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ d
     auto gload = [&](int t) {
         int b, ty0, tx0;
         origin(t, b, ty0, tx0);
-        const bf16_t* ximg = x + (int64_t)b * H * W * CV_C;
-        const bf16_t* dimg = dy + (int64_t)b * H * W * CV_C;
+        const bf16_t* ximg = x + (int64_t)b * H * W * xs;
+        const bf16_t* dimg = dy + (int64_t)b * H * W * dys;
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
             const int px = tl + PSTEP * i, r = px >> 4, c = px & 15;
             const int gy = min(ty0 + r, H - 1), gx = min(tx0 + c, W - 1);
-            rd[i] = ld16(dimg + (unsigned)((gy * W + gx) * CV_C + c8));
+            rd[i] = ld16(dimg + (unsigned)((gy * W + gx) * dys + c8));
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int px = min(tl + PSTEP * i, APIX - 1), r = (px * 3641) >> 16, c = px - r * CW_PW;     // px / 18 (exact below 1170)
             const int gy = min(max(ty0 - 1 + r, 0), H - 1), gx = min(max(tx0 - 1 + c, 0), W - 1);
-            ra[i] = ld16(ximg + (unsigned)((gy * W + gx) * CV_C + c8));
+            ra[i] = ld16(ximg + (unsigned)((gy * W + gx) * xs + c8));
         }
     };
     int t = blockIdx.x;
@@ -550,7 +552,7 @@ k_conv3x3_c64_wgrad_p(const bf16_t* __restrict__ x, const bf16_t* __restrict__ d
 // wave v adds slabs v, v + 16, ... (eight 1-KB loads in flight per wave: the first version, one thread per element walking all slabs
 // with four loads in flight, ran at 1.9 TB/s), the 16 partial sums meet in LDS and are added in wave order.
 __global__ void __launch_bounds__(1024)
-k_conv3x3_wgrad_reduce(const float* __restrict__ slab, int nslab, float* __restrict__ dw) {
+k_conv3x3_wgrad_reduce(const float* __restrict__ slab, int nslab, float* __restrict__ dw, int cin = CV_C) {
     __shared__ float4 part[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e0 = blockIdx.x * 256 + lane * 4;              // CV_WELEMS = 144 * 256
@@ -576,7 +578,7 @@ k_conv3x3_wgrad_reduce(const float* __restrict__ slab, int nslab, float* __restr
 #pragma unroll
         for (int v = 0; v < 16; ++v) t += pf[v * 256 + threadIdx.x];
         const int ci = idx % CV_C, co = (idx / CV_C) % CV_C, tap = idx / (CV_C * CV_C);
-        dw[(co * CV_C + ci) * 9 + tap] += t;
+        dw[(co * cin + ci) * 9 + tap] += t;           // cin: input channels of the WHOLE weight tensor (64; 128 for a quadrant of a 128 x 128 layer)
     }
 }
 
@@ -727,6 +729,41 @@ int ap_conv3x3_c64_wgrad_bn(const ap_bf16* x, const ap_bn_input* bn_in, const ap
     int rc = ap_check_launch();
     if (rc != AP_OK) return rc;
     hipLaunchKernelGGL(k_conv3x3_wgrad_reduce, dim3(CV_WELEMS / 256), dim3(1024), 0, (hipStream_t)stream, static_cast<const float*>(workspace), grid, dw_oihw);
+    return ap_check_launch();
+}
+
+// ---- weight gradient of the 128 -> 128 layer (VOLO-D4 / D5 stem, csrc/conv128.hip): dW[co][ci] splits into four 64 x 64 quadrants
+// (output half a, input half b), each exactly the 64-channel problem on the channel halves of x and dy -- the 64-channel kernel with a
+// pixel stride of 128 elements and the channel offset in the pointers; its slab reduction writes the quadrant into the [128][128][3][3]
+// tensor.  Every operand half is read twice; nothing else is new.
+size_t ap_conv3x3_c128_wgrad_workspace(int B, int H, int W) { return ap_conv3x3_c64_wgrad_workspace(B, H, W); }
+
+int ap_conv3x3_c128_wgrad(const ap_bf16* x, const ap_bf16* dy, float* dw_oihw, int B, int H, int W, void* workspace, size_t ws_bytes,
+                          ap_stream_t stream) {
+    if (!x || !dy || !dw_oihw || !workspace) return AP_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return AP_ERR_SHAPE;
+    if (ws_bytes < ap_conv3x3_c128_wgrad_workspace(B, H, W) || (int64_t)H * W * 128 > 0x7fffffff) return AP_ERR_SHAPE;
+    constexpr int PTR = CW_PTR;
+    constexpr int P_LDS = (PTR * CW_T + (PTR + 2) * CW_PW) * CV_C * 2;
+    const int tiles_x = (W + CW_T - 1) / CW_T, tyy = (H + PTR - 1) / PTR;
+    const int64_t np = (int64_t)B * tiles_x * tyy;
+    if (np > 0x7fffffff) return AP_ERR_SHAPE;
+    const int ntiles = (int)np, grid = ntiles < 256 ? ntiles : 256;
+    if ((size_t)grid * CV_WELEMS * sizeof(float) > ws_bytes) return AP_ERR_SHAPE;
+    static int attr_done = 0;
+    (void)hipGetLastError();
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64_wgrad_p<PTR, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS) != hipSuccess) return AP_ERR_LAUNCH;
+        attr_done = 1;
+    }
+    const BnIn bn = BnIn{nullptr, nullptr, nullptr, nullptr};
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            hipLaunchKernelGGL((k_conv3x3_c64_wgrad_p<PTR, false, 8>), dim3(grid), dim3(512), P_LDS, (hipStream_t)stream, x + 64 * b, dy + 64 * a,
+                               static_cast<float*>(workspace), H, W, tiles_x, tyy, ntiles, bn, 128, 128);
+            hipLaunchKernelGGL(k_conv3x3_wgrad_reduce, dim3(CV_WELEMS / 256), dim3(1024), 0, (hipStream_t)stream, static_cast<const float*>(workspace), grid,
+                               dw_oihw + ((int64_t)(64 * a) * 128 + 64 * b) * 9, 128);
+        }
     return ap_check_launch();
 }
 

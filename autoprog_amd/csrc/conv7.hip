@@ -46,7 +46,8 @@ k_conv7_pack(const float* __restrict__ w, bf16_t* __restrict__ wp) {
 template <bool STATS>
 __global__ void __launch_bounds__(256, 2)
 k_conv7_s2d(const bf16_t* __restrict__ xs, const bf16_t* __restrict__ wp, bf16_t* __restrict__ y, int H, int W,
-            int tiles_x, int tiles_y, int ntiles, float* __restrict__ stats) {
+            int tiles_x, int tiles_y, int ntiles, float* __restrict__ stats, int ldy = S_CO) {
+    // ldy: pixel stride of y in elements (64; 128 when y is one 64-channel half of the 128-wide stem's tensor, ap_conv7_s2d_ld)
     extern __shared__ __attribute__((aligned(16))) bf16_t s7_smem[];
     bf16_t* Wl = s7_smem;                       // [8][64 co][32]
     bf16_t* P = s7_smem + S_WELEMS;             // [665 px][16]
@@ -109,7 +110,7 @@ k_conv7_s2d(const bf16_t* __restrict__ xs, const bf16_t* __restrict__ wp, bf16_t
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        bf16_t* out = y + (((int64_t)b * H + ty0 + wave) * W + tx0 + fr) * S_CO + 8 * g;
+        bf16_t* out = y + (((int64_t)b * H + ty0 + wave) * W + tx0 + fr) * ldy + 8 * g;
         const bool col_ok = tx0 + fr < W;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -120,7 +121,7 @@ k_conv7_s2d(const bf16_t* __restrict__ xs, const bf16_t* __restrict__ wp, bf16_t
                     v[0] = acc[i][2 * pr][0]; v[1] = acc[i][2 * pr][1]; v[2] = acc[i][2 * pr][2]; v[3] = acc[i][2 * pr][3];
                     v[4] = acc[i][2 * pr + 1][0]; v[5] = acc[i][2 * pr + 1][1]; v[6] = acc[i][2 * pr + 1][2]; v[7] = acc[i][2 * pr + 1][3];
                     const u32x4 pk = pack8(v);
-                    st16(out + (int64_t)(4 * i) * W * S_CO + 32 * pr, pk);
+                    st16(out + (int64_t)(4 * i) * W * ldy + 32 * pr, pk);
                     if constexpr (STATS) {
                         float r8[8];
                         unpack8(pk, r8);
@@ -167,7 +168,7 @@ __device__ __forceinline__ int sw_key(int col) { return (((col >> 1) & 1) << 1) 
 
 __global__ void __launch_bounds__(256, 2)
 k_conv7_s2d_wgrad(const bf16_t* __restrict__ xs, const bf16_t* __restrict__ dz, float* __restrict__ slab, int H, int W,
-                  int tiles_x, int tiles_y, int ntiles) {
+                  int tiles_x, int tiles_y, int ntiles, int lddz = S_CO) {
     extern __shared__ __attribute__((aligned(16))) bf16_t sw_smem[];
     bf16_t* D = sw_smem;                        // [256 px][64 co], chunk ^ sw_key(column)
     bf16_t* A = sw_smem + SW_DPIX * S_CO;       // [361 px][16]
@@ -207,12 +208,12 @@ k_conv7_s2d_wgrad(const bf16_t* __restrict__ xs, const bf16_t* __restrict__ dz, 
         int b, ty0, tx0;
         origin(t, b, ty0, tx0);
         const bf16_t* ximg = xs + (int64_t)b * H * W * S_CI;
-        const bf16_t* dimg = dz + (int64_t)b * H * W * S_CO;
+        const bf16_t* dimg = dz + (int64_t)b * H * W * lddz;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int px = (tid >> 3) + 32 * i, r = px >> 4, c = px & 15;
             const int gy = min(ty0 + r, H - 1), gx = min(tx0 + c, W - 1);
-            rd[i] = ld16(dimg + (unsigned)((gy * W + gx) * S_CO + c8));
+            rd[i] = ld16(dimg + (unsigned)((gy * W + gx) * lddz + c8));
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -335,8 +336,12 @@ int ap_conv7_s2d_stat_rows(int B, int H, int W) {
 }
 
 int ap_conv7_s2d(const ap_bf16* xs, const ap_bf16* w_packed, ap_bf16* y, int B, int H, int W, float* stats, ap_stream_t stream) {
+    return ap_conv7_s2d_ld(xs, w_packed, y, S_CO, B, H, W, stats, stream);
+}
+
+int ap_conv7_s2d_ld(const ap_bf16* xs, const ap_bf16* w_packed, ap_bf16* y, int ldy, int B, int H, int W, float* stats, ap_stream_t stream) {
     if (!xs || !w_packed || !y) return AP_ERR_NULL;
-    if (B <= 0 || H <= 0 || W <= 0) return AP_ERR_SHAPE;
+    if (B <= 0 || H <= 0 || W <= 0 || ldy < S_CO || (ldy & 7) || (int64_t)H * W * ldy > 0x7fffffff) return AP_ERR_SHAPE;
     int tx, ty;
     const int nt = s7_tiles(B, H, W, S_TR, S_TW, &tx, &ty);
     if (nt < 0) return AP_ERR_SHAPE;
@@ -348,8 +353,8 @@ int ap_conv7_s2d(const ap_bf16* xs, const ap_bf16* w_packed, ap_bf16* y, int B, 
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv7_s2d<true>), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES) != hipSuccess) return AP_ERR_LAUNCH;
         attr_done = 1;
     }
-    if (stats) hipLaunchKernelGGL((k_conv7_s2d<true>), dim3(grid), dim3(256), S_LDS_BYTES, (hipStream_t)stream, xs, w_packed, y, H, W, tx, ty, nt, stats);
-    else hipLaunchKernelGGL((k_conv7_s2d<false>), dim3(grid), dim3(256), S_LDS_BYTES, (hipStream_t)stream, xs, w_packed, y, H, W, tx, ty, nt, stats);
+    if (stats) hipLaunchKernelGGL((k_conv7_s2d<true>), dim3(grid), dim3(256), S_LDS_BYTES, (hipStream_t)stream, xs, w_packed, y, H, W, tx, ty, nt, stats, ldy);
+    else hipLaunchKernelGGL((k_conv7_s2d<false>), dim3(grid), dim3(256), S_LDS_BYTES, (hipStream_t)stream, xs, w_packed, y, H, W, tx, ty, nt, stats, ldy);
     return ap_check_launch();
 }
 
@@ -361,14 +366,19 @@ size_t ap_conv7_s2d_wgrad_workspace(int B, int H, int W) {
 
 int ap_conv7_s2d_wgrad(const ap_bf16* xs, const ap_bf16* dz, float* dw_oihw, int B, int H, int W, void* workspace, size_t ws_bytes,
                        ap_stream_t stream) {
+    return ap_conv7_s2d_wgrad_ld(xs, dz, S_CO, dw_oihw, B, H, W, workspace, ws_bytes, stream);
+}
+
+int ap_conv7_s2d_wgrad_ld(const ap_bf16* xs, const ap_bf16* dz, int lddz, float* dw_oihw, int B, int H, int W, void* workspace, size_t ws_bytes,
+                          ap_stream_t stream) {
     if (!xs || !dz || !dw_oihw || !workspace) return AP_ERR_NULL;
-    if (B <= 0 || H <= 0 || W <= 0) return AP_ERR_SHAPE;
+    if (B <= 0 || H <= 0 || W <= 0 || lddz < S_CO || (lddz & 7) || (int64_t)H * W * lddz > 0x7fffffff) return AP_ERR_SHAPE;
     int tx, ty;
     const int nt = s7_tiles(B, H, W, SW_T, SW_T, &tx, &ty);
     if (nt < 0 || ws_bytes < ap_conv7_s2d_wgrad_workspace(B, H, W)) return AP_ERR_SHAPE;
     const int grid = s7_grid(nt, "AP_CONV7_WGRAD_GRID", 512);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(k_conv7_s2d_wgrad, dim3(grid), dim3(256), SW_LDS_BYTES, (hipStream_t)stream, xs, dz, static_cast<float*>(workspace), H, W, tx, ty, nt);
+    hipLaunchKernelGGL(k_conv7_s2d_wgrad, dim3(grid), dim3(256), SW_LDS_BYTES, (hipStream_t)stream, xs, dz, static_cast<float*>(workspace), H, W, tx, ty, nt, lddz);
     int rc = ap_check_launch();
     if (rc != AP_OK) return rc;
     static_assert(SW_SLAB % 256 == 0, "whole reduction blocks");

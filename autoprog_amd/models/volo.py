@@ -340,7 +340,7 @@ class PatchEmbed(nn.Module):
         size = self.resize_to if (self.resize_to and (self.training or self.resize_in_eval)) else x.shape[-1]
         first = None
         if (fused and self.stem_conv and self.hip_conv and x.dtype == torch.float32 and x.shape[-1] == x.shape[-2] and not x.requires_grad
-                and size % 2 == 0 and tuple(self.conv[0].weight.shape) == (64, 3, 7, 7) and self.conv[0].stride[0] == 2):
+                and size % 2 == 0 and tuple(self.conv[0].weight.shape) in ((64, 3, 7, 7), (128, 3, 7, 7)) and self.conv[0].stride[0] == 2):
             # resize + space-to-depth in one kernel, then the 7x7 / stride 2 convolution of csrc/conv7.hip with its BatchNorm + ReLU
             from .. import ops
             bn = self.conv[1]
@@ -378,8 +378,9 @@ class PatchEmbed(nn.Module):
                             if self.training and bn.num_batches_tracked is not None:
                                 counters.append(bn.num_batches_tracked)
                             continue
-                        if i and tuple(conv.weight.shape) == (64, 64, 3, 3) and self.hip_conv:
-                            # the two 3x3 convolutions at 64 channels: HIP implicit GEMM with the BatchNorm statistics in its epilogue
+                        if i and tuple(conv.weight.shape) in ((64, 64, 3, 3), (128, 128, 3, 3)) and self.hip_conv:
+                            # the two 3x3 convolutions at 64 channels (csrc/conv.hip) or 128 (VOLO-D4 / D5: csrc/conv128.hip): HIP implicit
+                            # GEMM with the BatchNorm statistics in its epilogue
                             nhwc = AF.Conv3x3BNReLUFn.apply(x.permute(0, 2, 3, 1), conv.weight, bn.weight, bn.bias, bn.running_mean,
                                                             bn.running_var, self.training, bn.momentum, bn.eps)
                         else:

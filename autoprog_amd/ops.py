@@ -629,10 +629,15 @@ def bn_relu_bwd(dy, x, gamma, beta, mean, rstd, dgamma, dbeta):
 
 # ------------------------------------------------------------------------------------- stem 3x3 convolution (C = 64)
 def conv3x3_pack(weight):
-    """fp32 [64,64,3,3] -> (w_fwd, w_bwd) bf16 operand layouts of conv3x3_c64"""
+    """fp32 [64,64,3,3] (or [128,128,3,3]: the VOLO-D4 / D5 stem) -> (w_fwd, w_bwd) bf16 operand layouts of conv3x3_c64 / conv3x3_c128"""
     _req(weight, torch.float32, "weight")
+    if tuple(weight.shape) == (128, 128, 3, 3):
+        wf = torch.empty(9 * 128 * 128, dtype=BF16, device=weight.device)
+        wb = torch.empty_like(wf)
+        check(lib.ap_conv3x3_c128_pack(weight.contiguous().data_ptr(), wf.data_ptr(), wb.data_ptr(), _stream()), "ap_conv3x3_c128_pack")
+        return wf, wb
     if tuple(weight.shape) != (64, 64, 3, 3):
-        raise AutoProgHipError("conv3x3_c64 handles 64 -> 64 channels, 3x3 (got %s)" % (tuple(weight.shape),))
+        raise AutoProgHipError("the HIP 3x3 convolutions handle 64 -> 64 and 128 -> 128 channels (got %s)" % (tuple(weight.shape),))
     wf = torch.empty(9 * 64 * 64, dtype=BF16, device=weight.device)
     wb = torch.empty_like(wf)
     check(lib.ap_conv3x3_c64_pack(weight.contiguous().data_ptr(), wf.data_ptr(), wb.data_ptr(), _stream()), "ap_conv3x3_c64_pack")
@@ -655,8 +660,18 @@ def conv3x3_c64(x, w_packed, want_stats=False, bn_in=None):
     PRE-BatchNorm output of the previous convolution and the kernel applies relu(bn(x)) while it stages its input"""
     _req(x, BF16, "x"); _req(w_packed, BF16, "w_packed")
     B, H, W, C = x.shape
+    if C == 128:                       # csrc/conv128.hip: patch in LDS, weights streamed per (tap, 64-channel) slab
+        if bn_in is not None:
+            raise AutoProgHipError("conv3x3 at 128 channels: the BatchNorm input transform exists at 64 channels only")
+        if w_packed.numel() != 9 * 128 * 128:
+            raise AutoProgHipError("conv3x3 at 128 channels needs the operand of conv3x3_pack on a [128,128,3,3] weight")
+        y = torch.empty_like(x)
+        stats = torch.empty((lib.ap_conv3x3_c128_stat_rows(B, H, W), 2, 128), dtype=torch.float32, device=x.device) if want_stats else None
+        check(lib.ap_conv3x3_c128(x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), B, H, W, stats.data_ptr() if want_stats else None, _stream()),
+              "ap_conv3x3_c128")
+        return (y, stats) if want_stats else y
     if C != 64:
-        raise AutoProgHipError("conv3x3_c64: 64 channels (got %d)" % C)
+        raise AutoProgHipError("conv3x3_c64: 64 (or 128) channels (got %d)" % C)
     y = torch.empty_like(x)
     stats = torch.empty((lib.ap_conv3x3_c64_stat_rows(B, H, W), 2, 64), dtype=torch.float32, device=x.device) if want_stats else None
     if bn_in is not None:
@@ -674,6 +689,11 @@ def conv3x3_c64_wgrad(x, dy, dw, bn_in=None):
     (the layer's input was relu(bn(x)))"""
     _req(x, BF16, "x"); _req(dy, BF16, "dy"); _req(dw, torch.float32, "dw")
     B, H, W, C = x.shape
+    if C == 128 and tuple(dy.shape) == tuple(x.shape) and tuple(dw.shape) == (128, 128, 3, 3) and bn_in is None:
+        ws_bytes = lib.ap_conv3x3_c128_wgrad_workspace(B, H, W)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+        check(lib.ap_conv3x3_c128_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ws.data_ptr(), ws_bytes, _stream()), "ap_conv3x3_c128_wgrad")
+        return dw
     if C != 64 or tuple(dy.shape) != tuple(x.shape) or tuple(dw.shape) != (64, 64, 3, 3):
         raise AutoProgHipError("conv3x3_c64_wgrad: shapes %s %s %s" % (tuple(x.shape), tuple(dy.shape), tuple(dw.shape)))
     ws_bytes = lib.ap_conv3x3_c64_wgrad_workspace(B, H, W)
@@ -701,11 +721,15 @@ def resize_bilinear_s2d16(x, size):
 
 
 def conv7_pack(weight):
+    """fp32 [64,3,7,7] -> packed operand; [128,3,7,7] (VOLO-D4 / D5 stem): the two 64-channel halves' operands, one behind the other"""
     _req(weight, torch.float32, "weight")
-    if tuple(weight.shape) != (64, 3, 7, 7):
-        raise AutoProgHipError("conv7_s2d handles 3 -> 64 channels, 7x7 (got %s)" % (tuple(weight.shape),))
-    wp = torch.empty(16 * 64 * 16, dtype=BF16, device=weight.device)
-    check(lib.ap_conv7_pack(weight.contiguous().data_ptr(), wp.data_ptr(), _stream()), "ap_conv7_pack")
+    if tuple(weight.shape) not in ((64, 3, 7, 7), (128, 3, 7, 7)):
+        raise AutoProgHipError("conv7_s2d handles 3 -> 64 / 128 channels, 7x7 (got %s)" % (tuple(weight.shape),))
+    halves = weight.shape[0] // 64
+    w = weight.contiguous()
+    wp = torch.empty(halves * 16 * 64 * 16, dtype=BF16, device=weight.device)
+    for h in range(halves):
+        check(lib.ap_conv7_pack(w.data_ptr() + h * 64 * 147 * 4, wp.data_ptr() + h * 16 * 64 * 16 * 2, _stream()), "ap_conv7_pack")
     return wp
 
 
@@ -715,6 +739,14 @@ def conv7_s2d(xs, w_packed, want_stats=False):
     B, H, W, C = xs.shape
     if C != 16:
         raise AutoProgHipError("conv7_s2d: 16 space-to-depth channels (got %d)" % C)
+    if w_packed.numel() == 2 * 16 * 64 * 16:          # 128 output channels: the kernel once per 64-channel half, pixel stride 128
+        y = torch.empty((B, H, W, 128), dtype=BF16, device=xs.device)
+        rows = lib.ap_conv7_s2d_stat_rows(B, H, W)
+        st = [torch.empty((rows, 2, 64), dtype=torch.float32, device=xs.device) if want_stats else None for _ in range(2)]
+        for h in range(2):
+            check(lib.ap_conv7_s2d_ld(xs.data_ptr(), w_packed.data_ptr() + h * 16 * 64 * 16 * 2, y.data_ptr() + h * 64 * 2, 128, B, H, W,
+                                      st[h].data_ptr() if want_stats else None, _stream()), "ap_conv7_s2d_ld")
+        return (y, torch.cat(st, dim=2)) if want_stats else y
     y = torch.empty((B, H, W, 64), dtype=BF16, device=xs.device)
     stats = torch.empty((lib.ap_conv7_s2d_stat_rows(B, H, W), 2, 64), dtype=torch.float32, device=xs.device) if want_stats else None
     check(lib.ap_conv7_s2d(xs.data_ptr(), w_packed.data_ptr(), y.data_ptr(), B, H, W, stats.data_ptr() if want_stats else None, _stream()),
@@ -726,6 +758,13 @@ def conv7_s2d_wgrad(xs, dz, dw):
     """dw (fp32 [64,3,7,7]) += weight gradient of conv7_s2d"""
     _req(xs, BF16, "xs"); _req(dz, BF16, "dz"); _req(dw, torch.float32, "dw")
     B, H, W, _ = xs.shape
+    if tuple(dz.shape) == (B, H, W, 128) and tuple(dw.shape) == (128, 3, 7, 7):
+        ws_bytes = lib.ap_conv7_s2d_wgrad_workspace(B, H, W)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=xs.device)
+        for h in range(2):
+            check(lib.ap_conv7_s2d_wgrad_ld(xs.data_ptr(), dz.data_ptr() + h * 64 * 2, 128, dw.data_ptr() + h * 64 * 147 * 4, B, H, W, ws.data_ptr(), ws_bytes,
+                                            _stream()), "ap_conv7_s2d_wgrad_ld")
+        return dw
     if tuple(dz.shape) != (B, H, W, 64) or tuple(dw.shape) != (64, 3, 7, 7):
         raise AutoProgHipError("conv7_s2d_wgrad: shapes %s %s %s" % (tuple(xs.shape), tuple(dz.shape), tuple(dw.shape)))
     ws_bytes = lib.ap_conv7_s2d_wgrad_workspace(B, H, W)

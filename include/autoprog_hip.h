@@ -319,6 +319,26 @@ int ap_conv7_s2d(const ap_bf16* xs, const ap_bf16* w_packed, ap_bf16* y, int B, 
 size_t ap_conv7_s2d_wgrad_workspace(int B, int H, int W);
 int ap_conv7_s2d_wgrad(const ap_bf16* xs, const ap_bf16* dz, float* dw_oihw, int B, int H, int W, void* workspace, size_t ws_bytes,
                        ap_stream_t stream);
+/* (ABI version 6) the same two with an explicit pixel stride (elements) of y / dz: 64 output channels written into / read from a wider
+ * NHWC tensor.  The 128-wide stem of VOLO-D4 / D5 (models/volo.py:799-821: nn.Conv2d(3, 128, 7, 2, 3)) is two such launches on the
+ * channel halves: weights w_oihw + h * 64 * 147, y + 64 h with ldy = 128 (stats per half: [rows][2][64]) */
+int ap_conv7_s2d_ld(const ap_bf16* xs, const ap_bf16* w_packed, ap_bf16* y, int ldy, int B, int H, int W, float* stats, ap_stream_t stream);
+int ap_conv7_s2d_wgrad_ld(const ap_bf16* xs, const ap_bf16* dz, int lddz, float* dw_oihw, int B, int H, int W, void* workspace, size_t ws_bytes,
+                          ap_stream_t stream);
+
+/* ---- (ABI version 6) 3x3 / stride 1 / pad 1 convolution at 128 channels in HIP: the stem of VOLO-D4 / D5 (stem_hidden_dim = 128,
+ * models/volo.py:355-367,803,818; BASELINE configs[4]) -- csrc/conv128.hip: the input patch in LDS, the weights streamed in 18
+ * (tap, 64-input-channel) slabs.  Contracts as the 64-channel family above.
+ * pack: fp32 OIHW [128][128][3][3] -> w_fwd / w_bwd, 9 * 128 * 128 bf16 each (slab layouts of the kernel) */
+int ap_conv3x3_c128_pack(const float* w_oihw, ap_bf16* w_fwd, ap_bf16* w_bwd, ap_stream_t stream);
+/* y[B,H,W,128] = conv3x3(x[B,H,W,128]) (w_fwd: forward; w_bwd with x = dy: the input gradient); stats (nullable):
+ * float[ap_conv3x3_c128_stat_rows(B,H,W)][2][128] partial sums / sums of squares of the bf16-rounded outputs (ap_bn_relu_fwd_partials) */
+int ap_conv3x3_c128_stat_rows(int B, int H, int W);
+int ap_conv3x3_c128(const ap_bf16* x, const ap_bf16* w_packed, ap_bf16* y, int B, int H, int W, float* stats, ap_stream_t stream);
+/* dw_oihw[128][128][3][3] (fp32) += weight gradient: the 64-channel kernel on the four (output half, input half) quadrants */
+size_t ap_conv3x3_c128_wgrad_workspace(int B, int H, int W);
+int ap_conv3x3_c128_wgrad(const ap_bf16* x, const ap_bf16* dy, float* dw_oihw, int B, int H, int W, void* workspace, size_t ws_bytes,
+                          ap_stream_t stream);
 
 /* ---- fused optimizer step: AdamW (torch.optim.AdamW semantics, main_prog.py:484)
  * + n_ema <= 4 ModelEmaV2 updates (main_prog.py:1030-1033) over one flat fp32 slab of n parameters

@@ -97,9 +97,9 @@ def test_patch_embed_stem_vs_reference_golden():
     assert rel(ye, d["eval.y"]) < 3e-2, rel(ye, d["eval.y"])
 
 
-def _stem64_module(d, hip):
+def _stem64_module(d, hip, width=64):
     from autoprog_amd.models import volo as V
-    pe = V.PatchEmbed(stem_conv=True, stem_stride=2, patch_size=8, in_chans=3, hidden_dim=64, embed_dim=32)
+    pe = V.PatchEmbed(stem_conv=True, stem_stride=2, patch_size=8, in_chans=3, hidden_dim=width, embed_dim=32)
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sub(d, "train.w").items()}
     for k in sd:                                   # the fixture stores the statistics AFTER the train step: start from the defaults
         if k.endswith("running_mean"):
@@ -193,6 +193,53 @@ def test_hip_stem64_vs_reference_golden(monkeypatch):
     print("stem64 vs oracle (3 x 48 x 48) gradient errors:", {k: round(v, 4) for k, v in sorted(errs2.items(), key=lambda kv: -kv[1])})
     bad = {k: v for k, v in errs2.items() if v > (1.5e-2 if k.startswith("proj") else 1.3 * max(base.values()))}
     assert not bad, bad
+
+
+def test_hip_stem128_vs_reference_golden(monkeypatch):
+    """VERDICT r4, missing 2 (row X1): the 128-wide stem of VOLO-D4 / D5 (models/volo.py:799-821, stem_hidden_dim = 128) on HIP kernels --
+    conv7 as two 64-channel launches into the 128-channel tensor, csrc/conv128.hip (patch in LDS, weights streamed per (tap, 64-channel)
+    slab) forward and input gradient, the 64-channel weight-gradient kernel on the four quadrants, the patch-addressed projection --
+    against reference-generated vectors (tests/golden/stem128.npz, tools/gen_golden.py::gen_stem128).  Any torch convolution on the GPU
+    fails the HIP part.  Bounds as test_hip_stem64_vs_reference_golden: the same module on MIOpen's bf16 convolutions is measured first
+    (the cost of bf16 activations under three training-mode BatchNorms of 2 x 16 x 16 samples) and the HIP kernels are held to 1.3x ITS
+    error per tensor (floor 1e-2)."""
+    import torch.nn.functional as F
+    d = load("stem128")
+    x = torch.from_numpy(d["train.x"]).cuda()
+    dy = torch.from_numpy(d["train.dy"]).cuda()
+    pm = _stem64_module(d, hip=False, width=128)
+    ym = pm(x)
+    ym.backward(dy.to(ym.dtype))
+    base = {n: rel(p.grad, d["train.g." + n]) for n, p in pm.named_parameters()}
+    base_y = rel(ym, d["train.y"])
+    pe = _stem64_module(d, hip=True, width=128)
+    torch_conv2d = F.conv2d
+
+    def no_miopen(inp, *a, **k):
+        if inp.is_cuda:
+            raise AssertionError("torch conv2d called on the GPU: the 128-wide stem must run on the HIP convolution kernels")
+        return torch_conv2d(inp, *a, **k)
+    monkeypatch.setattr(F, "conv2d", no_miopen)
+    y = pe(x)
+    e_y = rel(y, d["train.y"])
+    y.backward(dy.to(y.dtype))
+    for i in (1, 4, 7):
+        bn = pe.conv[i]
+        assert rel(bn.running_mean, d["train.w.conv.%d.running_mean" % i]) < 1.5e-2, i
+        assert rel(bn.running_var, d["train.w.conv.%d.running_var" % i]) < 1.5e-2, i
+        assert int(bn.num_batches_tracked) == 1
+    errs = {n: rel(p.grad, d["train.g." + n]) for n, p in pe.named_parameters()}
+    print("stem128 train output error hip %.4f (miopen bf16 %.4f); gradient errors hip / miopen bf16:" % (e_y, base_y),
+          {k: (round(v, 4), round(base[k], 4)) for k, v in sorted(errs.items(), key=lambda kv: -kv[1])})
+    assert e_y < 1.5e-2 and e_y < 1.3 * base_y + 1e-3, (e_y, base_y)
+    bad = {k: (v, base[k]) for k, v in errs.items() if v > max(1e-2, 1.3 * base[k])}
+    assert not bad, bad
+    sd_eval = {k: torch.from_numpy(np.asarray(v)) for k, v in sub(d, "train.w").items()}
+    pe.load_state_dict(sd_eval, strict=True)
+    pe.eval()
+    with torch.no_grad():
+        ye = pe(x)
+    assert rel(ye, d["eval.y"]) < 1.5e-2, rel(ye, d["eval.y"])
 
 
 def test_transformer_block_kernels_vs_fp64_with_the_same_rounding_points():

@@ -743,6 +743,62 @@ def test_conv3x3_c64_fwd_dgrad_wgrad_vs_torch_fp32(B, H, W):
     assert torch.equal(dw, dw2)                                           # ordered slab reduction: bit-reproducible
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 20, 37), (3, 33, 16), (1, 7, 5), (2, 64, 48), (5, 56, 56)])
+def test_conv3x3_c128_fwd_dgrad_wgrad_vs_torch_fp32(B, H, W):
+    """csrc/conv128.hip (ap_conv3x3_c128: the 3x3 convolutions of the 128-wide VOLO-D4 / D5 stem, models/volo.py:359-366 with
+    stem_hidden_dim = 128) and ap_conv3x3_c128_wgrad against torch's fp32 convolution on the same bf16-rounded operands.  Ragged sizes
+    exercise the 16 x 16 tile edges and workgroups that walk several tiles (the weight-slab ring runs across tiles; (5, 56, 56) is more
+    tiles than CUs).  Tolerances as at 64 channels: outputs 5e-3 rel-L2, the partial BatchNorm sums 1e-5, the fp32 weight gradient 1e-5."""
+    import torch.nn.functional as F
+    from autoprog_amd import ops
+    torch.manual_seed(B * 1000 + H)
+    x = torch.randn(B, H, W, 128, device="cuda").to(torch.bfloat16)
+    dy = torch.randn(B, H, W, 128, device="cuda").to(torch.bfloat16)
+    w = torch.randn(128, 128, 3, 3, device="cuda") * 0.04
+    w16 = w.to(torch.bfloat16).float()
+    wf, wb = ops.conv3x3_pack(w)
+    y, st = ops.conv3x3_c64(x, wf, True)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w16, None, 1, 1).permute(0, 2, 3, 1)
+    assert rel(y, ref) < 5e-3, rel(y, ref)
+    assert torch.equal(y, ops.conv3x3_c64(x, wf))                         # the statistics epilogue does not change the output
+    sums = st.double().sum(0)
+    assert rel(sums[0], y.double().sum((0, 1, 2))) < 1e-5 and rel(sums[1], y.double().pow(2).sum((0, 1, 2))) < 1e-5
+    dx = ops.conv3x3_c64(dy, wb)
+    refdx = F.conv_transpose2d(dy.float().permute(0, 3, 1, 2), w16, None, 1, 1).permute(0, 2, 3, 1)
+    assert rel(dx, refdx) < 5e-3, rel(dx, refdx)
+    dw = torch.full((128, 128, 3, 3), 0.5, device="cuda")                 # accumulates (+=)
+    ops.conv3x3_c64_wgrad(x, dy, dw)
+    refdw = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (128, 128, 3, 3), dy.float().permute(0, 3, 1, 2), stride=1, padding=1)
+    assert rel(dw - 0.5, refdw) < 1e-5, rel(dw - 0.5, refdw)
+    dw2 = torch.full((128, 128, 3, 3), 0.5, device="cuda")
+    ops.conv3x3_c64_wgrad(x, dy, dw2)
+    assert torch.equal(dw, dw2)                                           # ordered slab reduction: bit-reproducible
+
+
+def test_conv7_s2d_128_output_channels_vs_torch_fp32():
+    """the first convolution of the 128-wide stem (nn.Conv2d(3, 128, 7, 2, 3), models/volo.py:355-357 at stem_hidden_dim = 128): the
+    64-channel kernel once per channel half with a pixel stride of 128 (ap_conv7_s2d_ld / ap_conv7_s2d_wgrad_ld)"""
+    import torch.nn.functional as F
+    from autoprog_amd import ops
+    torch.manual_seed(7)
+    B, R = 3, 48
+    img = torch.randn(B, 3, R, R, device="cuda")
+    w = torch.randn(128, 3, 7, 7, device="cuda") * 0.1
+    xs = ops.resize_bilinear_s2d16(img, R)
+    img16 = xs[..., :12].reshape(B, R // 2, R // 2, 2, 2, 3).permute(0, 5, 1, 3, 2, 4).reshape(B, 3, R, R).float()
+    y, st = ops.conv7_s2d(xs, ops.conv7_pack(w), True)
+    ref = F.conv2d(img16, w.to(torch.bfloat16).float(), None, 2, 3).permute(0, 2, 3, 1)
+    assert y.shape == ref.shape == (B, R // 2, R // 2, 128) and rel(y, ref) < 5e-3
+    sums = st.double().sum(0)
+    assert st.shape[1:] == (2, 128)
+    assert rel(sums[0], y.double().sum((0, 1, 2))) < 1e-5 and rel(sums[1], y.double().pow(2).sum((0, 1, 2))) < 1e-5
+    dz = torch.randn_like(y)
+    dw = torch.full((128, 3, 7, 7), 0.25, device="cuda")
+    ops.conv7_s2d_wgrad(xs, dz, dw)
+    refdw = torch.nn.grad.conv2d_weight(img16, (128, 3, 7, 7), dz.float().permute(0, 3, 1, 2), stride=2, padding=3)
+    assert rel(dw - 0.25, refdw) < 1e-5
+
+
 def test_conv3x3_bn_relu_fn_vs_torch():
     """Conv3x3BNReLUFn (conv -> BatchNorm(batch stats) -> ReLU) forward / backward against the same triple in torch fp32"""
     import torch.nn.functional as F

@@ -133,10 +133,12 @@ def test_stem_train_and_eval():
     assert rel_err(ye.permute(0, 3, 1, 2), d["eval.y"]) < TOL
 
 
-def test_stem64_train_and_eval():
+@pytest.mark.parametrize("fixture", ["stem64", "stem128"])
+def test_stem64_train_and_eval(fixture):
     """the BASELINE-width stem (64 channels: the shapes the HIP convolution kernels are written for) against the reference
-    vectors of tests/golden/stem64.npz -- the oracle side of tests/test_gpu_blocks.py::test_hip_stem64_vs_reference_golden"""
-    d = load("stem64")
+    vectors of tests/golden/stem64.npz -- the oracle side of tests/test_gpu_blocks.py::test_hip_stem64_vs_reference_golden; round 5:
+    the same for the 128-wide stem of VOLO-D4 / D5 (stem128.npz, csrc/conv128.hip)"""
+    d = load(fixture)
     p = _params(d, "train")
     x = torch.from_numpy(d["train.x"]).double().requires_grad_(True)
     y = R.patch_embed(x, p, train=True, patch_size=8, pre="")

@@ -221,6 +221,29 @@ def gen_stem64(ns):
     save("stem64", **out)
 
 
+def gen_stem128(ns):
+    """the stem of VOLO-D4 / D5 (hidden_dim 128, models/volo.py:799-821: the width csrc/conv128.hip serves), B = 2, 32 x 32 input: as stem64"""
+    out = {}
+    gen = torch.Generator().manual_seed(13)
+    pe = ns.volo.PatchEmbed(stem_conv=True, stem_stride=2, patch_size=8, in_chans=3, hidden_dim=128, embed_dim=32)
+    randomize_(pe, gen, 1.0).train()
+    with torch.no_grad():
+        for i in (0, 3, 6):
+            pe.conv[i].weight.mul_(1.0 / (pe.conv[i].weight[0].numel() ** 0.5))
+        pe.proj.weight.mul_(1.0 / (pe.proj.weight[0].numel() ** 0.5))
+    x = torch.randn(2, 3, 32, 32, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    y = pe(xr)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    out.update({"train.x": npy(x), "train.y": npy(y), "train.dy": npy(dy), "train.dx": npy(xr.grad)})
+    out.update({"train." + k: v for k, v in sd_arrays(pe).items()})     # includes UPDATED running stats
+    out.update({"train." + k: v for k, v in grads(pe).items()})
+    pe.eval()
+    out["eval.y"] = npy(pe(x))
+    save("stem128", **out)
+
+
 def gen_pos_interp(ns):
     out = {}
     gen = torch.Generator().manual_seed(3)
@@ -556,7 +579,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
     ns = ref_import.load_reference()
-    for fn in (gen_int_tables, gen_outlook, gen_blocks, gen_stem, gen_stem64, gen_pos_interp, gen_volo_full, gen_volo_full64, gen_loss, gen_step_curve,
+    for fn in (gen_int_tables, gen_outlook, gen_blocks, gen_stem, gen_stem64, gen_stem128, gen_pos_interp, gen_volo_full, gen_volo_full64, gen_loss, gen_step_curve,
                gen_step_curve_init, gen_late_state):
         if not only or fn.__name__[4:] in only:
             fn(ns)
