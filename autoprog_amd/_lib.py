@@ -84,7 +84,10 @@ _SIGNATURES = {
     "ap_bn_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, _P]),
     "ap_sumsq_workspace": (ctypes.c_size_t, []),
     "ap_sumsq_f32": (_I, [_P, _L, _P, _P, ctypes.c_size_t, _P]),
-    "ap_adamw_ema_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _F, _F, POINTER(c_void_p), POINTER(c_float), _I, _P, _P]),
+    "ap_adamw_ema_step": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P, _F, _F, _P, POINTER(c_void_p), POINTER(c_float), _I, _P, _P]),
+    "ap_mix_token_swap_dev": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "ap_soft_ce_fwd_bwd_dev": (_I, [_P, _I, _P, _L, _L, _L, _I, _P, _P, _F, _L, _I, _F, _I, _P, _P]),
+    "ap_soft_ce_sparse_fwd_bwd_dev": (_I, [_P, _I, _P, _P, _I, _L, _L, _I, _F, _P, _P, _F, _L, _I, _F, _I, _P, _P]),
     "ap_batched_transpose_bf16": (_I, [_P, _P, _P, _I, _I, _P]),
 }
 _SIGNATURES["ap_resize_bilinear_s2d16"] = (_I, [_P, _P, _I, _I, _I, _I, _I, _P])

@@ -138,7 +138,8 @@ __global__ void k_sum_reps_acc(const bf16_t* __restrict__ x, float* __restrict__
 
 // ------------------------------------------------------------------------------- mix token
 __global__ void k_mix_swap(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int Cv,
-                           int r0, int r1, int c0, int c1) {
+                           int r0, int r1, int c0, int c1, const int* __restrict__ box_dev = nullptr, int scale = 1) {
+    if (box_dev) { r0 = box_dev[0] * scale; r1 = box_dev[1] * scale; c0 = box_dev[2] * scale; c1 = box_dev[3] * scale; }    // the step's box from device memory (graph replay)
     const int64_t total = (int64_t)B * H * W * Cv;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t img = (int64_t)H * W * Cv;
@@ -537,7 +538,15 @@ int ap_mix_token_swap(const ap_bf16* x, ap_bf16* y, int B, int H, int W, int C, 
     if ((C & 7) || B <= 0 || H <= 0 || W <= 0 || x == y) return AP_ERR_SHAPE;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_mix_swap, dim3(grid_for((int64_t)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
-                       x, y, B, H, W, C / 8, r0, r1, c0, c1);
+                       x, y, B, H, W, C / 8, r0, r1, c0, c1, nullptr, 1);
+    return ap_check_launch();
+}
+int ap_mix_token_swap_dev(const ap_bf16* x, ap_bf16* y, int B, int H, int W, int C, const int* box_dev, int scale, ap_stream_t stream) {
+    if (!x || !y || !box_dev) return AP_ERR_NULL;
+    if ((C & 7) || B <= 0 || H <= 0 || W <= 0 || x == y || scale < 1) return AP_ERR_SHAPE;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_mix_swap, dim3(grid_for((int64_t)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       x, y, B, H, W, C / 8, 0, 0, 0, 0, box_dev, scale);
     return ap_check_launch();
 }
 int ap_avgpool2_fwd(const ap_bf16* x, ap_bf16* y, int B, int H, int W, int C, ap_stream_t stream) {

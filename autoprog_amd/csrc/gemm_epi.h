@@ -42,14 +42,14 @@ struct EpiArgs {
 __device__ __forceinline__ unsigned gq_code(float g) {
     return (unsigned)fminf(fmaxf(__builtin_rintf(fmaf(g, GQ_SCALE, GQ_ZERO)), 0.f), 255.f);
 }
-// four codes into a dword: v_cvt_pk_u8_f32 saturates to [0, 255] and places the byte; its input is already an integer (v_rndne_f32),
-// so the instruction's own rounding does not matter: fma + rndne + cvt_pk per element
+// four codes into a dword: v_cvt_pk_u8_f32 rounds to nearest even, saturates to [0, 255] and places the byte (tools/probe/cvt_u8.hip on
+// gfx950: 0.5 -> 0, 1.5 -> 2, 2.5 -> 2, 254.5 -> 254, 300 -> 255, -3 -> 0) -- rint + clamp + pack in one instruction: fma + cvt_pk per element
 __device__ __forceinline__ unsigned gq_pack4(const float* g) {
     unsigned w = 0;
-    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(g[0], GQ_SCALE, GQ_ZERO)), 0, w);
-    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(g[1], GQ_SCALE, GQ_ZERO)), 1, w);
-    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(g[2], GQ_SCALE, GQ_ZERO)), 2, w);
-    w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(fmaf(g[3], GQ_SCALE, GQ_ZERO)), 3, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g[0], GQ_SCALE, GQ_ZERO), 0, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g[1], GQ_SCALE, GQ_ZERO), 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g[2], GQ_SCALE, GQ_ZERO), 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(g[3], GQ_SCALE, GQ_ZERO), 3, w);
     return w;
 }
 __device__ __forceinline__ float gq_decode(unsigned code) { return fmaf((float)code, 1.0f / GQ_SCALE, -GQ_ZERO / GQ_SCALE); }

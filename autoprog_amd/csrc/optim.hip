@@ -11,6 +11,7 @@ struct AdamArgs {
     const float* gnorm_sq;                             // device scalar: sum of squares of the UNSCALED slab (ap_sumsq_f32), or nullptr
     float max_norm;                                    // clip_grad_norm_ bound on the scaled gradient (with gnorm_sq)
     float clip_value;                                  // clip_grad_value_ bound on the scaled gradient elements (> 0), else 0
+    const float* step_dev;                             // device [lr, 1 - beta1^t, sqrt(1 - beta2^t)] (graph replay), or nullptr: the host values above
     int n_ema;
     float decay[4];
     float* ema[4];
@@ -21,6 +22,7 @@ k_adamw_ema(float* __restrict__ p, const float* __restrict__ g, float* __restric
             const unsigned char* __restrict__ wd_mask, int64_t n, AdamArgs a, bf16_t* __restrict__ p16) {
     const int64_t nv = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (a.step_dev) { a.lr = a.step_dev[0]; a.bc1 = a.step_dev[1]; a.bc2_sqrt = a.step_dev[2]; }
     const float step_size = a.lr / a.bc1;
     // gradient clipping folded into the update (prog/scaler.py:60-68 -> timm dispatch_clip_grad, main_prog.py:1019-1027):
     // mode 'norm' = torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (||g|| + 1e-6)) with ||g|| the norm of the MEAN gradient
@@ -113,14 +115,14 @@ extern "C" int ap_sumsq_f32(const float* x, int64_t n, float* out, void* workspa
 
 extern "C" int ap_adamw_ema_step(float* p, const float* g, float* m, float* v, const unsigned char* wd_mask, int64_t n,
                                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                                 const float* gnorm_sq, float max_norm, float clip_value,
+                                 const float* gnorm_sq, float max_norm, float clip_value, const float* step_scalars_dev,
                                  float* const* ema, const float* ema_decay, int n_ema, ap_bf16* p_bf16, ap_stream_t stream) {
     if (!p || !g || !m || !v || !wd_mask) return AP_ERR_NULL;
     if (n <= 0 || (n & 3) || n_ema < 0 || n_ema > 4 || step < 1) return AP_ERR_SHAPE;
     if (gnorm_sq && !(max_norm > 0.f)) return AP_ERR_SHAPE;
     AdamArgs a;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.gscale = grad_scale;
-    a.gnorm_sq = gnorm_sq; a.max_norm = max_norm; a.clip_value = clip_value > 0.f ? clip_value : 0.f;
+    a.gnorm_sq = gnorm_sq; a.max_norm = max_norm; a.clip_value = clip_value > 0.f ? clip_value : 0.f; a.step_dev = step_scalars_dev;
     a.bc1 = 1.0f - powf(beta1, (float)step);
     a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
     a.n_ema = n_ema;

@@ -16,7 +16,8 @@
 __global__ void __launch_bounds__(256)
 k_soft_ce(const bf16_t* __restrict__ logits, int ldx, const float* __restrict__ target, int64_t t_sb, int64_t t_sc,
           int64_t t_sn, int rows_per_batch, float* __restrict__ row_loss, bf16_t* __restrict__ dlogits,
-          float gscale, int64_t M, int C, int tiles_per_batch, float mix_lam, int mix_batches) {
+          float gscale, int64_t M, int C, int tiles_per_batch, float mix_lam, int mix_batches, const float* __restrict__ lam_dev = nullptr) {
+    if (lam_dev) mix_lam = lam_dev[0];                   // the step's lam from device memory (graph replay; lam = 1: lam t + 0 t' = t exactly)
     extern __shared__ __attribute__((aligned(16))) float tt[];      // [CE_TN][Cp] Cp odd
     const int Cp = C | 1;
     const int64_t b = blockIdx.x / tiles_per_batch;
@@ -125,7 +126,8 @@ k_soft_ce(const bf16_t* __restrict__ logits, int ldx, const float* __restrict__ 
 __global__ void __launch_bounds__(256)
 k_soft_ce_sparse(const bf16_t* __restrict__ logits, int ldx, const int* __restrict__ idx, const float* __restrict__ val, int K,
                  int64_t p_sb, int64_t p_sn, int rows_per_batch, float smoothing, float* __restrict__ row_loss,
-                 bf16_t* __restrict__ dlogits, float gscale, int64_t M, int C, float mix_lam, int mix_batches) {
+                 bf16_t* __restrict__ dlogits, float gscale, int64_t M, int C, float mix_lam, int mix_batches, const float* __restrict__ lam_dev = nullptr) {
+    if (lam_dev) mix_lam = lam_dev[0];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * CE_SR;
     if (row0 >= M) return;
@@ -230,6 +232,12 @@ extern "C" int ap_loss_combine(const float* a, int64_t na, float wa, const float
 extern "C" int ap_soft_ce_fwd_bwd(const ap_bf16* logits, int ldx, const float* target, int64_t t_sb, int64_t t_sc,
                                   int64_t t_sn, int rows_per_batch, float* row_loss, ap_bf16* dlogits,
                                   float grad_scale, int64_t M, int C, float mix_lam, int mix_batches, ap_stream_t stream) {
+    return ap_soft_ce_fwd_bwd_dev(logits, ldx, target, t_sb, t_sc, t_sn, rows_per_batch, row_loss, dlogits, grad_scale, M, C, mix_lam, mix_batches, nullptr, stream);
+}
+
+extern "C" int ap_soft_ce_fwd_bwd_dev(const ap_bf16* logits, int ldx, const float* target, int64_t t_sb, int64_t t_sc,
+                                      int64_t t_sn, int rows_per_batch, float* row_loss, ap_bf16* dlogits,
+                                      float grad_scale, int64_t M, int C, float mix_lam, int mix_batches, const float* mix_lam_dev, ap_stream_t stream) {
     if (!logits || !target || !row_loss || !dlogits) return AP_ERR_NULL;
     if (mix_batches != 0 && (mix_batches < 0 || (int64_t)mix_batches * rows_per_batch != M)) return AP_ERR_SHAPE;
     if (C <= 0 || ldx < C || (ldx & 7) || rows_per_batch <= 0 || M % rows_per_batch) return AP_ERR_SHAPE;
@@ -240,13 +248,20 @@ extern "C" int ap_soft_ce_fwd_bwd(const ap_bf16* logits, int ldx, const float* t
     const size_t lds = (size_t)CE_TN * (C | 1) * sizeof(float);
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_soft_ce, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, logits, ldx, target, t_sb, t_sc,
-                       t_sn, rows_per_batch, row_loss, dlogits, grad_scale, M, C, tiles, mix_lam, mix_batches);
+                       t_sn, rows_per_batch, row_loss, dlogits, grad_scale, M, C, tiles, mix_lam, mix_batches, mix_lam_dev);
     return ap_check_launch();
 }
 
 extern "C" int ap_soft_ce_sparse_fwd_bwd(const ap_bf16* logits, int ldx, const int* idx, const float* val, int K, int64_t p_sb, int64_t p_sn,
                                          int rows_per_batch, float smoothing, float* row_loss, ap_bf16* dlogits, float grad_scale,
                                          int64_t M, int C, float mix_lam, int mix_batches, ap_stream_t stream) {
+    return ap_soft_ce_sparse_fwd_bwd_dev(logits, ldx, idx, val, K, p_sb, p_sn, rows_per_batch, smoothing, row_loss, dlogits, grad_scale, M, C, mix_lam, mix_batches,
+                                         nullptr, stream);
+}
+
+extern "C" int ap_soft_ce_sparse_fwd_bwd_dev(const ap_bf16* logits, int ldx, const int* idx, const float* val, int K, int64_t p_sb, int64_t p_sn,
+                                             int rows_per_batch, float smoothing, float* row_loss, ap_bf16* dlogits, float grad_scale,
+                                             int64_t M, int C, float mix_lam, int mix_batches, const float* mix_lam_dev, ap_stream_t stream) {
     if (!logits || !idx || !val || !row_loss || !dlogits) return AP_ERR_NULL;
     if (C <= 0 || ldx < C || (ldx & 7) || rows_per_batch <= 0 || M < 0 || K <= 0 || K > CE_MAXK || smoothing < 0.f || smoothing >= 1.f) return AP_ERR_SHAPE;
     if (mix_batches != 0 && (mix_batches < 0 || (int64_t)mix_batches * rows_per_batch != M || 2 * K > CE_MAXK)) return AP_ERR_SHAPE;
@@ -254,6 +269,6 @@ extern "C" int ap_soft_ce_sparse_fwd_bwd(const ap_bf16* logits, int ldx, const i
     if (M == 0) return AP_OK;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_soft_ce_sparse, dim3((unsigned)((M + 4 * CE_SR - 1) / (4 * CE_SR))), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const bf16_t*>(logits), ldx,
-                       idx, val, K, p_sb, p_sn, rows_per_batch, smoothing, row_loss, reinterpret_cast<bf16_t*>(dlogits), grad_scale, M, C, mix_lam, mix_batches);
+                       idx, val, K, p_sb, p_sn, rows_per_batch, smoothing, row_loss, reinterpret_cast<bf16_t*>(dlogits), grad_scale, M, C, mix_lam, mix_batches, mix_lam_dev);
     return ap_check_launch();
 }

@@ -871,6 +871,20 @@ class MixSwapFn(torch.autograd.Function):
         return ops.mix_token_swap(dy.contiguous(), *ctx.box), None, None, None, None
 
 
+class MixSwapDevFn(torch.autograd.Function):
+    """MixSwapFn with the step's box in device memory (graph.StepScalars: int32 {bbx1, bbx2, bby1, bby2} on the token-label grid, times
+    `scale`): the launch arguments do not change from step to step, so the step can be replayed from a HIP graph"""
+
+    @staticmethod
+    def forward(ctx, x, scalars, scale):
+        ctx.scalars, ctx.scale = scalars, scale
+        return ops.mix_token_swap_dev(x.contiguous(), scalars.box_ptr, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.mix_token_swap_dev(dy.contiguous(), ctx.scalars.box_ptr, ctx.scale), None, None
+
+
 _BICUBIC_TAPS = {}
 
 
@@ -999,9 +1013,12 @@ class TokenLabelCEFn(torch.autograd.Function):
         cls2d = padded(x_cls.reshape(B, C))
         sb, sc, sn = target.stride()
         rl_aux, d_aux = ops.soft_ce_fwd_bwd(aux2d, C, target[:, :, 2:], sb, sc, sn, N, dense_weight / (B * N))
-        mixed = lam < 1
-        rl_cls, d_cls = ops.soft_ce_fwd_bwd(cls2d, C, target[:, :, 1], sb, sc, 0, 1, cls_weight / B,
-                                            mix_lam=lam if mixed else 1.0, mix_batches=B if mixed else 0)
+        if hasattr(lam, "lam_ptr"):           # graph.StepScalars: lam lives in device memory (lam = 1 blends nothing: lam t + 0 t' = t)
+            rl_cls, d_cls = ops.soft_ce_fwd_bwd(cls2d, C, target[:, :, 1], sb, sc, 0, 1, cls_weight / B, mix_lam=1.0, mix_batches=B, mix_lam_ptr=lam.lam_ptr)
+        else:
+            mixed = lam < 1
+            rl_cls, d_cls = ops.soft_ce_fwd_bwd(cls2d, C, target[:, :, 1], sb, sc, 0, 1, cls_weight / B,
+                                                mix_lam=lam if mixed else 1.0, mix_batches=B if mixed else 0)
         ctx.save_for_backward(d_cls, d_aux)
         ctx.dims = (B, N, C)
         return ops.loss_combine(rl_cls, cls_weight / B, rl_aux, dense_weight / (B * N))
@@ -1041,8 +1058,12 @@ class SparseTokenLabelCEFn(torch.autograd.Function):
                                                    dense_weight / (B * N))
         # the class row: slot 1 of every image, in place (stride (2 + N) K); the mix-token target lam * t[b] + (1 - lam) * t[B-1-b] is
         # formed by the kernel from the two images' pairs
-        rl_cls, d_cls = ops.soft_ce_sparse_fwd_bwd(padded(x_cls.reshape(B, C)), C, idx[:, 1], val[:, 1], (2 + N) * K, 0, 1, smoothing, cls_weight / B,
-                                                   mix_lam=lam, mix_batches=B if lam < 1 else 0)
+        if hasattr(lam, "lam_ptr"):           # graph.StepScalars
+            rl_cls, d_cls = ops.soft_ce_sparse_fwd_bwd(padded(x_cls.reshape(B, C)), C, idx[:, 1], val[:, 1], (2 + N) * K, 0, 1, smoothing, cls_weight / B,
+                                                       mix_lam=1.0, mix_batches=B, mix_lam_ptr=lam.lam_ptr)
+        else:
+            rl_cls, d_cls = ops.soft_ce_sparse_fwd_bwd(padded(x_cls.reshape(B, C)), C, idx[:, 1], val[:, 1], (2 + N) * K, 0, 1, smoothing, cls_weight / B,
+                                                       mix_lam=lam, mix_batches=B if lam < 1 else 0)
         ctx.save_for_backward(d_cls, d_aux)
         ctx.dims = (B, N, C)
         return ops.loss_combine(rl_cls, cls_weight / B, rl_aux, dense_weight / (B * N))

@@ -1,0 +1,169 @@
+"""A training step as ONE HIP graph (missing 4; SURVEY.md section 8(f) row N2 / BASELINE configs[2]).
+
+The early AutoProg stages -- (l, r) = (9, 128), (12, 160): main_prog.py:973-974 resizes every batch to the stage's resolution,
+:1824-1836 picks a sub-network per step in a search -- are launch-gap bound on an MI355X: ~450 kernels of ~10 us each, and the GPU-side
+gap between two dependent launches (~1.5 us) is a tenth of the kernel it precedes.  A graph replay removes those gaps (stage 1: 5.36 ->
+4.25 ms per step, profiles/r04_exp_graph.txt).  What stood in the way was that a step reads HOST scalars that change every step:
+
+    the mix-token box and its lam            models/volo.py:319-339, 649-658, 684-691 ; loss/cross_entropy.py:149-152
+    the learning rate and Adam's bias corrections   main_prog.py:1019-1027 (scheduler writes param_groups[i]["lr"]; torch.optim.AdamW's step count)
+
+DropPath's draws are device-side already (torch's generator is graph-safe: a replay advances its philox offset).  Here those scalars
+live in a small DEVICE buffer (`StepScalars`: ABI 6 entry points ap_mix_token_swap_dev, ap_soft_ce_*_dev, the `step_scalars` argument of
+ap_adamw_ema_step) that is refreshed by one 64-byte host-to-device copy in front of every replay; the host draws the box with the
+same numpy calls in the same order as the eager forward, so a graphed run and an eager run with the same seeds see the same boxes.
+
+    gs = GraphedStep(model, loss_fn, reducer, opt, images, target)      # static input buffers (copied from the given tensors)
+    gs.capture()                                                        # warm-up steps on a side stream, then one captured step
+    loss = gs.step(new_images, new_target)                              # copies the batch in, refreshes the scalars, replays
+
+One graph per elastic configuration: `set_sample_config` changes which kernels run, so the driver keeps a GraphedStep per (l, r).
+Single-rank only (RCCL collectives are not captured here): with world > 1 the eager step runs."""
+import numpy as np
+import torch
+
+from . import ops
+
+
+class StepScalars:
+    """the per-step host scalars of a training step in device memory.  Layout (16 x 4 bytes; include/autoprog_hip.h ap_step_scalars):
+         int32 [0..3]  mix-token box on the token-label grid: bbx1, bbx2, bby1, bby2 (rows [bbx1, bbx2), columns [bby1, bby2))
+         fp32  [4]     lam of the loss = 1 - box area / N
+         fp32  [5..7]  learning rate, 1 - beta1^t, sqrt(1 - beta2^t)
+       The host side is a pinned buffer; push() is one asynchronous copy on the current stream."""
+
+    def __init__(self, device):
+        self.host = torch.zeros(16, dtype=torch.int32).pin_memory()
+        self.dev = torch.zeros(16, dtype=torch.int32, device=device)
+        self._hf = self.host.view(torch.float32)
+        self._hf[4] = 1.0
+        self.push()
+
+    @property
+    def box_ptr(self):
+        return self.dev.data_ptr()
+
+    @property
+    def lam_ptr(self):
+        return self.dev.data_ptr() + 4 * 4
+
+    @property
+    def adam_ptr(self):
+        return self.dev.data_ptr() + 5 * 4
+
+    def set_box(self, box, n_tokens):
+        bbx1, bby1, bbx2, bby2 = (int(v) for v in box)
+        self.host[0], self.host[1], self.host[2], self.host[3] = bbx1, bbx2, bby1, bby2
+        self._hf[4] = 1.0 - ((bbx2 - bbx1) * (bby2 - bby1) / float(n_tokens))
+        self.box = (bbx1, bby1, bbx2, bby2)
+
+    def set_adam(self, lr, beta1, beta2, step):
+        self._hf[5] = float(lr)
+        self._hf[6] = 1.0 - float(beta1) ** int(step)
+        self._hf[7] = float(np.sqrt(1.0 - float(beta2) ** int(step)))
+
+    def push(self):
+        self.dev.copy_(self.host, non_blocking=True)
+
+
+class DeviceBox:
+    """what a VOLO forward in graph mode returns in place of the (bbx1, bby1, bbx2, bby2) tuple: the loss reads lam from the device"""
+
+    def __init__(self, scalars):
+        self.scalars = scalars
+
+    def __iter__(self):                      # callers that unpack the box get the host copy of the step being prepared
+        return iter(self.scalars.box)
+
+
+class GraphedStep:
+    def __init__(self, model, loss_fn, reducer, opt, images, target, clip_grad=None, clip_mode="norm"):
+        if getattr(reducer, "world", 1) > 1:
+            raise ValueError("GraphedStep: single-rank only (the gradient exchange is not captured)")
+        self.model, self.loss_fn, self.reducer, self.opt = model, loss_fn, reducer, opt
+        self.clip_grad, self.clip_mode = clip_grad, clip_mode
+        self.images = images.clone()
+        self.target = _clone_target(target)
+        self.scalars = StepScalars(self.images.device)
+        self.graph = None
+        self.loss = None
+
+    # ---- host side of a step: the draws VOLO.forward makes (models/volo.py:649-653: beta, then rand_bbox's two randint calls)
+    def _draw(self):
+        m = self.model
+        if getattr(m, "mix_token", False) and m.training:
+            from .models.volo import rand_bbox
+            r = m.patch_embed.resize_to or self.images.shape[-1]
+            pe = m.patch_embed
+            patch = pe.proj.kernel_size[0] * (pe.conv[0].stride[0] if pe.stem_conv else 1)
+            g1 = r // patch                                       # token grid in front of the first stage (patch size 8 in every VOLO)
+            lam = np.random.beta(m.beta, m.beta)
+            box = rand_bbox((self.images.shape[0], g1, g1, 0), lam, scale=m.pooling_scale)
+            n = (g1 // m.pooling_scale) ** 2
+        else:
+            box, n = (0, 0, 0, 0), 1
+        self.scalars.set_box(box, n)
+
+    def _prepare(self):
+        self._draw()
+        o = self.opt
+        self.scalars.set_adam(o.param_groups[0]["lr"], o.betas[0], o.betas[1], o.step_count + 1)
+        self.scalars.push()
+
+    def _step_body(self):
+        self.reducer.zero_grad()
+        loss = self.loss_fn(self.model(self.images), self.target)
+        loss.backward()
+        self.reducer.finish()
+        self.opt.step(clip_grad=self.clip_grad, clip_mode=self.clip_mode, scalars=self.scalars)
+        return loss
+
+    def capture(self, warmup=3):
+        self.model.step_scalars = self.scalars
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._prepare()
+                self._step_body()
+        torch.cuda.current_stream().wait_stream(s)
+        self._prepare()
+        count = self.opt.step_count
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._step_body()
+        self.opt.step_count = count            # the capture recorded a step, it did not run one
+        return self
+
+    def step(self, images=None, target=None):
+        if self.graph is None:
+            raise RuntimeError("GraphedStep.step() before capture()")
+        if images is not None:
+            self.images.copy_(images, non_blocking=True)
+        if target is not None:
+            _copy_target(self.target, target)
+        self.model.step_scalars = self.scalars
+        self._prepare()
+        self.graph.replay()
+        self.opt.step_count += 1
+        return self.loss
+
+    def release(self):
+        if getattr(self.model, "step_scalars", None) is self.scalars:
+            self.model.step_scalars = None
+
+
+def _clone_target(t):
+    from .loss.cross_entropy import SparseTokenLabelTarget
+    if isinstance(t, SparseTokenLabelTarget):
+        return SparseTokenLabelTarget(t.idx.clone(), t.val.clone(), t.smoothing)
+    return t.clone()
+
+
+def _copy_target(dst, src):
+    from .loss.cross_entropy import SparseTokenLabelTarget
+    if isinstance(dst, SparseTokenLabelTarget):
+        dst.idx.copy_(src.idx, non_blocking=True)
+        dst.val.copy_(src.val, non_blocking=True)
+    else:
+        dst.copy_(src, non_blocking=True)

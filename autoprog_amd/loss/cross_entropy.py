@@ -61,7 +61,8 @@ class _TokenLabelBase(nn.Module):
 
     def forward(self, x, target):
         output, aux_output, bb = x
-        bbx1, bby1, bbx2, bby2 = bb
+        dev_box = getattr(bb, "scalars", None)                  # graph.DeviceBox: the step's box / lam live in device memory (graph replay)
+        bbx1, bby1, bbx2, bby2 = (0, 0, 0, 0) if dev_box is not None else bb
         B, N, C = aux_output.shape
         if isinstance(target, SparseTokenLabelTarget):
             # the sparse kernel takes up to 16 (class, score) pairs per row -- the mix-token class row carries 2K -- and rows of up to
@@ -69,16 +70,18 @@ class _TokenLabelBase(nn.Module):
             K = target.idx.shape[-1]
             if (type(self)._adjust_cls is _TokenLabelBase._adjust_cls and target.idx.is_cuda and target.idx.shape[1] == 2 + N
                     and 2 * K <= SPARSE_CE_MAX_PAIRS and -(-C // 8) * 8 <= SPARSE_CE_MAX_CLASSES):
-                lam = 1 - ((bbx2 - bbx1) * (bby2 - bby1) / N)
+                lam = dev_box if dev_box is not None else float(1 - ((bbx2 - bbx1) * (bby2 - bby1) / N))
                 return AF.SparseTokenLabelCEFn.apply(output.to(torch.bfloat16), aux_output.to(torch.bfloat16), target.idx, target.val,
-                                                     target.smoothing, float(lam), float(self.cls_weight), float(self.dense_weight))
+                                                     target.smoothing, lam, float(self.cls_weight), float(self.dense_weight))
             target = target.dense(C)
         target = target.float()
         if target.dim() == 3 and type(self)._adjust_cls is _TokenLabelBase._adjust_cls and target.is_cuda:
             # the production case (TokenLabelCrossEntropy with token labels): three launches, see functional.TokenLabelCEFn
-            lam = 1 - ((bbx2 - bbx1) * (bby2 - bby1) / N)
-            return AF.TokenLabelCEFn.apply(output.to(torch.bfloat16), aux_output.to(torch.bfloat16), target, float(lam),
+            lam = dev_box if dev_box is not None else float(1 - ((bbx2 - bbx1) * (bby2 - bby1) / N))
+            return AF.TokenLabelCEFn.apply(output.to(torch.bfloat16), aux_output.to(torch.bfloat16), target, lam,
                                            float(self.cls_weight), float(self.dense_weight))
+        if dev_box is not None:
+            raise NotImplementedError("a graph-mode forward (device-resident mix box) needs the fused token-label loss paths")
         aux2d = aux_output.reshape(B * N, C).to(torch.bfloat16)
         if target.dim() == 2:
             target_cls = target

@@ -513,6 +513,7 @@ class VOLO(nn.Module):
         trunc_normal_(self.pos_embed, std=0.02)
         self.apply(self._init_weights)
         self.active_layers = None          # ActiveLayerMask of the current elastic config (None = all)
+        self.step_scalars = None           # graph.StepScalars: the mix-token box comes from device memory (a step replayed from a HIP graph)
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):
@@ -613,7 +614,13 @@ class VOLO(nn.Module):
     def forward(self, x):
         x = self.forward_embeddings(x)
         patch_h = patch_w = 0
-        if self.mix_token and self.training:
+        dev = self.step_scalars if (self.mix_token and self.training) else None
+        if dev is not None:
+            # graph mode (autoprog_amd/graph.py): the host drew the box (same numpy calls, same order) and put it in device memory
+            patch_h, patch_w = x.shape[1] // self.pooling_scale, x.shape[2] // self.pooling_scale
+            bbx1, bby1, bbx2, bby2 = 0, 0, 0, 0
+            x = AF.MixSwapDevFn.apply(x, dev, self.pooling_scale)
+        elif self.mix_token and self.training:
             lam = np.random.beta(self.beta, self.beta)
             patch_h, patch_w = x.shape[1] // self.pooling_scale, x.shape[2] // self.pooling_scale
             bbx1, bby1, bbx2, bby2 = rand_bbox(x.size(), lam, scale=self.pooling_scale)
@@ -640,6 +647,12 @@ class VOLO(nn.Module):
         if self.mix_token and self.training:
             nc = x_aux.shape[-1]
             grid = x_aux.reshape(x_aux.shape[0], patch_h, patch_w, nc)
+            if dev is not None:
+                if nc % 8:
+                    raise NotImplementedError("graph-mode forward: class counts that are multiples of 8")
+                from ..graph import DeviceBox
+                grid = AF.MixSwapDevFn.apply(grid, dev, 1)
+                return x_cls, grid.reshape(grid.shape[0], patch_h * patch_w, nc), DeviceBox(dev)
             if nc % 8 == 0:
                 grid = AF.MixSwapFn.apply(grid, bbx1, bbx2, bby1, bby2)
             else:                       # odd class counts only occur in unit-test sized heads

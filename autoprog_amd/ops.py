@@ -497,6 +497,15 @@ def mix_token_swap(x, r0, r1, c0, c1):
     return y
 
 
+def mix_token_swap_dev(x, box_ptr, scale):
+    """the same with the box {r0, r1, c0, c1} read from device memory (int32[4] at box_ptr, times `scale`): graph.StepScalars"""
+    _req(x, BF16, "x")
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    check(lib.ap_mix_token_swap_dev(x.data_ptr(), y.data_ptr(), B, H, W, C, int(box_ptr), int(scale), _stream()), "ap_mix_token_swap_dev")
+    return y
+
+
 def loss_combine(a, wa, b=None, wb=0.0):
     """fp32 scalar tensor wa * sum(a) + wb * sum(b) (one launch)"""
     _req(a, torch.float32, "a")
@@ -506,21 +515,23 @@ def loss_combine(a, wa, b=None, wb=0.0):
     return out
 
 
-def soft_ce_fwd_bwd(logits, C, target, t_sb, t_sc, t_sn, rows_per_batch, grad_scale, mix_lam=1.0, mix_batches=0):
-    """returns (row_loss fp32 [M], dlogits bf16 like logits); mix_batches = B: target of batch b is lam*t[b] + (1-lam)*t[B-1-b]."""
+def soft_ce_fwd_bwd(logits, C, target, t_sb, t_sc, t_sn, rows_per_batch, grad_scale, mix_lam=1.0, mix_batches=0, mix_lam_ptr=None):
+    """returns (row_loss fp32 [M], dlogits bf16 like logits); mix_batches = B: target of batch b is lam*t[b] + (1-lam)*t[B-1-b].
+    mix_lam_ptr: device address of lam (overrides mix_lam: graph.StepScalars)"""
     _req(logits, BF16, "logits")
     if not (target.is_cuda and target.dtype == torch.float32):
         raise AutoProgHipError("target must be a CUDA fp32 tensor (any strides; pass them explicitly)")
     M, ldx = logits.shape
     row_loss = torch.empty(M, dtype=torch.float32, device=logits.device)
     dlogits = torch.empty_like(logits)
-    check(lib.ap_soft_ce_fwd_bwd(logits.data_ptr(), ldx, target.data_ptr(), int(t_sb), int(t_sc), int(t_sn), int(rows_per_batch),
-                                 row_loss.data_ptr(), dlogits.data_ptr(), float(grad_scale), M, C, float(mix_lam), int(mix_batches), _stream()),
-          "ap_soft_ce_fwd_bwd")
+    check(lib.ap_soft_ce_fwd_bwd_dev(logits.data_ptr(), ldx, target.data_ptr(), int(t_sb), int(t_sc), int(t_sn), int(rows_per_batch),
+                                     row_loss.data_ptr(), dlogits.data_ptr(), float(grad_scale), M, C, float(mix_lam), int(mix_batches),
+                                     int(mix_lam_ptr) if mix_lam_ptr else None, _stream()),
+          "ap_soft_ce_fwd_bwd_dev")
     return row_loss, dlogits
 
 
-def soft_ce_sparse_fwd_bwd(logits, C, idx, val, p_sb, p_sn, rows_per_batch, smoothing, grad_scale, mix_lam=1.0, mix_batches=0):
+def soft_ce_sparse_fwd_bwd(logits, C, idx, val, p_sb, p_sn, rows_per_batch, smoothing, grad_scale, mix_lam=1.0, mix_batches=0, mix_lam_ptr=None):
     """soft-target CE against top-K (class, score) pairs + label smoothing (the token-label target before it is densified);
     idx int32 / val fp32 with K = idx.shape[-1] pairs per row at b * p_sb + n * p_sn.  Returns (row_loss fp32 [M], dlogits bf16).
     mix_batches = B: the target of row (b, n) is mix_lam * t[b, n] + (1 - mix_lam) * t[B-1-b, n] (the mix-token class target)."""
@@ -530,10 +541,10 @@ def soft_ce_sparse_fwd_bwd(logits, C, idx, val, p_sb, p_sn, rows_per_batch, smoo
     M, ldx = logits.shape
     row_loss = torch.empty(M, dtype=torch.float32, device=logits.device)
     dlogits = torch.empty_like(logits)
-    check(lib.ap_soft_ce_sparse_fwd_bwd(logits.data_ptr(), ldx, idx.data_ptr(), val.data_ptr(), int(idx.shape[-1]), int(p_sb), int(p_sn),
-                                        int(rows_per_batch), float(smoothing), row_loss.data_ptr(), dlogits.data_ptr(), float(grad_scale), M, C,
-                                        float(mix_lam), int(mix_batches), _stream()),
-          "ap_soft_ce_sparse_fwd_bwd")
+    check(lib.ap_soft_ce_sparse_fwd_bwd_dev(logits.data_ptr(), ldx, idx.data_ptr(), val.data_ptr(), int(idx.shape[-1]), int(p_sb), int(p_sn),
+                                            int(rows_per_batch), float(smoothing), row_loss.data_ptr(), dlogits.data_ptr(), float(grad_scale), M, C,
+                                            float(mix_lam), int(mix_batches), int(mix_lam_ptr) if mix_lam_ptr else None, _stream()),
+          "ap_soft_ce_sparse_fwd_bwd_dev")
     return row_loss, dlogits
 
 

@@ -126,7 +126,7 @@ class FlatAdamWEma:
             check(lib.ap_batched_transpose_bf16(self.p16.data_ptr(), self.p16_t.data_ptr(), self._tr_desc.data_ptr(), self._tr_count,
                                                 self._tr_tiles, ops._stream()), "ap_batched_transpose_bf16")
 
-    def step(self, clip_grad=None, clip_mode="norm"):
+    def step(self, clip_grad=None, clip_mode="norm", scalars=None):
         """one AdamW + EMA update from the gradient slab.  clip_grad / clip_mode: the reference's `--clip-grad` / `--clip-mode`
         (main_prog.py:129-132; prog/scaler.py:60-68 calls timm's dispatch_clip_grad between backward and optimizer.step()):
           'norm'  -- torch.nn.utils.clip_grad_norm_(parameters, clip_grad): ONE pass over the flat slab for the global norm
@@ -134,7 +134,9 @@ class FlatAdamWEma:
           'value' -- clip_grad_value_: every gradient element clamped to [-clip, clip] inside the update kernel.
         Both act on the MEAN gradient: with GradientBucketReducer(defer_mean=True) the slab still holds the all-reduced SUM and the
         1/world factor is applied first -- clipping the slab from outside before step() would be off by `world`.
-        `last_grad_norm` (device scalar, 'norm' mode) is the norm of the mean gradient before clipping."""
+        `last_grad_norm` (device scalar, 'norm' mode) is the norm of the mean gradient before clipping.
+        scalars: graph.StepScalars -- the learning rate and Adam's bias corrections are read from device memory (the caller refreshed
+        them for this step): nothing in the launch changes from step to step, the step can be replayed from a HIP graph."""
         self.step_count += 1
         g = self.reducer.flat
         if self.g is None:                                   # slab length not a multiple of 4: padded copy
@@ -161,7 +163,7 @@ class FlatAdamWEma:
             raise ValueError("FlatAdamWEma: both parameter groups must share one learning rate (timm schedulers do)")
         check(lib.ap_adamw_ema_step(self.p.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.wd_mask.data_ptr(),
                                     self.n_pad, lr, self.betas[0], self.betas[1], self.eps, wd, self.step_count, gscale,
-                                    gnorm_ptr, max_norm, clip_value, self._ema_ptrs, self._ema_decay, len(self.ema), self.p16.data_ptr(),
+                                    gnorm_ptr, max_norm, clip_value, scalars.adam_ptr if scalars is not None else None, self._ema_ptrs, self._ema_decay, len(self.ema), self.p16.data_ptr(),
                                     ops._stream()), "ap_adamw_ema_step")
         self._refresh_transposes()
         from . import functional

@@ -297,6 +297,10 @@ def main():
     ap.add_argument("--dense-target", action="store_true",
                     help="feed the token-label target as the dense fp32 [B,1000,2+N] tensor (default: the top-5 label maps it is built from; the CE "
                          "kernel forms the same target rows in registers, main_prog.py:994-1004 folded into the loss)")
+    ap.add_argument("--graph", action="store_true",
+                    help="d1 / stages workloads, one rank: replay each step from a HIP graph (autoprog_amd/graph.py: the mix-token box, lam, lr and "
+                         "Adam's bias corrections live in device memory and are refreshed in front of every replay).  The early AutoProg stages are "
+                         "launch-gap bound; never the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-roofline", action="store_true")
@@ -424,7 +428,29 @@ def main():
                 opt.step()
             return loss
 
-    if args.workload == "stages":
+    eager_step = step
+    if args.graph:
+        if world > 1 or args.no_optimizer or args.workload not in ("d1", "stages") or args.search_mix:
+            raise SystemExit("--graph: one rank, d1 or stages (fixed schedule), with the optimizer")
+        from autoprog_amd.graph import GraphedStep
+        if args.workload == "stages":
+            graphs = []
+            for l_, r_, dp_ in STAGES:       # one graph per elastic configuration: set_sample_config decides which kernels a step launches
+                model.set_sample_config(dict(layer_num=l_, min_layer_num=STAGES[0][0], max_layer_num=STAGES[-1][0], input_size=r_))
+                model.set_drop_path_rate(dp_)
+                graphs.append(GraphedStep(model, loss_fn, reducer, opt, images, targets[r_]).capture())
+            gcount = [0]
+
+            def step():
+                g = graphs[gcount[0] % len(graphs)]
+                gcount[0] += 1
+                return g.step()
+        else:
+            graph1 = GraphedStep(model, loss_fn, reducer, opt, images, target).capture()
+
+            def step():
+                return graph1.step()
+    elif args.workload == "stages":
         # MIOpen measures its conv solvers the first time it sees a shape (cudnn.benchmark): touch every resolution once, untimed
         for l_, r_, dp_ in STAGES:
             model.set_sample_config(dict(layer_num=l_, min_layer_num=STAGES[0][0], max_layer_num=STAGES[-1][0], input_size=r_))
@@ -487,8 +513,11 @@ def main():
         probe = GemmProbe()
         probe.install()
         nprobe = 3 if args.workload == "d1" else 4
+        if args.graph:                 # (the probe wraps the Python launch functions: the eager step of the same configuration sequence)
+            for g_ in (graphs if args.workload == "stages" else [graph1]):
+                g_.release()
         for _ in range(nprobe):
-            step()
+            eager_step()
         launches, ms, flops = probe.summary()
         if rank == 0 and os.environ.get("AP_GEMM_TABLE") == "1":
             print(probe.table(), file=sys.stderr, flush=True)
@@ -554,7 +583,8 @@ def main():
                 "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "allreduce_ms_standalone": None if allreduce_ms is None else round(allreduce_ms, 3),
                 "config": {"workload": wl,
                            "model": args.variant, "global_batch": B * world, "per_gpu_batch": B, "res": res, "parallelism": "dp%d" % world,
-                           "step": "fwd+loss+bwd" + ("" if args.no_optimizer else "+AdamW+4xEMA") + ("+RCCL grad all-reduce" if world > 1 else ""),
+                           "step": "fwd+loss+bwd" + ("" if args.no_optimizer else "+AdamW+4xEMA") + ("+RCCL grad all-reduce" if world > 1 else "") +
+                                   (" (each step replayed from a HIP graph)" if args.graph else ""),
                            "target": ("soft-target [B,1000]" if args.workload == "deit_base" else
                                       "dense fp32 [B,1000,2+N]" if args.dense_target else
                                       "top-5 label maps [B,2+N,5] + smoothing 0.1, densified inside the CE kernel (== the dense tensor of main_prog.py:994-1004)"),

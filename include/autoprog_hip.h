@@ -218,6 +218,10 @@ int ap_class_attn_bwd(const ap_bf16* q, const ap_bf16* kv, const ap_bf16* kv_cls
  * y = x except y[b, r0:r1, c0:c1, :] = x[B-1-b, r0:r1, c0:c1, :]  (x: [B,H,W,C])            */
 int ap_mix_token_swap(const ap_bf16* x, ap_bf16* y, int B, int H, int W, int C,
                       int r0, int r1, int c0, int c1, ap_stream_t stream);
+/* (ABI version 6) the same with the box in DEVICE memory: box_dev = int[4] {r0, r1, c0, c1} on the token-label grid, multiplied by `scale`
+ * (2 for the token swap in front of the stages, 1 for the aux-logit swap: models/volo.py:654-658, 685-689).  Part of the graph-replayable
+ * step: the box of the step is written into a device buffer in front of the replay instead of being a launch argument. */
+int ap_mix_token_swap_dev(const ap_bf16* x, ap_bf16* y, int B, int H, int W, int C, const int* box_dev, int scale, ap_stream_t stream);
 
 /* ---- Dense soft-target cross entropy (loss/cross_entropy.py:35-36, 147-156) -------------
  * logits [M,ldx] (C valid classes); target element (row,c) =
@@ -242,6 +246,14 @@ int ap_soft_ce_fwd_bwd(const ap_bf16* logits, int ldx, const float* target, int6
 int ap_soft_ce_sparse_fwd_bwd(const ap_bf16* logits, int ldx, const int* idx, const float* val, int K, int64_t p_sb, int64_t p_sn,
                               int rows_per_batch, float smoothing, float* row_loss, ap_bf16* dlogits, float grad_scale,
                               int64_t M, int C, float mix_lam, int mix_batches, ap_stream_t stream);
+/* (ABI version 6) both losses with the mix-token lam in DEVICE memory (mix_lam_dev non-NULL overrides mix_lam; pass mix_batches = B
+ * always: lam = 1 gives lam t + 0 t' = t exactly) -- the graph-replayable step */
+int ap_soft_ce_fwd_bwd_dev(const ap_bf16* logits, int ldx, const float* target, int64_t t_sb, int64_t t_sc, int64_t t_sn, int rows_per_batch,
+                           float* row_loss, ap_bf16* dlogits, float grad_scale, int64_t M, int C, float mix_lam, int mix_batches,
+                           const float* mix_lam_dev, ap_stream_t stream);
+int ap_soft_ce_sparse_fwd_bwd_dev(const ap_bf16* logits, int ldx, const int* idx, const float* val, int K, int64_t p_sb, int64_t p_sn,
+                                  int rows_per_batch, float smoothing, float* row_loss, ap_bf16* dlogits, float grad_scale, int64_t M, int C,
+                                  float mix_lam, int mix_batches, const float* mix_lam_dev, ap_stream_t stream);
 /* out[0] = wa * sum(a[0:na]) + wb * sum(b[0:nb]): cls_weight * mean(row losses) + dense_weight * mean(row losses)
  * of the token-label loss (loss/cross_entropy.py:154-156) in one launch */
 int ap_loss_combine(const float* a, int64_t na, float wa, const float* b, int64_t nb, float wb, float* out, ap_stream_t stream);
@@ -357,6 +369,8 @@ int ap_adamw_ema_step(float* p, const float* g, float* m, float* v, const unsign
                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                       float grad_scale /* g is multiplied by this first: 1/world_size turns the all-reduced SUM into the mean */,
                       const float* gnorm_sq, float max_norm, float clip_value,
+                      const float* step_scalars_dev /* nullable DEVICE float[3] {lr, 1 - beta1^step, sqrt(1 - beta2^step)}: overrides lr / step
+                                                     * (the graph-replayable step: the scheduler's lr and the step count change per replay) */,
                       float* const* ema, const float* ema_decay, int n_ema,
                       ap_bf16* p_bf16 /* nullable: bf16 copy of the updated parameters, same offsets */,
                       ap_stream_t stream);
