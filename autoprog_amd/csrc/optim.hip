@@ -123,8 +123,10 @@ extern "C" int ap_adamw_ema_step(float* p, const float* g, float* m, float* v, c
     AdamArgs a;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.gscale = grad_scale;
     a.gnorm_sq = gnorm_sq; a.max_norm = max_norm; a.clip_value = clip_value > 0.f ? clip_value : 0.f; a.step_dev = step_scalars_dev;
-    a.bc1 = 1.0f - powf(beta1, (float)step);
-    a.bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    // (in double from the float arguments, rounded once: graph.StepScalars.set_adam forms the SAME two numbers on the host, so a step
+    // replayed from a graph -- which reads them from device memory -- is bit-identical to the eager step)
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     a.n_ema = n_ema;
     for (int e = 0; e < 4; ++e) { a.ema[e] = (e < n_ema) ? ema[e] : nullptr; a.decay[e] = (e < n_ema) ? ema_decay[e] : 0.f; if (e < n_ema && !ema[e]) return AP_ERR_NULL; }
     int64_t grid = (n / 4 + 255) / 256;

@@ -58,9 +58,11 @@ class StepScalars:
         self.box = (bbx1, bby1, bbx2, bby2)
 
     def set_adam(self, lr, beta1, beta2, step):
+        # exactly what ap_adamw_ema_step derives from its float arguments (csrc/optim.hip): double arithmetic on the fp32-rounded betas
+        b1, b2 = float(np.float32(beta1)), float(np.float32(beta2))
         self._hf[5] = float(lr)
-        self._hf[6] = 1.0 - float(beta1) ** int(step)
-        self._hf[7] = float(np.sqrt(1.0 - float(beta2) ** int(step)))
+        self._hf[6] = 1.0 - b1 ** int(step)
+        self._hf[7] = float(np.sqrt(1.0 - b2 ** int(step)))
 
     def push(self):
         self.dev.copy_(self.host, non_blocking=True)

@@ -301,6 +301,10 @@ def main():
                     help="d1 / stages workloads, one rank: replay each step from a HIP graph (autoprog_amd/graph.py: the mix-token box, lam, lr and "
                          "Adam's bias corrections live in device memory and are refreshed in front of every replay).  The early AutoProg stages are "
                          "launch-gap bound; never the default line")
+    ap.add_argument("--stage-blocks", action="store_true",
+                    help="stages workload: run the four stages in consecutive blocks of steps/4 (the schedule's order: a stage lasts 25 epochs) instead "
+                         "of one stage per step in turn -- in turn, the host enqueues the short stage-1 step while the GPU still runs the long "
+                         "stage-4 step before it, which hides the launch gaps a real stage-1 epoch has")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-roofline", action="store_true")
@@ -397,13 +401,20 @@ def main():
         random.seed(0)                 # identical (l, r) sequence on every rank (reference: random.seed(epoch), main_prog.py:1861)
         counter = [0]
 
+        def stage_of(i):
+            if not args.stage_blocks:
+                return i % len(STAGES)
+            i -= args.warmup                                   # the timed steps: steps / 4 consecutive steps per stage (warm-up: stage 0)
+            per = max(1, args.steps // len(STAGES))
+            return min(max(i, 0) // per, len(STAGES) - 1) if i < args.steps else (i - args.steps) % len(STAGES)
+
         def step():
             i = counter[0]
             counter[0] += 1
             if args.search_mix:
                 l, r, dp = random.choice(l_list), random.choice(r_list), 0.1        # search epochs use the final strengths (main_prog.py:814-815)
             else:
-                l, r, dp = STAGES[i % len(STAGES)]
+                l, r, dp = STAGES[stage_of(i)]
             model.set_sample_config(dict(layer_num=l, min_layer_num=l_list[0], max_layer_num=l_list[-1], input_size=r))
             model.set_drop_path_rate(dp)
             reducer.zero_grad()
@@ -442,7 +453,7 @@ def main():
             gcount = [0]
 
             def step():
-                g = graphs[gcount[0] % len(graphs)]
+                g = graphs[stage_of(gcount[0])]
                 gcount[0] += 1
                 return g.step()
         else:
@@ -565,7 +576,8 @@ def main():
                   "soft-target CE, batch %d, on-device resize from %d px" % (DEIT_L, DEIT_R, B, res))
         elif args.workload == "stages":
             wl = ("BASELINE.json configs[2]: %s supernet over the AutoProg stages (l,r) = %s, %s, batch %d, on-device resize from %d px"
-                  % (args.variant, [(s[0], s[1]) for s in STAGES], "uniform random (l,r) per step" if args.search_mix else "a quarter of the steps each", B, res))
+                  % (args.variant, [(s[0], s[1]) for s in STAGES], "uniform random (l,r) per step" if args.search_mix else
+                     ("a quarter of the steps each, in consecutive blocks" if args.stage_blocks else "a quarter of the steps each, one stage per step in turn"), B, res))
         else:
             wl = (("BASELINE.json configs[4]: volo_d5 448px token-label training step, batch %d; " % B) +
                   ("forward Linear GEMMs of the transformer blocks on e4m3 operands (fp32 accumulate, delayed per-tensor scaling), everything else bf16"
