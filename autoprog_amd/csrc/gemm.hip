@@ -739,6 +739,26 @@ k_tn_reduce(TnGroup grp) {
 }
 
 
+// the GELU table of gemm_epi.h (gelu = 3 launches of the 8-phase kernel): a static device array, filled once per process on the stream of
+// its first use (no allocation inside the library; AP_GELU_TABLE=0: the row phase evaluates the functions instead)
+__device__ unsigned g8_gelu_table[2 * GQ_TAB_N];
+__global__ void __launch_bounds__(256) k_build_gelu_table(unsigned* tab) {
+    const unsigned idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < 2 * GQ_TAB_N) tab[idx] = gq_tab_entry(idx);
+}
+static const unsigned* g8_gelu_table_ptr(hipStream_t st) {
+    static int state = 0;                       // 0: not built, 1: built, -1: switched off
+    static unsigned* ptr = nullptr;
+    if (state == 0) {
+        const char* e = getenv("AP_GELU_TABLE");
+        if (e && e[0] == '0') { state = -1; return nullptr; }
+        if (hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(g8_gelu_table)) != hipSuccess || !ptr) { (void)hipGetLastError(); state = -1; return nullptr; }
+        hipLaunchKernelGGL(k_build_gelu_table, dim3(2 * GQ_TAB_N / 256), dim3(256), 0, st, ptr);
+        state = 1;
+    }
+    return state == 1 ? ptr : nullptr;
+}
+
 // launch of the persistent 8-phase kernel (gemm8p.h): one instantiation per epilogue flavour of the training step, a generic one
 // for anything else
 template <int NT1, int EF>
@@ -903,7 +923,10 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     }
     // variants 20 / 21: the persistent 8-phase kernel of gemm8p.h with 256 x 192 / 256 x 256 tiles (whole 8-column chunks only)
     if ((variant == 20 || variant == 21) && ((K & 63) || (N & 7) || (ldc & 7) || (ep.residual && (ep.ldr & 7)))) variant = 1;
-    if (variant == 20 || variant == 21) return g8_launch(variant == 20 ? 192 : 256, A, lda, B, ldb, C, ldc, M, N, K, ep, (hipStream_t)stream);
+    if (variant == 20 || variant == 21) {
+        if (ep.gelu == 3) ep.gelu_tab = g8_gelu_table_ptr((hipStream_t)stream);
+        return g8_launch(variant == 20 ? 192 : 256, A, lda, B, ldb, C, ldc, M, N, K, ep, (hipStream_t)stream);
+    }
     const int lds_epi = rule_epi >= 0 ? rule_epi : (lds_epi_env >= 0 ? lds_epi_env : (variant != 2 && variant != 10));
 #define NT_LAUNCH(TMv, TNv, WMv, WNv)                                                                        \
     {                                                                                                          \

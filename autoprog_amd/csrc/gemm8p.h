@@ -65,6 +65,7 @@ __device__ __forceinline__ void g8_lds_st16(unsigned a, const u32x4& v) { asm vo
 __device__ __forceinline__ void g8_lds_st8(unsigned a, const u32x2& v) { asm volatile("ds_write_b64 %0, %1" :: "v"(a), "v"(v) : "memory"); }
 __device__ __forceinline__ u32x4 g8_lds_ld16(unsigned a) { u32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory"); return v; }
 __device__ __forceinline__ u32x2 g8_lds_ld8(unsigned a) { u32x2 v; asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(a) : "memory"); return v; }
+__device__ __forceinline__ unsigned g8_lds_ld4(unsigned a) { unsigned v; asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(a) : "memory"); return v; }
 
 struct G8Args {
     const bf16_t* A; int lda;
@@ -116,11 +117,15 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     constexpr int VMN = 4 + NT1;                 // DMA instructions of the three parts in flight behind a counted wait
     constexpr int KS = 49152 + 8192 * NT1;       // bytes of a K-tile buffer (A h0 | A h1 | B part 0 | B part 1); the two buffers are adjacent
     constexpr int STG = 2 * KS;                  // epilogue staging region: the rest of the LDS (48 KB at BN = 192, 32 KB at BN = 256)
-    constexpr int PASS_MT = NT1 == 1 ? 4 : 2;    // 16-row tiles per wave group and staging pass
+    // GTAB (the GELU flavours): 16 KB of the staging region hold the GELU table of gemm_epi.h (gelu = 3 launches: Phi(h) and the 8-bit
+    // derivative code per bf16 value); the staging passes are half as tall
+    constexpr bool GTAB = EF >= 0 && (EF & G8_GELU) != 0 && !FP8;
+    constexpr int PASS_MT = (NT1 == 1 ? 4 : 2) / (GTAB ? 2 : 1);    // 16-row tiles per wave group and staging pass
     constexpr int NPASS = 8 / PASS_MT;
     constexpr int RS = BN * 2;                   // bytes of a staged row
     constexpr int GRP = 16 * PASS_MT * RS;       // bytes of a wave group's staging area (24 KB / 16 KB)
-    static_assert(STG + 2 * GRP <= G8_LDS_BYTES, "staging region");
+    constexpr int TAB = STG + 2 * GRP;           // byte offset of the GELU table
+    static_assert(TAB + (GTAB ? 16384 : 0) <= G8_LDS_BYTES, "staging region");
     extern __shared__ __attribute__((aligned(16))) unsigned char g8_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -161,6 +166,16 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     const int t_begin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xi;
     const int t_end = (xcd < xr ? (xcd + 1) * (xq + 1) : xr * (xq + 1) + (xcd + 1 - xr) * xq);
     if (t_begin >= t_end) return;                                  // (whole workgroup; before any barrier)
+    const bool use_tab = GTAB && ep.gelu == 3 && ep.gelu_tab != nullptr;
+    if constexpr (GTAB) {
+        // the table by LDS-DMA, two 1 KB pieces per wave, in FRONT of the operand stream: every counted wait of the stream retires them
+        // first (in-order vmcnt), the K loop's barriers publish them long before the first epilogue reads
+        if (use_tab) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_global_load_lds(G8_GLB(ep.gelu_tab + (wave * 2 + j) * 256 + lane * 4), G8_LDS(g8_smem + TAB + (wave * 2 + j) * 1024), 16, 0, 0);
+        }
+    }
 
     // ---- issue side of the stream
     int q_tile = t_begin, q_kt = 0;
@@ -409,6 +424,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
             // ds_write_b128 then hit 8 different bank quads, and a DMA / row read still covers whole 128-byte lines.
             unsigned char* const stg = g8_smem + STG + wr * GRP;
             const unsigned stg_a = g8_lds_addr(stg);
+            const unsigned tab_a = g8_lds_addr(g8_smem + TAB);
             const bf16_t* const in_src = has_dgelu ? ep.dgelu_of : has_mul ? ep.mul_by : (has_res ? ep.residual : nullptr);
             const int in_ld = (has_dgelu || has_mul) ? ga.ldc : ep.ldr;
             const bool rowgelu = has_gelu;                        // GELU (and what follows it) is applied in the row phase
@@ -584,6 +600,28 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                     u32x2 q8v = {0u, 0u}; bool q8ok = false;
                     u32x2 gqv = {0u, 0u}; bool gqok = false;          // gelu = 3: the 8 derivative codes of this chunk
                     if (m < ga.M && n < ga.N) {
+                        if (GTAB && use_tab) {
+                            // x = 8 bf16-rounded pre-activations: gelu(h) = h * Phi(h) and the derivative code from the table (see gemm_epi.h)
+                            const float rs = has_rs ? ep.row_scale[m / ep.rows_per_scale] : 1.f;
+                            unsigned e8[8];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                e8[2 * q] = g8_lds_ld4(tab_a + 4 * gq_tab_index<0>(x[q]));
+                                e8[2 * q + 1] = g8_lds_ld4(tab_a + 4 * gq_tab_index<16>(x[q]));
+                            }
+                            G8_LGKM(0);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(e8[q]));
+                            u32x4 o;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                o[q] = pack_bf2(bf_lo(x[q]) * __uint_as_float(e8[2 * q]) * rs, bf_hi(x[q]) * __uint_as_float(e8[2 * q + 1]) * rs);
+                            // codes: byte 0 of each entry
+                            gqv[0] = __builtin_amdgcn_perm(e8[1], e8[0], 0x0c0c0400u) | (__builtin_amdgcn_perm(e8[3], e8[2], 0x0c0c0400u) << 16);
+                            gqv[1] = __builtin_amdgcn_perm(e8[5], e8[4], 0x0c0c0400u) | (__builtin_amdgcn_perm(e8[7], e8[6], 0x0c0c0400u) << 16);
+                            gqok = true;
+                            x = o;
+                        } else
                         if (rowgelu) {
                             // x = the bf16-rounded pre-activation (bias included): the activation is applied to the rounded value; what is stored
                             // beside the output is x itself, or (gelu = 2) its activation derivative -- all the backward needs of it

@@ -33,6 +33,7 @@ struct EpiArgs {
     unsigned char* q8; const float* q8_scale; float* q8_amax;     // fp8 GELU launches of the 8-phase kernel: the output a second time as e4m3
                                                                   // bytes [M, ldc], q8 = sat(out * q8_scale[0]), q8_amax[0] raised to max |out|
     const unsigned char* mul8;  // out = v * gq_decode(mul8[m,n]) (ld = ldc bytes): the 8-bit derivative codes of a gelu = 3 forward
+    const unsigned* gelu_tab;   // gelu = 3 launches of the 8-phase kernel: the 4096-entry table of gq_tab_entry() below (global memory), or nullptr
 };
 
 // 8-bit fixed-point code of gelu'(h) in [-0.1290, 1.1290] (gelu = 3 / mul_by8, include/autoprog_hip.h): code = clamp(rint(202 g) + 26, 0, 255),
@@ -57,6 +58,29 @@ __device__ __forceinline__ float gq_decode(unsigned code) { return fmaf((float)c
 __device__ __forceinline__ void gq_unpack4(unsigned w, float* f) {
     f[0] = gq_decode(w & 0xffu); f[1] = gq_decode((w >> 8) & 0xffu); f[2] = gq_decode((w >> 16) & 0xffu); f[3] = gq_decode(w >> 24);
 }
+
+// The GELU of a bf16 value is a function of 16 bits.  For |h| in [2^-12, 16) -- 16 exponents x 128 mantissas x 2 signs = 4096 values, 16 KB --
+// the table holds, per value, Phi(h) (so that gelu(h) = h * Phi(h): one multiply) in the top 24 bits of an fp32 and the 8-bit code of
+// gelu'(h) in the low byte.  Below 2^-12 the entry of 2^-12 serves (Phi = 0.5 + 1e-4, the code of 0.5), from 16 on the entry of 15.94
+// (Phi = 1 or 0, codes of 1 and 0): a clamp of the index, no branch.  The row phase of the GELU launches (gemm8p.h) costs ~30 VALU slots
+// per element in arithmetic (one v_rcp, one v_exp, the A&S polynomial, the derivative) and ~11 with the table in LDS.
+#define GQ_TAB_LO (115 << 7)                  // bf16 bits of 2^-12
+#define GQ_TAB_N 2048                         // entries per sign
+__device__ __forceinline__ unsigned gq_tab_entry(unsigned idx) {
+    const unsigned bits = ((GQ_TAB_LO + (idx & (GQ_TAB_N - 1))) | ((idx >> 11) << 15)) << 16;
+    const float h = __uint_as_float(bits);
+    float c, e;
+    gelu_parts(h, c, e);
+    const float gp = fmaf(h * 0.39894228040143268f, e, c);
+    return ((__float_as_uint(c) + 0x80u) & 0xffffff00u) | gq_code(gp);
+}
+// table index of a bf16 bit pattern held in bits [SH, SH + 16) of w
+template <int SH>
+__device__ __forceinline__ int gq_tab_index(unsigned w) {
+    const int mag = (int)((w >> SH) & 0x7fffu) - GQ_TAB_LO;
+    return min(max(mag, 0), GQ_TAB_N - 1) | (int)((w >> (SH + 4)) & 0x800u);
+}
+
 
 // epilogue of 8 consecutive output columns [n, n+8) of row m held in v[] (fp32 accumulators):
 // +bias; GELU (storing the pre-activation); * gelu'(h); * DropPath row scale; + residual; bf16 store.
