@@ -767,6 +767,26 @@ static void g8_go(const G8Args& ga, const EpiArgs& ep, int grid, hipStream_t st)
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_gemm_nt_8p<NT1, EF>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS_BYTES); attr = true; (void)hipGetLastError(); }
     hipLaunchKernelGGL((k_gemm_nt_8p<NT1, EF>), dim3(grid), dim3(512), G8_LDS_BYTES, st, ga, ep);
 }
+// the 224-row instantiations (256 x 192 tiles only): the flavours of the N = 384 products of a transformer block -- plain, row scale,
+// bias (+ row scale) + residual; -> false for any other flavour (the caller then launches 256-row tiles)
+template <int EF>
+static void g8_go224(const G8Args& ga, const EpiArgs& ep, int grid, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_gemm_nt_8p<1, EF, false, 224>, hipFuncAttributeMaxDynamicSharedMemorySize, G8_LDS_BYTES); attr = true; (void)hipGetLastError(); }
+    hipLaunchKernelGGL((k_gemm_nt_8p<1, EF, false, 224>), dim3(grid), dim3(512), G8_LDS_BYTES, st, ga, ep);
+}
+static bool g8_has224(const EpiArgs& ep) {
+    const int f = g8_flavour(ep);
+    return f == 0 || f == G8_RS || f == (G8_BIAS | G8_RES) || f == (G8_BIAS | G8_RS | G8_RES);
+}
+static void g8_pick224(const G8Args& ga, const EpiArgs& ep, int grid, hipStream_t st) {
+    switch (g8_flavour(ep)) {
+        case 0: g8_go224<0>(ga, ep, grid, st); break;
+        case G8_RS: g8_go224<G8_RS>(ga, ep, grid, st); break;
+        case G8_BIAS | G8_RES: g8_go224<G8_BIAS | G8_RES>(ga, ep, grid, st); break;
+        default: g8_go224<G8_BIAS | G8_RS | G8_RES>(ga, ep, grid, st); break;
+    }
+}
 template <int NT1>
 static void g8_pick(const G8Args& ga, const EpiArgs& ep, int grid, hipStream_t st) {
     switch (g8_flavour(ep)) {
@@ -775,6 +795,8 @@ static void g8_pick(const G8Args& ga, const EpiArgs& ep, int grid, hipStream_t s
         case G8_RS: g8_go<NT1, G8_RS>(ga, ep, grid, st); break;
         case G8_BIAS | G8_GELU: g8_go<NT1, G8_BIAS | G8_GELU>(ga, ep, grid, st); break;
         case G8_BIAS | G8_GELU | G8_RS: g8_go<NT1, G8_BIAS | G8_GELU | G8_RS>(ga, ep, grid, st); break;
+        case G8_BIAS | G8_GELU | G8_GTAB: g8_go<NT1, G8_BIAS | G8_GELU | G8_GTAB>(ga, ep, grid, st); break;
+        case G8_BIAS | G8_GELU | G8_RS | G8_GTAB: g8_go<NT1, G8_BIAS | G8_GELU | G8_RS | G8_GTAB>(ga, ep, grid, st); break;
         case G8_DGELU: g8_go<NT1, G8_DGELU>(ga, ep, grid, st); break;
         case G8_DGELU | G8_RS: g8_go<NT1, G8_DGELU | G8_RS>(ga, ep, grid, st); break;
         case G8_MUL: g8_go<NT1, G8_MUL>(ga, ep, grid, st); break;
@@ -814,7 +836,22 @@ static int g8_launch(int bn, const bf16_t* A, int lda, const bf16_t* B, int ldb,
     G8Args ga;
     ga.A = A; ga.lda = lda; ga.B = B; ga.ldb = ldb; ga.C = C; ga.ldc = ldc; ga.M = M; ga.N = N; ga.K = K;
     ga.tiles_n = (N + bn - 1) / bn; ga.ntiles = ((M + 255) / 256) * ga.tiles_n;
-    const int cap = n_cu & ~7, want = (ga.ntiles + 7) & ~7;        // a multiple of 8: the kernel deals tiles per XCD label
+    const int cap = n_cu & ~7;
+    // 224-row tiles where they put more CUs to work inside ONE round of the persistent grid (a launch of fewer tiles than CUs takes
+    // about one tile's time whatever the number of idle CUs: tools/tile_rounds_probe.py): VOLO-D1's N = 384 products at 25088 rows,
+    // 98 x 2 = 196 tiles of 256 rows -> 112 x 2 = 224 tiles of 224.  AP_GEMM_BM224=0: 256-row tiles everywhere.
+    static int bm224 = -1;
+    if (bm224 < 0) { const char* e = getenv("AP_GEMM_BM224"); bm224 = e ? atoi(e) : 1; }
+    if (bm224 && !fp8 && bn == 192 && g8_has224(ep)) {
+        const int t224 = ((M + 223) / 224) * ga.tiles_n;
+        if (ga.ntiles < cap && t224 <= cap && t224 > ga.ntiles) {
+            ga.ntiles = t224;
+            const int want4 = (t224 + 7) & ~7;
+            g8_pick224(ga, ep, want4 < cap ? want4 : cap, st);
+            return ap_check_launch();
+        }
+    }
+    const int want = (ga.ntiles + 7) & ~7;        // a multiple of 8: the kernel deals tiles per XCD label
     const int grid = want < cap ? want : cap;
     if (fp8) { if (bn == 192) g8_pick_fp8<1>(ga, ep, grid, st); else g8_pick_fp8<2>(ga, ep, grid, st); }
     else if (bn == 192) g8_pick<1>(ga, ep, grid, st); else g8_pick<2>(ga, ep, grid, st);

@@ -78,10 +78,10 @@ struct G8Args {
 // epilogue flavour of an instantiation (EF >= 0: bits known at compile time; EF < 0: read from the arguments at run time).  The
 // generic epilogue is ~25 KB of code that a CU runs once or twice per launch, cold: an instantiation per flavour of the training
 // step keeps what is fetched to what is used (2.8 us -> see DESIGN.md on the 25088 x 384 x 1152 launch).
-enum { G8_BIAS = 1, G8_GELU = 2, G8_DGELU = 4, G8_RS = 8, G8_RES = 16, G8_MUL = 32, G8_MUL8 = 64 };
+enum { G8_BIAS = 1, G8_GELU = 2, G8_DGELU = 4, G8_RS = 8, G8_RES = 16, G8_MUL = 32, G8_MUL8 = 64, G8_GTAB = 128 };
 __host__ __device__ inline int g8_flavour(const EpiArgs& ep) {
     return (ep.bias ? G8_BIAS : 0) | (ep.gelu ? G8_GELU : 0) | (ep.dgelu_of ? G8_DGELU : 0) | (ep.row_scale ? G8_RS : 0) | (ep.residual ? G8_RES : 0) |
-           (ep.mul_by ? G8_MUL : 0) | (ep.mul8 ? G8_MUL8 : 0);
+           (ep.mul_by ? G8_MUL : 0) | (ep.mul8 ? G8_MUL8 : 0) | ((ep.gelu == 3 && ep.gelu_tab) ? G8_GTAB : 0);
 }
 
 // NT1: B part 1 holds NT1 16-column tiles per wave (1: 256 x 192 block tile, 2: 256 x 256).
@@ -102,8 +102,16 @@ __device__ __forceinline__ f32x4 g8_mma_fp8(const u32x4& b0, const u32x4& b1, co
     const g8_i32x8 a = __builtin_bit_cast(g8_i32x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b, a, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
-template <int NT1, int EF, bool FP8 = false>
+// BM = 224 (NT1 = 1 only; round 5): a 224-row block tile -- the second A half contributes 96 rows, three 16-row tiles per wave instead of four.
+// 25088 rows (VOLO-D1, B = 128, 196 tokens) are 98 tiles of 256 rows: the N = 384 products of a transformer block are 196 tiles on 256 CUs,
+// and tools/tile_rounds_probe.py shows that such a launch takes (nearly) the time of ONE tile whatever the number of idle CUs
+// (T(256 tiles) / T(196 tiles) = 1.06 - 1.16): 112 tiles of 224 rows x 2 = 224 tiles do 7 / 8 of the work per CU.  The DMA stream is
+// unchanged (the second half still stages 128 rows: its last 32 are the next tile's and are not read).
+template <int NT1, int EF, bool FP8 = false, int BM = 256>
 __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
+    static_assert(BM == 256 || (BM == 224 && NT1 == 1 && !FP8), "block rows");
+    constexpr int MT1 = BM == 224 ? 3 : 4;       // 16-row tiles per wave in the second A half
+    constexpr int R1 = MT1 * 16;                 // ... = rows per wave there
     const bool has_bias = EF < 0 ? ep.bias != nullptr : (EF & G8_BIAS) != 0;
     const bool has_gelu = EF < 0 ? ep.gelu != 0 : (EF & G8_GELU) != 0;
     const bool has_dgelu = EF < 0 ? ep.dgelu_of != nullptr : (EF & G8_DGELU) != 0;
@@ -119,7 +127,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     constexpr int STG = 2 * KS;                  // epilogue staging region: the rest of the LDS (48 KB at BN = 192, 32 KB at BN = 256)
     // GTAB (the GELU flavours): 16 KB of the staging region hold the GELU table of gemm_epi.h (gelu = 3 launches: Phi(h) and the 8-bit
     // derivative code per bf16 value); the staging passes are half as tall
-    constexpr bool GTAB = EF >= 0 && (EF & G8_GELU) != 0 && !FP8;
+    constexpr bool GTAB = EF >= 0 && (EF & G8_GELU) != 0 && (EF & G8_GTAB) != 0 && !FP8;        // (the gelu = 1 / 2 launches keep the tall passes: 55.9 against 61.4 us)
     constexpr int PASS_MT = (NT1 == 1 ? 4 : 2) / (GTAB ? 2 : 1);    // 16-row tiles per wave group and staging pass
     constexpr int NPASS = 8 / PASS_MT;
     constexpr int RS = BN * 2;                   // bytes of a staged row
@@ -155,6 +163,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     const int lane_off0 = lane_row + ((g ^ (fr & 7)) << 4);              // kb = 0
     const int lane_off1 = lane_row + (((4 + g) ^ (fr & 7)) << 4);        // kb = 1
     const unsigned char* const rdA = g8_smem + wr * 8192;                          // + bo + h*16384 + mt*2048 + lane_off{kb}
+    const unsigned char* const rdA1 = g8_smem + wr * (R1 * 128);                   // the second half's rows of this wave (BM = 224: 48 per wave)
     const unsigned char* const rdB0 = g8_smem + 32768 + wc * 4096;                 // + bo + nt*2048 + lane_off{kb}
     const unsigned char* const rdB1 = g8_smem + 49152 + wc * (2048 * NT1);         // + bo + nt*2048 + lane_off{kb}
 
@@ -183,7 +192,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     const bf16_t *qa0[2], *qa1[2], *qb0[2], *qb1[NT1];
     auto set_q = [&]() {
         const int t = q_tile < t_end ? q_tile : t_end - 1;
-        const int m0 = (t / ga.tiles_n) * 256, n0 = (t % ga.tiles_n) * BN;
+        const int m0 = (t / ga.tiles_n) * BM, n0 = (t % ga.tiles_n) * BN;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             qa0[j] = ga.A + (int64_t)min(m0 + srow + 8 * j, ga.M - 1) * ga.lda + scol;
@@ -224,12 +233,13 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                 for (int d = 0; d < NT1; ++d) acc1[a][c][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
     };
-    auto readA_to = [&](u32x4 (&a)[4][2], const unsigned char* base, int h) {
+    auto readA_to = [&](u32x4 (&a)[4][2], const unsigned char* base, int h, int nmt = 4) {
         if (!(G8_ABL & 2)) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) a[mt][kb] = ld16(base + h * 16384 + mt * 2048 + (kb ? lane_off1 : lane_off0));
+                for (int kb = 0; kb < 2; ++kb)
+                    if (mt < nmt) a[mt][kb] = ld16(base + h * 16384 + mt * 2048 + (kb ? lane_off1 : lane_off0));
         }
     };
     auto readA = [&](const unsigned char* base, int h) { readA_to(af, base, h); };
@@ -249,7 +259,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                 for (int kb = 0; kb < 2; ++kb) bf1[nt][kb] = ld16(base + nt * 2048 + (kb ? lane_off1 : lane_off0));
         }
     };
-    auto mma0_of = [&](int mh, const u32x4 (&a)[4][2]) {
+    auto mma0_of = [&](int mh, const u32x4 (&a)[4][2], int nmt = 4) {
         if (!(G8_ABL & 1)) {
             if constexpr (FP8) {
 #pragma unroll
@@ -264,11 +274,11 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
-                            acc0[mh][mt][nt] = g8_mma_bf16(bf0[nt][kb], a[mt][kb], acc0[mh][mt][nt]);
+                            if (mt < nmt) acc0[mh][mt][nt] = g8_mma_bf16(bf0[nt][kb], a[mt][kb], acc0[mh][mt][nt]);
             }
         }
     };
-    auto mma1_of = [&](int mh, const u32x4 (&a)[4][2]) {
+    auto mma1_of = [&](int mh, const u32x4 (&a)[4][2], int nmt = 4) {
         if (!(G8_ABL & 1)) {
             if constexpr (FP8) {
 #pragma unroll
@@ -283,7 +293,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < NT1; ++nt)
-                            acc1[mh][mt][nt] = g8_mma_bf16(bf1[nt][kb], a[mt][kb], acc1[mh][mt][nt]);
+                            if (mt < nmt) acc1[mh][mt][nt] = g8_mma_bf16(bf1[nt][kb], a[mt][kb], acc1[mh][mt][nt]);
             }
         }
     };
@@ -314,15 +324,15 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
             mma0(0); G8_FENCE();
             G8_BAR();
             const bool live = STEADY || q_tile < t_end;
-            readB1(rdB1 + bo); G8_FENCE(); readA_to(af1, rdA + bo, 1); G8_FENCE();
+            readB1(rdB1 + bo); G8_FENCE(); readA_to(af1, rdA1 + bo, 1, MT1); G8_FENCE();
             if (live) dma(qb0, bo, 2);
             G8_BAR(); G8_LGKM(0); G8_FENCE();
-            __builtin_amdgcn_s_setprio(1); mma1_of(0, af); mma1_of(1, af1); __builtin_amdgcn_s_setprio(0); G8_FENCE();
+            __builtin_amdgcn_s_setprio(1); mma1_of(0, af); mma1_of(1, af1, MT1); __builtin_amdgcn_s_setprio(0); G8_FENCE();
             G8_BAR();
             if (live) { dma(qa0, bo, 0); G8_VM(4); } else { G8_VM(0); }
             G8_FENCE();
             G8_BAR();
-            __builtin_amdgcn_s_setprio(1); mma0_of(1, af1); __builtin_amdgcn_s_setprio(0); G8_FENCE();
+            __builtin_amdgcn_s_setprio(1); mma0_of(1, af1, MT1); __builtin_amdgcn_s_setprio(0); G8_FENCE();
             G8_BAR();
         }
     };
@@ -380,7 +390,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
         for (; kt < nk; ++kt) { ktile(bo, std::false_type{}); bo = KS - bo; }
         if (wr == 0) G8_BAR();            // ... and is waited for here: the eight epilogues run together
         // ---- epilogue, straight from the accumulators: lane (fr, g) holds row fr of each 16-row tile
-        const int m0 = (tile / ga.tiles_n) * 256, n0 = (tile % ga.tiles_n) * BN;
+        const int m0 = (tile / ga.tiles_n) * BM, n0 = (tile % ga.tiles_n) * BN;
         if (G8_ABL & 8) {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -464,7 +474,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                 for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) {
-                        const int64_t roff = (int64_t)min(m0 + mh * 128 + wr * 64 + mt * 16 + fr, ga.M - 1) * ga.ldc;
+                        const int64_t roff = (int64_t)min(m0 + mh * 128 + wr * (mh ? R1 : 64) + mt * 16 + fr, ga.M - 1) * ga.ldc;
                         if constexpr (EF >= 0) {
                             asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(j0[mh][mt]) : "v"(jbase + roff) : "memory");
                             if constexpr (NT1 == 2) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(j1[mh][mt]) : "v"(jbase1 + roff) : "memory");
@@ -487,7 +497,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                 for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) {
-                        const int64_t roff = (int64_t)min(m0 + mh * 128 + wr * 64 + mt * 16 + fr, ga.M - 1) * in_ld;
+                        const int64_t roff = (int64_t)min(m0 + mh * 128 + wr * (mh ? R1 : 64) + mt * 16 + fr, ga.M - 1) * in_ld;
                         if constexpr (ASM_IN) {
                             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(in0[mh][mt]) : "v"(ibase + roff) : "memory");
                             if constexpr (NT1 == 2) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(in1[mh][mt]) : "v"(ibase1 + roff) : "memory");
@@ -507,10 +517,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int mh = pass / (NPASS / 2), mtb = (pass % (NPASS / 2)) * PASS_MT;    // this pass: tiles mt = mtb .. mtb + PASS_MT - 1 of half mh
-                const int rbase = m0 + mh * 128 + wr * 64 + mtb * 16;                        // first matrix row of the wave group's pass
+                const int rbase = m0 + mh * 128 + wr * (mh ? R1 : 64) + mtb * 16;            // first matrix row of the wave group's pass
+                const int vrows = mh ? max(0, min(16 * PASS_MT, R1 - mtb * 16)) : 16 * PASS_MT; // rows of this pass that exist (BM = 224: the second half has 3 tiles per wave)
 #pragma unroll
                 for (int t = 0; t < PASS_MT; ++t) {
                     const int mt = mtb + t;
+                    if (mh == 1 && mt >= MT1) continue;
                     const int m = min(rbase + t * 16 + fr, ga.M - 1);
                     const unsigned rowp = stg_a + (t * 16 + fr) * RS;
                     const float rs = has_rs ? ep.row_scale[m / ep.rows_per_scale] : 1.f;
@@ -599,7 +611,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                     u32x4 x = xs[it];
                     u32x2 q8v = {0u, 0u}; bool q8ok = false;
                     u32x2 gqv = {0u, 0u}; bool gqok = false;          // gelu = 3: the 8 derivative codes of this chunk
-                    if (m < ga.M && n < ga.N) {
+                    if (m < ga.M && n < ga.N && row < vrows) {
                         if (GTAB && use_tab) {
                             // x = 8 bf16-rounded pre-activations: gelu(h) = h * Phi(h) and the derivative code from the table (see gemm_epi.h)
                             const float rs = has_rs ? ep.row_scale[m / ep.rows_per_scale] : 1.f;

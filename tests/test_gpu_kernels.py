@@ -165,6 +165,30 @@ def test_gemm_nt_epilogues(ops, M, N, K):
         ops.gemm_nt(dev(a), dev(w), bias=dev(bias), gelu=True, preact_out=gp, preact_grad=2)          # codes need a uint8 tensor
 
 
+@pytest.mark.parametrize("M,K", [(25088, 384), (25088, 1152), (24999, 384), (18432, 1152), (4100, 384)])
+def test_gemm_nt_224_row_tiles(ops, M, K):
+    """round 5: the 224-row instantiation of the 8-phase kernel (csrc/gemm8p.h BM = 224), taken where it puts more CUs to work inside one
+    round of the persistent grid -- the N = 384 products of a VOLO-D1 transformer block at 25088 rows (196 -> 224 tiles): every flavour
+    it is instantiated for (plain, row scale, bias + residual, bias + row scale + residual) against fp64, with a ragged last row tile, and
+    bit-equal to the 256-row tiles (AP_GEMM_BM224=0 is checked by the environment-switch test): the accumulation order per element is the same."""
+    N = 384
+    rps = 196
+    a, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    res = rnd(M, N, seed=4)
+    rs = (torch.rand((M + rps - 1) // rps, generator=torch.Generator().manual_seed(5)) > 0.2).float() / 0.8
+    lin = a.double() @ w.double().t()
+    rsr = rs.double().repeat_interleave(rps)[:M, None]
+    da, dw_ = dev(a), dev(w)
+    assert rel(ops.gemm_nt(da, dw_), lin) < TOL_BF16
+    assert rel(ops.gemm_nt(da, dw_, row_scale=dev(rs), rows_per_scale=rps), lin * rsr) < TOL_BF16
+    assert rel(ops.gemm_nt(da, dw_, bias=dev(bias), residual=dev(res)), lin + bias.double() + res.double()) < TOL_BF16
+    out = ops.gemm_nt(da, dw_, bias=dev(bias), row_scale=dev(rs), rows_per_scale=rps, residual=dev(res))
+    assert rel(out, (lin + bias.double()) * rsr + res.double()) < TOL_BF16
+    dropped = (rs == 0).repeat_interleave(rps)[:M]
+    assert torch.equal(out.cpu()[dropped], res[dropped])            # dropped samples pass the residual through exactly
+
+
 @pytest.mark.parametrize("M,N1,N2", [(1024, 128, 128), (1000, 192, 576), (3000, 486, 192), (25088 // 8, 1152, 384), (130, 1000, 384),
                                      (77, 32, 96), (500, 16, 64)])
 def test_gemm_tn_acc(ops, M, N1, N2):
@@ -616,7 +640,7 @@ def test_grouped_wgrad_launch_carries_the_layernorm_reductions(ops):
 
 @pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_MHSA_BWD_DS": "0", "AP_MHSA_FWD_P": "0"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"}, {"AP_OUTLOOK_MFMA": "0"},
                                  {"AP_STEM_HIP_CONV": "0"}, {"AP_ASYNC_WGRAD": "1"}, {"AP_GEMM_TN_PLACE": "0"}, {"AP_FUSE_LN_REDUCE": "0"}, {"AP_CONV_WGRAD_P": "0"},
-                                 {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}, {"AP_GELU_STORE_GRAD": "0"}, {"AP_GELU_STORE_GRAD": "1"}, {"AP_LN_BWD_PF": "0"}, {"AP_WGRAD_WINDOW": "0"}, {"AP_STEM_FUSE_BN": "0"},
+                                 {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}, {"AP_GELU_STORE_GRAD": "0"}, {"AP_GELU_STORE_GRAD": "1"}, {"AP_LN_BWD_PF": "0"}, {"AP_GEMM_BM224": "0"}, {"AP_GELU_TABLE": "0"}, {"AP_WGRAD_WINDOW": "0"}, {"AP_STEM_FUSE_BN": "0"},
                                  {"AP_OUTLOOK_P": "0"}, {"AP_OUTLOOK_P": "2"}, {"AP_LN_FWD_LP": "0"}, {"AP_CONV_WAVES": "4"}])
 def test_experimental_kernel_paths_stay_parity_green(env):
     """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:
@@ -634,7 +658,7 @@ def test_experimental_kernel_paths_stay_parity_green(env):
         sel, files = "conv3x3 or stem64", ["tests/test_gpu_kernels.py", "tests/test_gpu_blocks.py"]
     elif "STEM" in key:          # AP_STEM_HIP_CONV, AP_STEM_FUSE_BN
         sel, files = "d1_shapes or hip_stem or patch_embed", ["tests/test_gpu_model.py", "tests/test_gpu_blocks.py"]
-    elif "WGRAD" in key or "FUSE_LN" in key or "GELU" in key:
+    elif "WGRAD" in key or "FUSE_LN" in key or ("GELU" in key and "TABLE" not in key):
         sel, files = "vs_reference_golden or grad_sink", ["tests/test_gpu_blocks.py", "tests/test_gpu_model.py"]
     else:
         sel, files = "gemm and not experimental", ["tests/test_gpu_kernels.py"]
