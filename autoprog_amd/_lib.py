@@ -56,6 +56,7 @@ _SIGNATURES = {
     "ap_layernorm_fwd_fp8": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P]),
     "ap_layernorm_bwd_workspace": (ctypes.c_size_t, [_L, _I]),
     "ap_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, _P]),
+    "ap_layernorm_bwd_partial_pool": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, ctypes.c_size_t, POINTER(c_int), _P]),
     "ap_gemm_nt": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, POINTER(GemmEpilogue), _P]),
     "ap_gemm_tn_acc": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P]),
     "ap_gemm_tn_grouped_workspace": (ctypes.c_size_t, [_P, _I]),

@@ -362,12 +362,17 @@ k_ln_bwd(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const floa
 // block that zeroes its destination: DESIGN section 3, round 1) -- rows past the end are skipped in the reduce, idle chunk lanes
 // (C/8 < G) are masked to zero after the load.  gamma comes straight from global memory (two 16-byte loads per chunk, L2 hits, under
 // the first trip's latency): no LDS trip and no barrier in front of the rows.
-template <int V, int U, int OCC = 1>
+// POOL: the incoming gradient of row (b, y, x) of a [B, H, W, C] token grid is dy + pool[b, y / 2, x / 2] / count -- the backward of the
+// 2 x 2 ceil-mode average pool that reads the SAME LayerNorm output (OutlookAttention: models/volo.py:75,87; count = the number of
+// pixels the pooled cell covers: 4, or 2 / 1 on the last odd row / column).  Was a pass of its own over the 77 MB gradient
+// (ap_avgpool2_bwd_acc, 19 us per outlooker block); here it is one more 16-byte load per chunk from a tensor a quarter of the size.
+struct LnPool { const bf16_t* grad; int H, W, h, w; unsigned magic_hw, magic_w; };
+template <int V, int U, int OCC = 1, bool POOL = false>
 __global__ void __launch_bounds__(256, OCC)
 k_ln_bwd_pf(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ gamma,
             const float* __restrict__ mean, const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
             bf16_t* __restrict__ dx, float* __restrict__ partial,
-            int64_t rows, int C, int G) {
+            int64_t rows, int C, int G, LnPool pool = LnPool{nullptr, 0, 0, 0, 0, 0u, 0u}) {
     extern __shared__ __attribute__((aligned(16))) float red[];     // [4 waves][C] x 2 (the end of the kernel only)
     const int lane_in_group = threadIdx.x & (G - 1);
     const int groups_per_block = 256 / G;
@@ -395,19 +400,29 @@ k_ln_bwd_pf(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const f
     const int64_t trip = row_stride * U;
     const int64_t last = rows - 1;
 
-#define LN_PF_LOAD(R0, DY, X, RES, MU, RS)                                                                   \
+#define LN_PF_LOAD(R0, DY, X, RES, MU, RS, PG, PI)                                                           \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                           \
         int64_t row = (R0) + u * row_stride;                                                                  \
         row = row < rows ? row : last;                                                                        \
         MU[u] = mean[row]; RS[u] = rstd[row];                                                                 \
+        int64_t prow = 0;                                                                                     \
+        if constexpr (POOL) {                                                                                 \
+            const unsigned r32 = (unsigned)row;                                                               \
+            const unsigned b = __umulhi(r32, pool.magic_hw), rem = r32 - b * (unsigned)(pool.H * pool.W);     \
+            const unsigned yy = __umulhi(rem, pool.magic_w), xx = rem - yy * (unsigned)pool.W;                \
+            const int cy = min(2, pool.H - (int)(yy & ~1u)), cx = min(2, pool.W - (int)(xx & ~1u));           \
+            PI[u] = 1.0f / (float)(cy * cx);                                                                  \
+            prow = ((int64_t)b * pool.h + (yy >> 1)) * pool.w + (xx >> 1);                                    \
+        }                                                                                                     \
         _Pragma("unroll") for (int i = 0; i < V; ++i) {                                                       \
             DY[u][i] = ld16(dy + row * C + choff[i]);                                                         \
             X[u][i] = ld16(x + row * C + choff[i]);                                                           \
             if (has_res) RES[u][i] = ld16(dres + row * C + choff[i]);                                         \
+            if constexpr (POOL) PG[u][i] = ld16(pool.grad + prow * C + choff[i]);                             \
         }                                                                                                     \
     }
 
-#define LN_PF_COMPUTE(R0, DY, X, RES, MU, RS)                                                                \
+#define LN_PF_COMPUTE(R0, DY, X, RES, MU, RS, PG, PI)                                                        \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                           \
         const int64_t row = (R0) + u * row_stride;                                                            \
         if (row < rows) {                                                                                     \
@@ -418,6 +433,13 @@ k_ln_bwd_pf(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const f
                 u32x4 dm = DY[u][i];                                                                          \
                 dm[0] &= chmask[i]; dm[1] &= chmask[i]; dm[2] &= chmask[i]; dm[3] &= chmask[i];               \
                 unpack8(dm, d8);                                                                              \
+                if constexpr (POOL) {                                                                         \
+                    float p8[8];                                                                              \
+                    u32x4 pm_ = PG[u][i];                                                                     \
+                    pm_[0] &= chmask[i]; pm_[1] &= chmask[i]; pm_[2] &= chmask[i]; pm_[3] &= chmask[i];       \
+                    unpack8(pm_, p8);                                                                         \
+                    _Pragma("unroll") for (int k = 0; k < 8; ++k) d8[k] = fmaf(p8[k], PI[u], d8[k]);          \
+                }                                                                                             \
                 unpack8(X[u][i], x8);                                                                         \
                 _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                               \
                     xh[i][k] = (x8[k] - MU[u]) * RS[u];                                                       \
@@ -443,16 +465,17 @@ k_ln_bwd_pf(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const f
     }
 
     u32x4 a_dy[U][V], a_x[U][V], a_res[U][V], b_dy[U][V], b_x[U][V], b_res[U][V];
-    float a_mu[U], a_rs[U], b_mu[U], b_rs[U];
+    u32x4 a_pg[POOL ? U : 1][POOL ? V : 1], b_pg[POOL ? U : 1][POOL ? V : 1];
+    float a_mu[U], a_rs[U], b_mu[U], b_rs[U], a_pi[U], b_pi[U];
     int64_t row0 = (int64_t)blockIdx.x * groups_per_block + group;
-    LN_PF_LOAD(row0, a_dy, a_x, a_res, a_mu, a_rs)
+    LN_PF_LOAD(row0, a_dy, a_x, a_res, a_mu, a_rs, a_pg, a_pi)
     for (; row0 < rows; row0 += 2 * trip) {
         const int64_t row1 = row0 + trip;
-        LN_PF_LOAD(row1, b_dy, b_x, b_res, b_mu, b_rs)
-        LN_PF_COMPUTE(row0, a_dy, a_x, a_res, a_mu, a_rs)
+        LN_PF_LOAD(row1, b_dy, b_x, b_res, b_mu, b_rs, b_pg, b_pi)
+        LN_PF_COMPUTE(row0, a_dy, a_x, a_res, a_mu, a_rs, a_pg, a_pi)
         if (row1 >= rows) break;
-        LN_PF_LOAD(row1 + trip, a_dy, a_x, a_res, a_mu, a_rs)
-        LN_PF_COMPUTE(row1, b_dy, b_x, b_res, b_mu, b_rs)
+        LN_PF_LOAD(row1 + trip, a_dy, a_x, a_res, a_mu, a_rs, a_pg, a_pi)
+        LN_PF_COMPUTE(row1, b_dy, b_x, b_res, b_mu, b_rs, b_pg, b_pi)
     }
 #undef LN_PF_LOAD
 #undef LN_PF_COMPUTE
@@ -618,6 +641,7 @@ k_ln_bwd_reduce_batched(LnReduceBatch bt) {
 }
 
 static thread_local int* g_ln_defer_blocks = nullptr;       // set by ap_layernorm_bwd_partial around its call of ap_layernorm_bwd
+static thread_local LnPool g_ln_pool = {nullptr, 0, 0, 0, 0, 0u, 0u};     // set by ap_layernorm_bwd_partial_pool likewise
 
 size_t ap_layernorm_bwd_workspace(int64_t rows, int C) {
     (void)rows;
@@ -647,6 +671,10 @@ int ap_layernorm_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, co
     // a sixth of them -- measured equal, 17.5 vs 17.7 us: the trips are not what the launch waits for)
     static int pf = -1;             // AP_LN_BWD_PF: 0 = the trip-by-trip kernel of rounds 1 - 4; 1 = pipelined, half the rows per trip (the same registers in flight);
     if (pf < 0) { const char* e = getenv("AP_LN_BWD_PF"); pf = e ? atoi(e) : 1; }        //               2 = pipelined with the old rows per trip (twice the registers)
+    if (g_ln_pool.grad) {           // the average pool's gradient rides in (pipelined kernel, one chunk per lane: C <= 512)
+        if (!pf || V != 1) return AP_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((k_ln_bwd_pf<1, 2, 1, true>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G, g_ln_pool);
+    } else
     if (pf && V <= 2) {             // (four chunks per lane: two register sets do not fit 256 registers)
         if (V == 1 && pf == 3) hipLaunchKernelGGL((k_ln_bwd_pf<1, 2, 4>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);
         else if (V == 1) { if (pf == 2) hipLaunchKernelGGL((k_ln_bwd_pf<1, 4>), dim3((int)grid), dim3(256), lds, s, dy, x, gamma, mean, rstd, dres, dx, partial, rows, C, G);
@@ -674,6 +702,24 @@ int ap_layernorm_bwd_partial(const ap_bf16* dy, const ap_bf16* x, const float* g
     *n_partial = 0;
     const int rc = ap_layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, &dummy, &dummy, rows, C, workspace, ws_bytes, stream);
     g_ln_defer_blocks = nullptr;
+    return rc;
+}
+
+int ap_layernorm_bwd_partial_pool(const ap_bf16* dy, const ap_bf16* pool_grad, int B, int H, int W, const ap_bf16* x, const float* gamma,
+                                  const float* mean, const float* rstd, const ap_bf16* dres, ap_bf16* dx, int C, void* workspace, size_t ws_bytes,
+                                  int* n_partial, ap_stream_t stream) {
+    if (!pool_grad) return AP_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || (int64_t)B * H * W > 0x7fffffff) return AP_ERR_SHAPE;
+    const unsigned hw = (unsigned)(H * W);
+    if (hw < 2 || W < 2) return AP_ERR_UNSUPPORTED;                  // (no exact 32-bit magic for a division by 1; no caller needs it)
+    LnPool p;
+    p.grad = pool_grad; p.H = H; p.W = W; p.h = (H + 1) / 2; p.w = (W + 1) / 2;
+    p.magic_hw = (unsigned)(0xFFFFFFFFu / hw) + 1u;                  // exact for rows < 2^32 / (H W)
+    p.magic_w = (unsigned)(0xFFFFFFFFu / (unsigned)W) + 1u;
+    if ((uint64_t)B * hw >= (uint64_t)(0xFFFFFFFFu / hw)) return AP_ERR_UNSUPPORTED;
+    g_ln_pool = p;
+    const int rc = ap_layernorm_bwd_partial(dy, x, gamma, mean, rstd, dres, dx, (int64_t)B * H * W, C, workspace, ws_bytes, n_partial, stream);
+    g_ln_pool.grad = nullptr;
     return rc;
 }
 

@@ -706,6 +706,9 @@ class ClassBlockFn(torch.autograd.Function):
         return (dcls.view(ctx.shapes[0]), dtok.view(ctx.shapes[1]), *_finish_param_grads(params, bufs, sunk, batch.deferred), None, None, None, None)
 
 
+FUSE_POOL_BWD = os.environ.get("AP_FUSE_POOL_BWD", "1") != "0"      # 0: the average pool's backward as a pass of its own (rounds 1 - 4)
+
+
 # ------------------------------------------------------------------------- outlooker block
 class OutlookerBlockFn(torch.autograd.Function):
     """Outlooker.forward (models/volo.py:140-144) with OutlookAttention (models/volo.py:77-103):
@@ -752,8 +755,11 @@ class OutlookerBlockFn(torch.autograd.Function):
             dv, dlogits = ops.outlook_bwd(v.view(B, H, W, C), logits, dyo.view(B, H, W, C), heads, scale)
             dpooled = _linear_bwd(dlogits, pooled2, attn_w, dattn_w, dattn_b, n=attn_w.shape[0])
             dxn1 = _linear_bwd(dv.view(T, C), xn1, v_w, dv_w, dv_b)
-            ops.avgpool2_bwd_acc(dpooled.view(B, (H + 1) // 2, (W + 1) // 2, C), dxn1.view(B, H, W, C))
-            dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b, defer=batch.ln)
+            # the average pool's backward (dxn1 += dpooled / count) rides in the LayerNorm backward kernel: one pass over the gradient less
+            dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b, defer=batch.ln, pool=(dpooled.view(B, (H + 1) // 2, (W + 1) // 2, C), (B, H, W))) if FUSE_POOL_BWD else None
+            if dx is None:
+                ops.avgpool2_bwd_acc(dpooled.view(B, (H + 1) // 2, (W + 1) // 2, C), dxn1.view(B, H, W, C))
+                dx = ops.layernorm_bwd(dxn1, x2, n1w, m1, r1, dx1, dn1w, dn1b, defer=batch.ln)
         return (dx.view(dy.shape), *_finish_param_grads(params, bufs, sunk, batch.deferred), None, None)
 
 

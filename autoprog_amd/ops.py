@@ -124,9 +124,11 @@ def layernorm_fwd(x, gamma, beta, eps, fp8=None):
 _ln_ws = {}          # (rows, C) -> ap_layernorm_bwd_workspace bytes (a pure function of the shape: one foreign call per shape, not per launch)
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, defer=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, defer=None, pool=None):
     """dx = dres + dLN/dx ; dgamma/dbeta (fp32) are accumulated in place.  defer: a list -- the dgamma/dbeta reduction is not
-    launched but appended to it (layernorm_bwd_reduce_batched reduces the LayerNorms of a block in one launch)."""
+    launched but appended to it (layernorm_bwd_reduce_batched reduces the LayerNorms of a block in one launch).
+    pool = (dpooled [B,h,w,C], (B, H, W)) with defer: the LayerNorm output also fed a 2 x 2 ceil-mode average pool whose output gradient is
+    dpooled -- its backward is applied to dy inside the kernel; -> None where that kernel does not apply (the caller falls back)"""
     _req(dy, BF16, "dy"); _req(x, BF16, "x")
     C = x.shape[-1]
     rows = x.numel() // C
@@ -135,6 +137,19 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, defer=None):
     if ws_bytes is None:
         ws_bytes = _ln_ws[(rows, C)] = lib.ap_layernorm_bwd_workspace(rows, C)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    if pool is not None:
+        dp, (B_, H_, W_) = pool
+        _req(dp, BF16, "dpooled")
+        if defer is None or B_ * H_ * W_ != rows:
+            raise AutoProgHipError("layernorm_bwd(pool=...) needs defer and a [B,H,W,C] token grid")
+        n = ctypes.c_int(0)
+        rc = lib.ap_layernorm_bwd_partial_pool(dy.data_ptr(), dp.data_ptr(), B_, H_, W_, x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                               dres.data_ptr() if dres is not None else None, dx.data_ptr(), C, ws.data_ptr(), ws_bytes, ctypes.byref(n), _stream())
+        if rc == -2:                   # AP_ERR_UNSUPPORTED
+            return None
+        check(rc, "ap_layernorm_bwd_partial_pool")
+        defer.append((ws, n.value, C, dgamma, dbeta))
+        return dx
     if defer is not None and rows > 0:
         n = ctypes.c_int(0)
         check(lib.ap_layernorm_bwd_partial(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),

@@ -80,6 +80,13 @@ typedef struct ap_ln_reduce { const float* partial; int n_partial; int C; float*
 int ap_layernorm_bwd_partial(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* mean, const float* rstd,
                              const ap_bf16* dres, ap_bf16* dx, int64_t rows, int C, void* workspace, size_t ws_bytes, int* n_partial,
                              ap_stream_t stream);
+/* (ABI version 6) the same for the LayerNorm whose output also feeds a 2 x 2 ceil-mode average pool (OutlookAttention, models/volo.py:75,87):
+ * rows = B*H*W tokens of a [B,H,W,C] grid, and the incoming gradient of token (b, y, x) is dy + pool_grad[b, y/2, x/2] / count (count = pixels
+ * under the pooled cell) -- the pool's backward rides in the kernel instead of a pass of its own over dy (ap_avgpool2_bwd_acc).
+ * AP_ERR_UNSUPPORTED where the pipelined one-chunk-per-lane kernel does not apply (C > 512): call ap_avgpool2_bwd_acc + the plain form. */
+int ap_layernorm_bwd_partial_pool(const ap_bf16* dy, const ap_bf16* pool_grad, int B, int H, int W, const ap_bf16* x, const float* gamma,
+                                  const float* mean, const float* rstd, const ap_bf16* dres, ap_bf16* dx, int C, void* workspace, size_t ws_bytes,
+                                  int* n_partial, ap_stream_t stream);
 int ap_layernorm_bwd_reduce_batched(const ap_ln_reduce* items, int count, ap_stream_t stream);
 
 /* ---- Linear layers (nn.Linear: models/volo.py:67,68,71,156,158,180,182,253,256,258,547,553)

@@ -468,13 +468,18 @@ class _OutlookBf16Points(torch.autograd.Function):
         return dv, dl, None
 
 
+POOL_GRAD_ROUNDED = False
+
+
 def outlooker_bf16_points(x, p: Params, pre: str, heads: int):
     """Outlooker.forward (models/volo.py:140-144) with the rounding points of functional.OutlookerBlockFn (see transformer_bf16_points);
-    x [B,H,W,C], bf16-valued.  LayerNorm-1's output feeds the v projection and the 2x2 average pool: the v path's input gradient is a
-    bf16 tensor that the pool's gradient is added into (ap_avgpool2_bwd_acc), hence the second rounding node on that path."""
+    x [B,H,W,C], bf16-valued.  LayerNorm-1's output feeds the v projection and the 2x2 average pool: the v path's input gradient and the
+    pool's output gradient are bf16 tensors (the rounding nodes on the two paths); their sum is formed in fp32 INSIDE the LayerNorm
+    backward kernel (ap_layernorm_bwd_partial_pool, round 5) and is not rounded -- POOL_GRAD_ROUNDED = True restores the extra rounding of
+    the separate ap_avgpool2_bwd_acc pass (AP_FUSE_POOL_BWD=0)."""
     rb, rw = _RoundBoth.apply, _RoundOperand.apply
     B, H, W, C = x.shape
-    xn1 = rb(layernorm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"]))
+    xn1 = (rb if POOL_GRAD_ROUNDED else rw)(layernorm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"]))
     v = rb(linear(rb(xn1), rw(p[pre + "attn.v.weight"]), p.get(pre + "attn.v.bias")))
     pooled = rb(avgpool_ceil(xn1, 2))
     logits = rb(linear(pooled.reshape(B, -1, C), rw(p[pre + "attn.attn.weight"]), p[pre + "attn.attn.bias"]))

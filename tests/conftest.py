@@ -26,6 +26,7 @@ def _oracle_rounding_points_follow_the_product_switches():
         from autoprog_amd import functional as AF
         from oracle import ref_cpu as R
         R.GELU_GRAD_BITS = 8 if AF.STORE_GELU_GRAD == 2 else 16
+        R.POOL_GRAD_ROUNDED = not AF.FUSE_POOL_BWD
     except Exception:
         pass
     yield

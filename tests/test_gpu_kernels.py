@@ -165,6 +165,45 @@ def test_gemm_nt_epilogues(ops, M, N, K):
         ops.gemm_nt(dev(a), dev(w), bias=dev(bias), gelu=True, preact_out=gp, preact_grad=2)          # codes need a uint8 tensor
 
 
+@pytest.mark.parametrize("B,H,W,C", [(3, 8, 8, 192), (2, 7, 7, 64), (5, 9, 6, 384), (16, 28, 28, 192)])
+def test_layernorm_bwd_with_the_average_pools_gradient(ops, B, H, W, C):
+    """ap_layernorm_bwd_partial_pool (round 5): the backward of the 2 x 2 ceil-mode average pool that reads the same LayerNorm output
+    (OutlookAttention, models/volo.py:75,87) applied to the incoming gradient INSIDE the LayerNorm backward kernel, against fp64: the pooled
+    gradient spread over the cells' pixels (divided by the CLIPPED count on odd grids), added to dy, LayerNorm backward, + residual
+    gradient; dgamma / dbeta through the deferred reduction.  And against the two-launch form it replaces (ap_avgpool2_bwd_acc rounds the
+    sum to bf16 first: equal within that rounding)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, H, W, C, generator=g).bfloat16()
+    dy = torch.randn(B, H, W, C, generator=g).bfloat16()
+    dres = torch.randn(B, H, W, C, generator=g).bfloat16()
+    h, w = (H + 1) // 2, (W + 1) // 2
+    dp = torch.randn(B, h, w, C, generator=g).bfloat16()
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y = F.layer_norm(x64, (C,), g64, b64, 1e-5)
+    pooled = F.avg_pool2d(y.permute(0, 3, 1, 2), 2, 2, ceil_mode=True, count_include_pad=False).permute(0, 2, 3, 1)
+    ((y * dy.double()).sum() + (pooled * dp.double()).sum()).backward()
+    want_dx = x64.grad + dres.double()
+    xd = dev(x)
+    yk, mean, rstd = ops.layernorm_fwd(xd.view(-1, C), dev(gamma), dev(beta), 1e-5)
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    items = []
+    dx = ops.layernorm_bwd(dev(dy).view(-1, C), xd.view(-1, C), dev(gamma), mean, rstd, dev(dres).view(-1, C), dg, db, defer=items, pool=(dev(dp), (B, H, W)))
+    assert dx is not None
+    ops.layernorm_bwd_reduce_batched(items)
+    assert rel(dx.view(B, H, W, C), want_dx) < TOL_BF16
+    assert rel(dg, g64.grad) < 1e-4 and rel(db, b64.grad) < 1e-4
+    # the two launches it replaces
+    dy2 = dev(dy).clone()
+    ops.avgpool2_bwd_acc(dev(dp), dy2)
+    dg2, db2 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx2 = ops.layernorm_bwd(dy2.view(-1, C), xd.view(-1, C), dev(gamma), mean, rstd, dev(dres).view(-1, C), dg2, db2)
+    assert rel(dx, dx2.cpu()) < 6e-3 and rel(dg, dg2.cpu()) < 6e-3
+
+
 @pytest.mark.parametrize("M,K", [(25088, 384), (25088, 1152), (24999, 384), (18432, 1152), (4100, 384)])
 def test_gemm_nt_224_row_tiles(ops, M, K):
     """round 5: the 224-row instantiation of the 8-phase kernel (csrc/gemm8p.h BM = 224), taken where it puts more CUs to work inside one
@@ -640,7 +679,7 @@ def test_grouped_wgrad_launch_carries_the_layernorm_reductions(ops):
 
 @pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_MHSA_BWD_DS": "0", "AP_MHSA_FWD_P": "0"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"}, {"AP_OUTLOOK_MFMA": "0"},
                                  {"AP_STEM_HIP_CONV": "0"}, {"AP_ASYNC_WGRAD": "1"}, {"AP_GEMM_TN_PLACE": "0"}, {"AP_FUSE_LN_REDUCE": "0"}, {"AP_CONV_WGRAD_P": "0"},
-                                 {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}, {"AP_GELU_STORE_GRAD": "0"}, {"AP_GELU_STORE_GRAD": "1"}, {"AP_LN_BWD_PF": "0"}, {"AP_GEMM_BM224": "0"}, {"AP_GELU_TABLE": "0"}, {"AP_WGRAD_WINDOW": "0"}, {"AP_STEM_FUSE_BN": "0"},
+                                 {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}, {"AP_GELU_STORE_GRAD": "0"}, {"AP_GELU_STORE_GRAD": "1"}, {"AP_LN_BWD_PF": "0"}, {"AP_GEMM_BM224": "0"}, {"AP_GELU_TABLE": "0"}, {"AP_FUSE_POOL_BWD": "0"}, {"AP_WGRAD_WINDOW": "0"}, {"AP_STEM_FUSE_BN": "0"},
                                  {"AP_OUTLOOK_P": "0"}, {"AP_OUTLOOK_P": "2"}, {"AP_LN_FWD_LP": "0"}, {"AP_CONV_WAVES": "4"}])
 def test_experimental_kernel_paths_stay_parity_green(env):
     """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:
@@ -652,7 +691,7 @@ def test_experimental_kernel_paths_stay_parity_green(env):
         sel, files = "test_mhsa", ["tests/test_gpu_kernels.py"]
     elif "AP_LN_" in key:
         sel, files = "layernorm or ln_", ["tests/test_gpu_kernels.py", "tests/test_gpu_fullsize.py"]
-    elif "OUTLOOK" in key:
+    elif "OUTLOOK" in key or "POOL" in key:
         sel, files = "outlook", ["tests/test_gpu_kernels.py", "tests/test_gpu_blocks.py"]
     elif "CONV_WGRAD" in key or "CONV_WAVES" in key:
         sel, files = "conv3x3 or stem64", ["tests/test_gpu_kernels.py", "tests/test_gpu_blocks.py"]
