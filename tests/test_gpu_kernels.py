@@ -192,6 +192,9 @@ def test_layernorm_bwd_with_the_average_pools_gradient(ops, B, H, W, C):
     dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
     items = []
     dx = ops.layernorm_bwd(dev(dy).view(-1, C), xd.view(-1, C), dev(gamma), mean, rstd, dev(dres).view(-1, C), dg, db, defer=items, pool=(dev(dp), (B, H, W)))
+    if os.environ.get("AP_LN_BWD_PF", "1") == "0":
+        assert dx is None                      # the pool's gradient rides in the pipelined kernel only: the caller falls back to two launches
+        return
     assert dx is not None
     ops.layernorm_bwd_reduce_batched(items)
     assert rel(dx.view(B, H, W, C), want_dx) < TOL_BF16
