@@ -641,25 +641,23 @@ class VOLO(nn.Module):
         if not self.return_dense:
             return x_cls
         tokens = x if cls is not None else x[:, 1:]
+        if self.mix_token and self.training:
+            # models/volo.py:684-691 swaps the AUX LOGITS of the box back between image b and B-1-b.  aux_head acts on every token by
+            # itself, so swapping its INPUT tokens is the same numbers: 384 channels per token to move instead of 1000 classes
+            # (19 MB against 50 MB per direction at B = 128)
+            Cn = tokens.shape[-1]
+            grid = tokens.reshape(tokens.shape[0], patch_h, patch_w, Cn)
+            if dev is not None:
+                from ..graph import DeviceBox
+                grid = AF.MixSwapDevFn.apply(grid, dev, 1)
+            else:
+                grid = AF.MixSwapFn.apply(grid, bbx1, bbx2, bby1, bby2)
+            tokens = grid.reshape(grid.shape[0], patch_h * patch_w, Cn)
+            x_aux = AF.linear(tokens, self.aux_head.weight, self.aux_head.bias)
+            return x_cls, x_aux, (DeviceBox(dev) if dev is not None else (bbx1, bby1, bbx2, bby2))
         x_aux = AF.linear(tokens, self.aux_head.weight, self.aux_head.bias)
         if not self.training:
             return x_cls + 0.5 * x_aux.max(1)[0]
-        if self.mix_token and self.training:
-            nc = x_aux.shape[-1]
-            grid = x_aux.reshape(x_aux.shape[0], patch_h, patch_w, nc)
-            if dev is not None:
-                if nc % 8:
-                    raise NotImplementedError("graph-mode forward: class counts that are multiples of 8")
-                from ..graph import DeviceBox
-                grid = AF.MixSwapDevFn.apply(grid, dev, 1)
-                return x_cls, grid.reshape(grid.shape[0], patch_h * patch_w, nc), DeviceBox(dev)
-            if nc % 8 == 0:
-                grid = AF.MixSwapFn.apply(grid, bbx1, bbx2, bby1, bby2)
-            else:                       # odd class counts only occur in unit-test sized heads
-                swapped = grid.clone()
-                swapped[:, bbx1:bbx2, bby1:bby2] = grid.flip(0)[:, bbx1:bbx2, bby1:bby2]
-                grid = swapped
-            x_aux = grid.reshape(grid.shape[0], patch_h * patch_w, nc)
         return x_cls, x_aux, (bbx1, bby1, bbx2, bby2)
 
 

@@ -527,6 +527,8 @@ def main():
         if args.graph:                 # (the probe wraps the Python launch functions: the eager step of the same configuration sequence)
             for g_ in (graphs if args.workload == "stages" else [graph1]):
                 g_.release()
+            if args.workload == "stages":
+                counter[0] = args.warmup + args.steps          # the probe steps take the stages in turn
         for _ in range(nprobe):
             eager_step()
         launches, ms, flops = probe.summary()
