@@ -41,6 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0        # ... dense fp8 (e4m3 / e5m2) MFMA peak, same table
 PEAK_HBM_TBS = 8.0              # HBM3E peak
 STAGES = [(9, 128, 0.0), (12, 160, 0.0333), (15, 192, 0.0667), (18, 224, 0.1)]      # prog/progressive.py:4-31 with scripts/train_autoprog.sh
 
@@ -180,6 +181,7 @@ class GemmProbe:
         self.keys = []
         self.bytes = 0.0
         self.fp8_launches = 0
+        self.fp8_flops = 0.0
 
     def install(self):
         from autoprog_amd import ops
@@ -195,10 +197,12 @@ class GemmProbe:
             nn = b.shape[0] if n is None else n
             kk = a.shape[1] if k is None else k
             probe.records.append((e0, e1, 2.0 * a.shape[0] * nn * kk))
-            probe.keys.append((a.shape[0], nn, kk, "+".join(k2 for k2 in ("bias", "gelu", "dgelu_of", "row_scale", "residual") if kw.get(k2) is not None and kw.get(k2) is not False) or "plain"))
+            probe.keys.append((a.shape[0], nn, kk, "+".join(k2 for k2 in ("bias", "gelu", "dgelu_of", "mul_by", "row_scale", "residual") if kw.get(k2) is not None and kw.get(k2) is not False) or "plain"))
             # algorithmic bytes: A + B + C once, plus the epilogue operands this call reads / writes
-            extra = sum(1 for k2 in ("residual", "dgelu_of", "preact_out") if kw.get(k2) is not None)
-            probe.bytes += 2.0 * (a.shape[0] * kk + nn * kk + a.shape[0] * nn * (1 + extra))
+            # (an epilogue tensor counts its own element size: the 8-bit gelu' codes of round 5 are one byte per element, written by the
+            # GELU launch as preact_out and read by the backward launch as mul_by)
+            extra = sum(float(kw[k2].element_size()) for k2 in ("residual", "dgelu_of", "preact_out", "mul_by") if kw.get(k2) is not None)
+            probe.bytes += 2.0 * (a.shape[0] * kk + nn * kk + a.shape[0] * nn) + extra * a.shape[0] * nn
             return out
         ops.gemm_nt = timed
         # the e4m3 launches of --fp8 (ops.gemm_nt_fp8: one byte per operand element, bf16 outputs) belong to the same kernel family
@@ -217,6 +221,7 @@ class GemmProbe:
             extra = sum(1 for k2 in ("residual", "preact_out") if kw.get(k2) is not None)
             probe.bytes += 1.0 * (a8.shape[0] * kk + nn * kk) + 2.0 * a8.shape[0] * nn * (1 + extra) + (1.0 * a8.shape[0] * nn if kw.get("q8") is not None else 0.0)
             probe.fp8_launches += 1
+            probe.fp8_flops += 2.0 * a8.shape[0] * nn * kk
             return out
         ops.gemm_nt_fp8 = timed8
 
@@ -537,8 +542,11 @@ def main():
         probe.remove()
         tflops = flops / (ms * 1e-3) / 1e12
         tbs = probe.bytes / (ms * 1e-3) / 1e12
+        # the MFMA roof of this launch set: an e4m3 launch (v_mfma_scale_f32_16x16x128_f8f6f4) is priced against the 5 PFLOP/s dense fp8
+        # peak, a bf16 launch against 2.5 -- the time the set would take at its peaks, turned back into a rate
+        peak_mfma = flops / ((flops - probe.fp8_flops) / PEAK_BF16_TFLOPS + probe.fp8_flops / PEAK_FP8_TFLOPS) if flops else PEAK_BF16_TFLOPS
         ai = flops / probe.bytes                      # FLOP per algorithmic byte, averaged over the launches of a step
-        ridge = PEAK_BF16_TFLOPS / PEAK_HBM_TBS       # 312.5 FLOP/B
+        ridge = peak_mfma / PEAK_HBM_TBS              # 312.5 FLOP/B for a bf16 launch set
         # HBM bytes per launch come from a separate rocprofv3 --pmc pass (tools/collect_profiles.sh writes the file below
         # from FETCH_SIZE / WRITE_SIZE with the gfx950 correction of MI355X_MICROARCH.md); null when that file is absent
         traffic = None
@@ -552,11 +560,12 @@ def main():
             pass
         hbm_bound = ai < ridge
         roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": "ap_gemm_nt launches (k_gemm_nt_8p<...> + k_gemm_nt<...>)",
-                    "achieved": round(tbs * 1e3 if hbm_bound else tflops, 2), "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else PEAK_BF16_TFLOPS,
+                    "achieved": round(tbs * 1e3 if hbm_bound else tflops, 2), "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else round(peak_mfma, 1),
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                    "frac": round(tbs / PEAK_HBM_TBS if hbm_bound else tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(tbs / PEAK_HBM_TBS if hbm_bound else tflops / peak_mfma, 4), "traffic": traffic,
                     "arithmetic_intensity_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
-                    "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / PEAK_BF16_TFLOPS, 4),
+                    "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / peak_mfma, 4), "mfma_peak_tflops": round(peak_mfma, 1),
+                    "fp8_flop_share": round(probe.fp8_flops / flops, 4) if flops else 0.0,
                     "hbm_tbs_algorithmic": round(tbs, 3), "hbm_frac": round(tbs / PEAK_HBM_TBS, 4),
                     "algorithmic_bytes_per_launch": round(probe.bytes / max(launches, 1)),
                     "launches_per_step": launches // nprobe, "fp8_launches_per_step": probe.fp8_launches // nprobe, "avg_launch_us": round(ms * 1e3 / launches, 2),
