@@ -22,7 +22,7 @@ class GemmEpilogue(Structure):
 class TnProblem(Structure):
     """ap_tn_problem (include/autoprog_hip.h)"""
     _fields_ = [("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int), ("C", c_void_p), ("ldc", c_int),
-                ("M", c_int), ("N1", c_int), ("N2", c_int), ("alpha", c_float), ("colsum_A", c_void_p), ("colsum_weight", c_void_p), ("colsum_scale", c_float), ("b_patch", c_void_p)]
+                ("M", c_int), ("N1", c_int), ("N2", c_int), ("alpha", c_float), ("colsum_A", c_void_p), ("colsum_weight", c_void_p), ("colsum_scale", c_float), ("b_patch", c_void_p), ("b_bn", c_void_p)]
 
 
 class BnInput(Structure):
@@ -107,6 +107,7 @@ _SIGNATURES["ap_conv3x3_c64_wgrad_bn"] = (_I, [_P, POINTER(BnInput), _P, _P, _I,
 _SIGNATURES["ap_mhsa_fwd_fp8"] = (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P])
 _SIGNATURES["ap_gemm_nt_fp8"] = (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, POINTER(GemmEpilogue), _P])
 _SIGNATURES["ap_gemm_nt_patch"] = (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, POINTER(PatchMap), _I, _P])
+_SIGNATURES["ap_gemm_nt_patch_bn"] = (_I, [_P, POINTER(BnInput), _P, _I, _P, _I, _I, _I, _I, _P, POINTER(PatchMap), _I, _P])
 _SIGNATURES["ap_bn_relu_fwd_partials"] = (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P])
 _SIGNATURES["ap_conv3x3_c64_stat_rows"] = (_I, [_I, _I, _I])
 _SIGNATURES["ap_conv3x3_c64_pack"] = (_I, [_P, _P, _P, _P])

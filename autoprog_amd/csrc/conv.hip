@@ -53,22 +53,6 @@ k_conv3x3_pack(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __r
 // relu((z - mean) * rstd * gamma + beta) -- in the arithmetic of k_bn_relu_apply, rounded to bf16 -- to every chunk on its way from the
 // staging registers to LDS; pixels outside the image stay zero (the padding is of the ACTIVATION).  The activation tensor between two
 // convolutions of the stem is then never written or read (models/volo.py:355-366): 2 x 411 MB per step and the pass that made them.
-struct BnIn { const float* mean; const float* rstd; const float* gamma; const float* beta; };
-__device__ __forceinline__ void bn_in_consts(const BnIn& bn, int c8, float* sc, float* sh) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        sc[k] = bn.rstd[c8 + k] * bn.gamma[c8 + k];
-        sh[k] = bn.beta[c8 + k] - bn.mean[c8 + k] * sc[k];
-    }
-}
-__device__ __forceinline__ u32x4 bn_in_apply(const u32x4& v, const float* sc, const float* sh) {
-    float f[8];
-    unpack8(v, f);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = fmaxf(fmaf(f[k], sc[k], sh[k]), 0.f);
-    return pack8(f);
-}
-
 // STATS: every workgroup also stores the per-channel sum / sum of squares of its (bf16-rounded) outputs to stats[blockIdx.x][2][64]
 // -- the partial sums of the BatchNorm that follows (models/volo.py:356-366), in the layout k_bn_finalize reads.
 //

@@ -148,7 +148,20 @@ k_gemm_nt(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, i
 
     // one K step: registers -> LDS, refill the same register set with step `refill_k`, MFMAs
     // (mode 0: a refill always follows; 1: the last step, the epilogue prefetch takes the refill's place; 2: decided at run time)
+    // PATCH = 1 with ep.abn: this thread's chunk kc holds channels 8 kc .. + 7 of a 64-channel pixel in EVERY K step (a 64-deep step is one pixel)
+    float bsc[PATCH == 1 ? 8 : 1], bsh[PATCH == 1 ? 8 : 1];
+    bool a_bn = false;
+    if constexpr (PATCH == 1) {
+        a_bn = ep.abn.mean != nullptr;
+        if (a_bn) bn_in_consts(ep.abn, kc * 8, bsc, bsh);
+    }
     auto step = [&](u32x4* ra, u32x4* rb, int refill_k, auto mode) {
+        if constexpr (PATCH == 1) {
+            if (a_bn) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) ra[i] = bn_in_apply(ra[i], bsc, bsh);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) st16(sA + soffa[i], ra[i]);
 #pragma unroll
@@ -435,7 +448,7 @@ __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, c
                                         int M, int N1, int N2, int steps_per_split, float* __restrict__ colsum, int t1, int t2, int nblocks, int block,
                                         bf16_t* sA, bf16_t* sB, const bf16_t* __restrict__ cs_weight = nullptr, float cs_scale = 1.0f,
                                         float* __restrict__ slab = nullptr, int splits = 1, float alpha = 1.0f,
-                                        const PatchMap pb = PatchMap{0, 0, 0, 0, 0, 0u, 0u}) {
+                                        const PatchMap pb = PatchMap{0, 0, 0, 0, 0, 0u, 0u}, const BnIn bbn = BnIn{nullptr, nullptr, nullptr, nullptr}) {
     // XCD-aware decode: workgroups that share an XCD (and its L2) get consecutive ids, i.e. all output
     // tiles of the SAME token split, so each token range is fetched from HBM by one L2 only
     // (before: 347 MB of beyond-L2 traffic for 77 MB of operands on the qkv shape)
@@ -522,11 +535,19 @@ __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, c
         const int r = srow + 16 * t;
         woff[t] = r * 128 + ((j ^ tn_swz(r)) << 3);
     }
+    // BPATCH with bbn: the B rows are relu(bn(.)) of the 64-channel map that is read; chunk j of a 128-column tile is channels 8 (j & 7) .. + 7
+    float tsc[BPATCH ? 8 : 1], tsh[BPATCH ? 8 : 1];
+    bool b_bn = false;
+    if constexpr (BPATCH) {
+        b_bn = bbn.mean != nullptr;
+        if (b_bn) bn_in_consts(bbn, (j & 7) * 8, tsc, tsh);
+    }
     auto stage_and_compute = [&](u32x4* ra, u32x4* rb, u32x4* rw, int refill_step) {
         const u32x4 wcur[2] = {rw[0], rw[1]};          // this step's weights (the refill below overwrites the set)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             st16(sA + woff[i], ra[i]);
+            if constexpr (BPATCH) { if (b_bn) rb[i] = bn_in_apply(rb[i], tsc, tsh); }
             st16(sB + woff[i], rb[i]);
         }
         __syncthreads();
@@ -709,11 +730,11 @@ k_gemm_tn_8p(T8Group grp, T8Map map, TnLn ln) {
 
 // one weight gradient whose B rows are patches of an NHWC feature map (PatchMap): a k x k / stride k convolution's dW
 __global__ void __launch_bounds__(256)
-k_gemm_tn_patch(TnArgs a) {
+k_gemm_tn_patch(TnArgs a, BnIn bbn) {
     __shared__ __attribute__((aligned(16))) bf16_t sA[TM * 128];
     __shared__ __attribute__((aligned(16))) bf16_t sB[TM * 128];
     tn_tile<true>(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N1, a.N2, a.steps_per_split, a.colsum, a.t1, a.t2, a.nblocks,
-                  (int)blockIdx.x, sA, sB, a.cs_weight, a.cs_scale, a.slab, a.splits, a.alpha, a.pb);
+                  (int)blockIdx.x, sA, sB, a.cs_weight, a.cs_scale, a.slab, a.splits, a.alpha, a.pb, bbn);
 }
 
 // deterministic mode, second pass: C[n][k] += sum over splits (in split order) of the stored partial tiles; same for the column sums
@@ -1033,7 +1054,13 @@ static bool patch_map_device(const ap_patch_map* map, PatchMap& pm) {
 
 int ap_gemm_nt_patch(const ap_bf16* A, const ap_bf16* B, int ldb, ap_bf16* C, int ld, int M, int N, int K,
                      const float* bias, const ap_patch_map* map, int side, ap_stream_t stream) {
+    return ap_gemm_nt_patch_bn(A, nullptr, B, ldb, C, ld, M, N, K, bias, map, side, stream);
+}
+
+int ap_gemm_nt_patch_bn(const ap_bf16* A, const ap_bn_input* a_bn, const ap_bf16* B, int ldb, ap_bf16* C, int ld, int M, int N, int K,
+                        const float* bias, const ap_patch_map* map, int side, ap_stream_t stream) {
     if (!A || !B || !C || !map) return AP_ERR_NULL;
+    if (a_bn && (side != 1 || !a_bn->mean || !a_bn->rstd || !a_bn->gamma || !a_bn->beta)) return AP_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (ldb & 7) || ldb < K) return AP_ERR_SHAPE;
     EpiArgs ep = {nullptr, 0, nullptr, nullptr, nullptr, 1, nullptr, 0, 0, nullptr, {0, 0, 0, 0, 0, 0u, 0u}, nullptr, nullptr, nullptr};
     if (!patch_map_device(map, ep.pm)) return AP_ERR_SHAPE;
@@ -1042,6 +1069,7 @@ int ap_gemm_nt_patch(const ap_bf16* A, const ap_bf16* B, int ldb, ap_bf16* C, in
     if (side == 1) {            // A rows are patches; C plain [M, ld]
         if ((K & 63) || (map->kseg & 63) || K % map->kseg || ld < N) return AP_ERR_SHAPE;
         ep.bias = bias;
+        if (a_bn) ep.abn = BnIn{a_bn->mean, a_bn->rstd, a_bn->gamma, a_bn->beta};       // (64-channel pixels: kseg % 64 == 0 is checked above)
         const int tm = (M + 127) / 128, tn = (N + 63) / 64, nt = tm * tn;
         hipLaunchKernelGGL((k_gemm_nt<128, 64, 2, 2, true, 1, false, 1>), dim3(nt), dim3(256), 0, (hipStream_t)stream, A, K, B, ldb, C, ld, M, N, K, tn, nt, ep);
     } else if (side == 2) {     // C rows are patches (input gradient); A plain [M, ld]
@@ -1361,7 +1389,14 @@ static int tn_grouped_128(const ap_tn_problem* problems, int count, const ap_ln_
     for (int i = 0; i < count; ++i) any_patch = any_patch || problems[i].b_patch != nullptr;
     if (any_patch) {
         if (count != 1) return AP_ERR_UNSUPPORTED;                  // a patch-addressed problem is launched on its own
-        hipLaunchKernelGGL(k_gemm_tn_patch, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp.p[0]);
+        BnIn bbn = BnIn{nullptr, nullptr, nullptr, nullptr};
+        if (problems[0].b_bn) {
+            const ap_bn_input* q = problems[0].b_bn;
+            if (!q->mean || !q->rstd || !q->gamma || !q->beta) return AP_ERR_NULL;
+            if (problems[0].b_patch->kseg % 64 || problems[0].N2 % 64) return AP_ERR_SHAPE;         // 64-channel pixels, whole pixels per patch row
+            bbn = BnIn{q->mean, q->rstd, q->gamma, q->beta};
+        }
+        hipLaunchKernelGGL(k_gemm_tn_patch, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp.p[0], bbn);
     } else {
         static int place = -1, cap = 0;
         if (place < 0) {

@@ -24,6 +24,25 @@ __device__ __forceinline__ int patch_col(const PatchMap& p, int kk) {
     return q * p.kstride + (kk - q * p.kseg);
 }
 
+// relu(bn(.)) applied to an operand while it is staged (conv.hip PRE_BN; round 5: the A rows of the patch GEMM and the B rows of its weight
+// gradient -- PatchEmbed.proj reads the PRE-BatchNorm output of the last stem convolution, models/volo.py:364-372)
+struct BnIn { const float* mean; const float* rstd; const float* gamma; const float* beta; };
+__device__ __forceinline__ void bn_in_consts(const BnIn& bn, int c8, float* sc, float* sh) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = bn.rstd[c8 + k] * bn.gamma[c8 + k];
+        sh[k] = bn.beta[c8 + k] - bn.mean[c8 + k] * sc[k];
+    }
+}
+__device__ __forceinline__ u32x4 bn_in_apply(const u32x4& v, const float* sc, const float* sh) {
+    float f[8];
+    unpack8(v, f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = fmaxf(fmaf(f[k], sc[k], sh[k]), 0.f);
+    return pack8(f);
+}
+
+
 struct EpiArgs {
     const float* bias; int gelu; bf16_t* preact; const bf16_t* dgelu_of; const float* row_scale;
     int rows_per_scale; const bf16_t* residual; int ldr; int dbg; unsigned long long* stamps;
@@ -34,6 +53,7 @@ struct EpiArgs {
                                                                   // bytes [M, ldc], q8 = sat(out * q8_scale[0]), q8_amax[0] raised to max |out|
     const unsigned char* mul8;  // out = v * gq_decode(mul8[m,n]) (ld = ldc bytes): the 8-bit derivative codes of a gelu = 3 forward
     const unsigned* gelu_tab;   // gelu = 3 launches of the 8-phase kernel: the 4096-entry table of gq_tab_entry() below (global memory), or nullptr
+    BnIn abn;                   // PATCH = 1 only: abn.mean != nullptr -> the A rows (patches of an NHWC map with 64 channels) are relu(bn(.)) of what is read
 };
 
 // 8-bit fixed-point code of gelu'(h) in [-0.1290, 1.1290] (gelu = 3 / mul_by8, include/autoprog_hip.h): code = clamp(rint(202 g) + 26, 0, 255),

@@ -1168,22 +1168,28 @@ class PatchConvFn(torch.autograd.Function):
     bias [N] or None -> [B, H/k, W/k, N] bf16."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, k):
+    def forward(ctx, x, weight, bias, k, bn_mean=None, bn_rstd=None, bn_gamma=None, bn_beta=None):
+        """bn_* given (round 5): x is the PRE-BatchNorm output z of the layer in front (64 channels) and this convolution acts on
+        relu(bn(z)) -- batch statistics bn_mean / bn_rstd, affine parameters bn_gamma / bn_beta -- applied while the kernels stage z (forward and
+        weight gradient); the backward runs the BatchNorm + ReLU backward on its input gradient and hands out dL/dz and the gradients of
+        gamma / beta: the activation between the stem's last BatchNorm and PatchEmbed.proj (models/volo.py:364-372) never exists."""
         xc = x.contiguous()
         B, H, W, C = xc.shape
         N = weight.shape[0]
         wmat = torch.empty((N, k, k, C), dtype=BF16, device=weight.device)
         wmat.copy_(weight.detach().permute(0, 2, 3, 1))                                      # re-layout + cast in ONE copy kernel
         wmat = wmat.view(N, k * k * C)                                                       # columns ordered (dy, dx, c)
-        y = ops.gemm_nt_patch_fwd(xc, wmat, bias, k)
-        ctx.save_for_backward(xc, weight, bias, wmat)
+        bn = (bn_mean, bn_rstd, bn_gamma, bn_beta) if bn_mean is not None else None
+        y = ops.gemm_nt_patch_fwd(xc, wmat, bias, k, bn_in=bn)
+        ctx.save_for_backward(xc, weight, bias, wmat, bn_mean, bn_rstd, bn_gamma, bn_beta)
         ctx.k = k
         out = y.view(B, H // k, W // k, y.shape[-1])
         return out if y.shape[-1] == N else out[..., :N]
 
     @staticmethod
     def backward(ctx, dy):
-        xc, weight, bias, wmat = ctx.saved_tensors
+        xc, weight, bias, wmat, bn_mean, bn_rstd, bn_gamma, bn_beta = ctx.saved_tensors
+        bn = (bn_mean, bn_rstd, bn_gamma, bn_beta) if bn_mean is not None else None
         k = ctx.k
         B, H, W, C = xc.shape
         N, K = wmat.shape
@@ -1194,10 +1200,10 @@ class PatchConvFn(torch.autograd.Function):
             gp[:, :N] = g
             g = gp
         g = g.contiguous()
-        params = (weight, bias)
+        params = (weight, bias) if bn is None else (weight, bias, bn_gamma, bn_beta)
         bufs, sunk = _param_grad_buffers(params)
         dwmat = torch.zeros((N, K), dtype=torch.float32, device=g.device)
-        _launch_wgrads([(g, xc, dwmat, N, K, bufs[1], None, 1.0, 1.0, ops.patch_map(H, W, C, k))])
+        _launch_wgrads([(g, xc, dwmat, N, K, bufs[1], None, 1.0, 1.0, ops.patch_map(H, W, C, k), bn)])
         join_wgrad_stream()
         bufs[0].add_(dwmat.view(N, k, k, C).permute(0, 3, 1, 2))                              # back to OIHW
         dx = None
@@ -1205,8 +1211,12 @@ class PatchConvFn(torch.autograd.Function):
             wt = torch.zeros((K, ld), dtype=BF16, device=g.device) if ld != N else torch.empty((K, N), dtype=BF16, device=g.device)
             wt[:, :N] = wmat.t()
             dx = ops.gemm_nt_patch_dgrad(g, wt, (B, H, W, C), k)
-        dw, db = _finish_param_grads(params, bufs, sunk)
-        return dx, dw, db, None
+            if bn is not None:            # dL/d(relu(bn(z))) -> dL/dz and the BatchNorm's parameter gradients
+                dx = ops.bn_relu_bwd(dx, xc, bn_gamma, bn_beta, bn_mean, bn_rstd, bufs[2], bufs[3])
+        elif bn is not None:
+            raise AutoProgHipError("PatchConvFn with a BatchNorm input: the BatchNorm's parameter gradients need the input gradient")
+        gr = _finish_param_grads(params, bufs, sunk)
+        return (dx, gr[0], gr[1], None, None, None) + ((gr[2], gr[3]) if bn is not None else (None, None))
 
 
 def patch_conv_ok(x, weight, k):
@@ -1287,7 +1297,10 @@ class Stem64Fn(torch.autograd.Function):
     Saves two passes of 411 MB per step at B = 128, 224 px.  AP_STEM_FUSE_BN=0 keeps the chain."""
 
     @staticmethod
-    def forward(ctx, xs, w7, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3, training, momentum, eps):
+    def forward(ctx, xs, w7, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, w3, g3, b3, rm3, rv3, training, momentum, eps, apply_last=True):
+        """apply_last = False (round 5): -> (z3, mean3, rstd3), the PRE-BatchNorm output of the last convolution and its batch (or running)
+        statistics; the consumer -- PatchConvFn with bn_* -- applies relu(bn3(.)) while it stages z3 and returns dL/dz3 with the BatchNorm's
+        backward already applied; g3 / b3 then get their gradients there, not here"""
         wp7 = ops.conv7_pack(w7.detach().float().contiguous())
         wf2, wb2 = ops.conv3x3_pack(w2.detach().float().contiguous())
         wf3, wb3 = ops.conv3x3_pack(w3.detach().float().contiguous())
@@ -1299,27 +1312,36 @@ class Stem64Fn(torch.autograd.Function):
             z2, p2 = ops.conv3x3_c64(z1, wf2, True, bn_in=(mean1, rstd1, g1, b1))
             _, mean2, rstd2 = ops.bn_relu_fwd(z2, g2, b2, rm2, rv2, True, mom2, eps2, partials=p2, apply=False)
             z3, p3 = ops.conv3x3_c64(z2, wf3, True, bn_in=(mean2, rstd2, g2, b2))
-            y, mean3, rstd3 = ops.bn_relu_fwd(z3, g3, b3, rm3, rv3, True, mom3, eps3, partials=p3)
+            y, mean3, rstd3 = ops.bn_relu_fwd(z3, g3, b3, rm3, rv3, True, mom3, eps3, partials=p3, apply=apply_last)
         else:
             z1 = ops.conv7_s2d(xs, wp7)
             _, mean1, rstd1 = ops.bn_relu_fwd(z1, g1, b1, rm1, rv1, False, mom1, eps1, apply=False)
             z2 = ops.conv3x3_c64(z1, wf2, bn_in=(mean1, rstd1, g1, b1))
             _, mean2, rstd2 = ops.bn_relu_fwd(z2, g2, b2, rm2, rv2, False, mom2, eps2, apply=False)
             z3 = ops.conv3x3_c64(z2, wf3, bn_in=(mean2, rstd2, g2, b2))
-            y, mean3, rstd3 = ops.bn_relu_fwd(z3, g3, b3, rm3, rv3, False, mom3, eps3)
+            y, mean3, rstd3 = ops.bn_relu_fwd(z3, g3, b3, rm3, rv3, False, mom3, eps3, apply=apply_last)
         ctx.save_for_backward(xs, z1, z2, z3, wb2, wb3, w7, g1, b1, w2, g2, b2, w3, g3, b3, mean1, rstd1, mean2, rstd2, mean3, rstd3)
         ctx.training = training
+        ctx.apply_last = apply_last
+        if not apply_last:
+            ctx.mark_non_differentiable(mean3, rstd3)
+            return z3, mean3, rstd3
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         (xs, z1, z2, z3, wb2, wb3, w7, g1, b1, w2, g2, b2, w3, g3, b3, mean1, rstd1, mean2, rstd2, mean3, rstd3) = ctx.saved_tensors
         if not ctx.training:
             raise AutoProgHipError("Stem64Fn backward is implemented for training mode (batch statistics) only")
-        params = (w7, g1, b1, w2, g2, b2, w3, g3, b3)
+        last = ctx.apply_last
+        params = (w7, g1, b1, w2, g2, b2, w3, g3, b3) if last else (w7, g1, b1, w2, g2, b2, w3)
         bufs, sunk = _param_grad_buffers(params)
-        dw7, dg1, db1, dw2, dg2, db2, dw3, dg3, db3 = bufs
-        dz3 = ops.bn_relu_bwd(dy.contiguous(), z3, g3, b3, mean3, rstd3, dg3, db3)
+        if last:
+            dw7, dg1, db1, dw2, dg2, db2, dw3, dg3, db3 = bufs
+            dz3 = ops.bn_relu_bwd(dy.contiguous(), z3, g3, b3, mean3, rstd3, dg3, db3)
+        else:                              # dy IS dL/dz3: the consumer ran the last BatchNorm's backward (PatchConvFn with bn_*)
+            dw7, dg1, db1, dw2, dg2, db2, dw3 = bufs
+            dz3 = dy.contiguous()
         da2 = ops.conv3x3_c64(dz3, wb3)
         ops.conv3x3_c64_wgrad(z2, dz3, dw3, bn_in=(mean2, rstd2, g2, b2))
         dz2 = ops.bn_relu_bwd(da2, z2, g2, b2, mean2, rstd2, dg2, db2)
@@ -1327,11 +1349,14 @@ class Stem64Fn(torch.autograd.Function):
         ops.conv3x3_c64_wgrad(z1, dz2, dw2, bn_in=(mean1, rstd1, g1, b1))
         dz1 = ops.bn_relu_bwd(da1, z1, g1, b1, mean1, rstd1, dg1, db1)
         ops.conv7_s2d_wgrad(xs, dz1, dw7)
-        gr = _finish_param_grads(params, bufs, sunk)
-        return (None, gr[0], gr[1], gr[2], None, None, gr[3], gr[4], gr[5], None, None, gr[6], gr[7], gr[8], None, None, None, None, None)
+        gr = list(_finish_param_grads(params, bufs, sunk))
+        if not last:
+            gr += [None, None]
+        return (None, gr[0], gr[1], gr[2], None, None, gr[3], gr[4], gr[5], None, None, gr[6], gr[7], gr[8], None, None, None, None, None, None)
 
 
 STEM_FUSE_BN = os.environ.get("AP_STEM_FUSE_BN", "1") != "0"
+STEM_FUSE_BN_PROJ = os.environ.get("AP_STEM_FUSE_BN_PROJ", "1") != "0"     # the LAST BatchNorm + ReLU of the stem inside PatchEmbed.proj's patch GEMMs
 
 
 def to_bf16(x):

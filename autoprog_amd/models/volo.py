@@ -349,12 +349,19 @@ class PatchEmbed(nn.Module):
                     and all(self.conv[i].running_mean is not None for i in (1, 4, 7))):
                 # the three convolutions as one node: the activations between them are applied inside the next convolution's staging
                 c = self.conv
+                k = self.proj.kernel_size[0]
+                # the last BatchNorm + ReLU inside the projection's staging (functional.PatchConvFn bn_*): its activation is never written
+                fuse_last = (AF.STEM_FUSE_BN_PROJ and self.proj.stride[0] == k and self.proj.in_channels == 64 and (xs.shape[1] % k == 0) and (xs.shape[2] % k == 0)
+                             and (k * 64) % 64 == 0)
                 whole = AF.Stem64Fn.apply(xs, c[0].weight, c[1].weight, c[1].bias, c[1].running_mean, c[1].running_var,
                                           c[3].weight, c[4].weight, c[4].bias, c[4].running_mean, c[4].running_var,
                                           c[6].weight, c[7].weight, c[7].bias, c[7].running_mean, c[7].running_var,
-                                          self.training, (c[1].momentum, c[4].momentum, c[7].momentum), (c[1].eps, c[4].eps, c[7].eps))
+                                          self.training, (c[1].momentum, c[4].momentum, c[7].momentum), (c[1].eps, c[4].eps, c[7].eps), not fuse_last)
                 if self.training:
                     torch._foreach_add_([c[i].num_batches_tracked for i in (1, 4, 7) if c[i].num_batches_tracked is not None], 1)
+                if fuse_last:
+                    z3, mean3, rstd3 = whole
+                    return AF.PatchConvFn.apply(z3, self.proj.weight, self.proj.bias, k, mean3, rstd3, c[7].weight, c[7].bias).permute(0, 3, 1, 2)
                 return self._project(whole.permute(0, 3, 1, 2), fused)
             first = AF.Conv7BNReLUFn.apply(xs, self.conv[0].weight, bn.weight, bn.bias,
                                            bn.running_mean, bn.running_var, self.training, bn.momentum, bn.eps)

@@ -319,15 +319,23 @@ def patch_map(H, W, C, k):
     return PatchMap(W // k, k * W * C, k * C, k * C, W * C)
 
 
-def gemm_nt_patch_fwd(x, wmat, bias, k):
+def gemm_nt_patch_fwd(x, wmat, bias, k, bn_in=None):
     """x [B,H,W,C] bf16 NHWC, wmat [N, k*k*C] bf16 (columns ordered (dy, dx, c)) -> [B*(H/k)*(W/k), round_up(N, 8)] bf16:
-    the forward of a k x k / stride k convolution, its input read in place (no gathered patch matrix)"""
+    the forward of a k x k / stride k convolution, its input read in place (no gathered patch matrix).
+    bn_in = (mean, rstd, gamma, beta) (C = 64): x is a PRE-BatchNorm tensor and the kernel convolves relu(bn(x)), applied while it stages x"""
     _req(x, BF16, "x"); _req(wmat, BF16, "wmat")
     B, H, W, C = x.shape
     pm = patch_map(H, W, C, k)
     M, N, K = B * (H // k) * (W // k), wmat.shape[0], k * k * C
     ld = round_up(N, 8)
     out = torch.empty((M, ld), dtype=BF16, device=x.device)
+    if bn_in is not None:
+        if C != 64:
+            raise AutoProgHipError("gemm_nt_patch_fwd(bn_in=...): 64-channel feature maps")
+        b = _bn_input(bn_in)
+        check(lib.ap_gemm_nt_patch_bn(x.data_ptr(), ctypes.byref(b), wmat.data_ptr(), wmat.shape[1], out.data_ptr(), ld, M, N, K,
+                                      bias.data_ptr() if bias is not None else None, ctypes.byref(pm), 1, _stream()), "ap_gemm_nt_patch_bn")
+        return out
     check(lib.ap_gemm_nt_patch(x.data_ptr(), wmat.data_ptr(), wmat.shape[1], out.data_ptr(), ld, M, N, K,
                                bias.data_ptr() if bias is not None else None, ctypes.byref(pm), 1, _stream()), "ap_gemm_nt_patch")
     return out
@@ -346,7 +354,8 @@ def gemm_nt_patch_dgrad(dy, wmat_t, shape, k):
 
 
 def gemm_tn_acc_grouped(problems, ln=None):
-    """problems: list of (a, b, c, n1, n2, colsum[, colsum_weight, colsum_scale[, alpha[, b_patch]]]) as for gemm_tn_acc; ONE launch for
+    """problems: list of (a, b, c, n1, n2, colsum[, colsum_weight, colsum_scale[, alpha[, b_patch[, b_bn]]]]) as for gemm_tn_acc (b_bn: the
+    (mean, rstd, gamma, beta) of a BatchNorm whose relu(bn(.)) is applied to the patch-addressed b while it is staged); ONE launch for
     the whole list (chunks of 8).  colsum_weight: bf16 per-token weights of the column sum (DropPath keep mask), colsum_scale its factor;
     alpha: factor of the product (c += alpha * a^T b); b_patch: PatchMap -- b is then an NHWC feature map whose patches are the rows.
     ln: deferred LayerNorm reductions (the entries layernorm_bwd(..., defer=...) appended): LN_MAX_BATCH of them ride in the first launch."""
@@ -369,6 +378,10 @@ def gemm_tn_acc_grouped(problems, ln=None):
             if bp is not None:
                 keep.append(bp)
                 q.b_patch = ctypes.addressof(bp)
+                if len(prob) > 10 and prob[10] is not None:
+                    bb = _bn_input(prob[10])
+                    keep.append(bb)
+                    q.b_bn = ctypes.addressof(bb)
                 q.A, q.lda, q.B, q.ldb, q.C, q.ldc = a.data_ptr(), a.shape[1], b.data_ptr(), 0, c.data_ptr(), c.shape[1]
                 q.M, q.N1, q.N2 = a.shape[0], (c.shape[0] if n1 is None else n1), (c.shape[1] if n2 is None else n2)
                 q.colsum_A = colsum.data_ptr() if colsum is not None else None

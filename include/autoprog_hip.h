@@ -102,6 +102,11 @@ typedef struct ap_patch_map { int group, group_stride, row_stride, kseg, kseg_st
  * side 2: C_patches[M, N] = A[M, ld >= K] . B[N, K]^T        (input gradient written in place of the feature map; bias NULL) */
 int ap_gemm_nt_patch(const ap_bf16* A, const ap_bf16* B, int ldb, ap_bf16* C, int ld, int M, int N, int K,
                      const float* bias, const ap_patch_map* map, int side, ap_stream_t stream);
+/* (ABI version 6) side = 1 with a_bn: the A rows are relu(bn(.)) of the 64-channel NHWC map that is read (the activation between the last
+ * stem convolution and PatchEmbed.proj, models/volo.py:364-372, is never materialised); a_bn NULL: ap_gemm_nt_patch */
+struct ap_bn_input;
+int ap_gemm_nt_patch_bn(const ap_bf16* A, const struct ap_bn_input* a_bn, const ap_bf16* B, int ldb, ap_bf16* C, int ld, int M, int N, int K,
+                        const float* bias, const ap_patch_map* map, int side, ap_stream_t stream);
 
 typedef struct ap_gemm_epilogue {
     const float* bias;          /* [N] or NULL */
@@ -164,6 +169,8 @@ typedef struct ap_tn_problem {
     float colsum_scale;             /* used with colsum_weight only (1/keep) */
     const struct ap_patch_map* b_patch;   /* non-NULL: the rows of B are patches of an NHWC feature map (ldb ignored) -- the weight
                                            * gradient of a k x k / stride k convolution without a gathered copy of its input */
+    const struct ap_bn_input* b_bn;       /* (ABI version 6, with b_patch, 64-channel maps) non-NULL: the B rows are relu(bn(.)) of the map that is read
+                                           * -- PatchEmbed.proj's weight gradient on the PRE-BatchNorm output of the last stem convolution */
 } ap_tn_problem;
 /* `workspace` NULL: partial tiles of the token splits are added with fp32 atomics (results vary in the last bits from run to run).
  * `workspace` of >= ap_gemm_tn_grouped_workspace() bytes: DETERMINISTIC -- every split stores its partial tile and a second kernel adds
