@@ -843,6 +843,8 @@ static void g8_pick_fp8(const G8Args& ga, const EpiArgs& ep, int grid, hipStream
         case G8_BIAS: g8_go_fp8<NT1, G8_BIAS>(ga, ep, grid, st); break;
         case G8_BIAS | G8_GELU: g8_go_fp8<NT1, G8_BIAS | G8_GELU>(ga, ep, grid, st); break;
         case G8_BIAS | G8_GELU | G8_RS: g8_go_fp8<NT1, G8_BIAS | G8_GELU | G8_RS>(ga, ep, grid, st); break;
+        case G8_BIAS | G8_GELU | G8_GTAB: g8_go_fp8<NT1, G8_BIAS | G8_GELU | G8_GTAB>(ga, ep, grid, st); break;
+        case G8_BIAS | G8_GELU | G8_RS | G8_GTAB: g8_go_fp8<NT1, G8_BIAS | G8_GELU | G8_RS | G8_GTAB>(ga, ep, grid, st); break;
         case G8_BIAS | G8_RES: g8_go_fp8<NT1, G8_BIAS | G8_RES>(ga, ep, grid, st); break;
         case G8_BIAS | G8_RS | G8_RES: g8_go_fp8<NT1, G8_BIAS | G8_RS | G8_RES>(ga, ep, grid, st); break;
         default: g8_go_fp8<NT1, -1>(ga, ep, grid, st); break;
@@ -1034,6 +1036,7 @@ int ap_gemm_nt_fp8(const unsigned char* A, int lda, const unsigned char* B, int 
     // (K % 128 == 0 here: whole 128-byte K-tiles), the 128 x 128-tile kernel otherwise
     if ((K & 127) == 0 && !ep.dgelu_of) {
         const int bn8 = use_8p(M, N, K / 2, ldc, ep);
+        if (bn8 && ep.gelu == 3) ep.gelu_tab = g8_gelu_table_ptr((hipStream_t)stream);
         if (bn8) return g8_launch(bn8, reinterpret_cast<const bf16_t*>(A), lda / 2, reinterpret_cast<const bf16_t*>(B), ldb / 2, C, ldc, M, N, K / 2, ep,
                                   (hipStream_t)stream, true);
     }

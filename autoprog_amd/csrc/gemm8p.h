@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     constexpr int STG = 2 * KS;                  // epilogue staging region: the rest of the LDS (48 KB at BN = 192, 32 KB at BN = 256)
     // GTAB (the GELU flavours): 16 KB of the staging region hold the GELU table of gemm_epi.h (gelu = 3 launches: Phi(h) and the 8-bit
     // derivative code per bf16 value); the staging passes are half as tall
-    constexpr bool GTAB = EF >= 0 && (EF & G8_GELU) != 0 && (EF & G8_GTAB) != 0 && !FP8;        // (the gelu = 1 / 2 launches keep the tall passes: 55.9 against 61.4 us)
+    constexpr bool GTAB = EF >= 0 && (EF & G8_GELU) != 0 && (EF & G8_GTAB) != 0;        // (the gelu = 1 / 2 launches keep the tall passes: 55.9 against 61.4 us)
     constexpr int PASS_MT = (NT1 == 1 ? 4 : 2) / (GTAB ? 2 : 1);    // 16-row tiles per wave group and staging pass
     constexpr int NPASS = 8 / PASS_MT;
     constexpr int RS = BN * 2;                   // bytes of a staged row
@@ -656,6 +656,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                                 for (int q = 0; q < 8; ++q) f[q] = gelu_erf(f[q]) * rs;
                             }
                             x = pack8(f);
+                        }
+                        if (rowgelu) {
                             if constexpr (FP8) {
                                 if (ep.q8) {           // the operand of the fp8 GEMM that consumes this activation (fc2), without a pass of its own
                                     float r8[8];
