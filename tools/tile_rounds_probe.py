@@ -9,6 +9,7 @@ probe times the same kernel, same N and K, cold operands (rotating buffers > 600
 tiles: the ratio T(256 tiles) / T(196 tiles) decides (1.0: per-tile time; 1.31: chip-wide delivery)."""
 import os
 import sys
+os.environ.setdefault("AP_GEMM_BM224", "0")          # the question is asked of the 256-row tiles (read once per process by the library)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from autoprog_amd import ops
