@@ -104,6 +104,9 @@ _SIGNATURES["ap_quantize_fp8_multi"] = (_I, [_P, _I, _P, _P, _P])
 _SIGNATURES["ap_debug_poison_lds"] = (_I, [ctypes.c_uint, _P, _P])
 _SIGNATURES["ap_conv3x3_c64_bn"] = (_I, [_P, POINTER(BnInput), _P, _P, _I, _I, _I, _P, _P])
 _SIGNATURES["ap_conv3x3_c64_wgrad_bn"] = (_I, [_P, POINTER(BnInput), _P, _P, _I, _I, _I, _P, ctypes.c_size_t, _P])
+_SIGNATURES["ap_conv3x3_c64_bwd_stats"] = (_I, [_P, _P, _P, _I, _I, _I, _P, POINTER(BnInput), _P, _P])
+_SIGNATURES["ap_bn_relu_bwd_act"] = (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, _P])
+_SIGNATURES["ap_bn_relu_bwd_partials"] = (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _P, ctypes.c_size_t, _P])
 _SIGNATURES["ap_mhsa_fwd_fp8"] = (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P])
 _SIGNATURES["ap_gemm_nt_fp8"] = (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, POINTER(GemmEpilogue), _P])
 _SIGNATURES["ap_gemm_nt_patch"] = (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P, POINTER(PatchMap), _I, _P])

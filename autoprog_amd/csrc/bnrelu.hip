@@ -157,10 +157,13 @@ k_bn_bwd_finalize(const float* __restrict__ partial, int nblocks, int C, float* 
 }
 
 // backward pass 2: dx = gamma*rstd*(dz - dbeta/T - xhat*dgamma/T)
+// ACT: also write act = relu(bn(x)) in the arithmetic of k_bn_relu_apply / bn_in_apply (the forward that never stored it, gemm_epi.h): the
+// pass holds x anyway, and the weight gradient of the layer above then reads a plain tensor instead of transforming every chunk it stages
+template <bool ACT>
 __global__ void __launch_bounds__(BN_BLOCK)
 k_bn_relu_bwd_dx(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const float* __restrict__ mean,
                  const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                 const float* __restrict__ sums, bf16_t* __restrict__ dx, int64_t T, int C) {
+                 const float* __restrict__ sums, bf16_t* __restrict__ dx, int64_t T, int C, bf16_t* __restrict__ act = nullptr) {
     const int cpr = C >> 3;
     const int chunk = threadIdx.x % cpr;
     const int rows_per_pass = BN_BLOCK / cpr;
@@ -175,6 +178,12 @@ k_bn_relu_bwd_dx(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, co
         float f[8], d[8];
         unpack8(ld16(x + row * C + chunk * 8), f);
         unpack8(ld16(dy + row * C + chunk * 8), d);
+        if constexpr (ACT) {
+            float a8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float sc = rs[k] * ga[k]; a8[k] = fmaxf(fmaf(f[k], sc, be[k] - mu[k] * sc), 0.f); }
+            st16(act + row * C + chunk * 8, pack8(a8));
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float xh = (f[k] - mu[k]) * rs[k];
@@ -244,7 +253,36 @@ int ap_bn_relu_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, cons
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_bn_relu_bwd_reduce, dim3(grid), dim3(BN_BLOCK), 0, s, dy, x, mean, rstd, gamma, beta, partial, T, C);
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(C), dim3(BN_BLOCK), 0, s, partial, grid, C, sums, dgamma, dbeta);
-    hipLaunchKernelGGL(k_bn_relu_bwd_dx, dim3(grid), dim3(BN_BLOCK), 0, s, dy, x, mean, rstd, gamma, beta, sums, dx, T, C);
+    hipLaunchKernelGGL(k_bn_relu_bwd_dx<false>, dim3(grid), dim3(BN_BLOCK), 0, s, dy, x, mean, rstd, gamma, beta, sums, dx, T, C, nullptr);
+    return ap_check_launch();
+}
+
+int ap_bn_relu_bwd_act(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* beta, const float* mean,
+                       const float* rstd, ap_bf16* dx, ap_bf16* act, float* dgamma, float* dbeta, int64_t T, int C,
+                       void* workspace, size_t ws_bytes, ap_stream_t stream) {
+    if (!dy || !x || !gamma || !beta || !mean || !rstd || !dx || !act || !dgamma || !dbeta || !workspace) return AP_ERR_NULL;
+    if (!bn_shape_ok(C) || T <= 0 || ws_bytes < ap_bn_relu_workspace(T, C)) return AP_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = bn_grid(T, C);
+    float* partial = static_cast<float*>(workspace);
+    float* sums = partial + (size_t)2048 * 2 * C;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_bn_relu_bwd_reduce, dim3(grid), dim3(BN_BLOCK), 0, s, dy, x, mean, rstd, gamma, beta, partial, T, C);
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(C), dim3(BN_BLOCK), 0, s, partial, grid, C, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(k_bn_relu_bwd_dx<true>, dim3(grid), dim3(BN_BLOCK), 0, s, dy, x, mean, rstd, gamma, beta, sums, dx, T, C, act);
+    return ap_check_launch();
+}
+
+int ap_bn_relu_bwd_partials(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* beta, const float* mean,
+                            const float* rstd, const float* partial, int n_partial, ap_bf16* dx, float* dgamma, float* dbeta,
+                            int64_t T, int C, void* workspace, size_t ws_bytes, ap_stream_t stream) {
+    if (!dy || !x || !gamma || !beta || !mean || !rstd || !partial || !dx || !dgamma || !dbeta || !workspace) return AP_ERR_NULL;
+    if (!bn_shape_ok(C) || T <= 0 || n_partial <= 0 || ws_bytes < ap_bn_relu_workspace(T, C)) return AP_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    float* sums = static_cast<float*>(workspace) + (size_t)2048 * 2 * C;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(C), dim3(BN_BLOCK), 0, s, partial, n_partial, C, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(k_bn_relu_bwd_dx<false>, dim3(bn_grid(T, C)), dim3(BN_BLOCK), 0, s, dy, x, mean, rstd, gamma, beta, sums, dx, T, C, nullptr);
     return ap_check_launch();
 }
 

@@ -66,10 +66,20 @@ k_conv3x3_pack(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __r
 // and every barrier of that wave leaves the SIMD's matrix pipe idle.  Eight waves (two per SIMD, 256 registers each -- the budget of
 // a wave does not shrink) take tile rows w, w + 8, ...: 4 x 4 accumulator tiles, half the staging and output registers per wave, the
 // weight fragments read by twice as many waves (0.5 instead of 0.375 KB of LDS reads per MFMA).
-template <bool STATS, int ABL = 0, bool PRE_BN = false, int NW = 4>
+//
+// BSTATS (round 5; the input-gradient launch of a stem layer, NW = 8): y is dL/da of the layer BELOW -- a = relu(bn(zprev)) -- and the
+// first pass of that BatchNorm's backward (k_bn_relu_bwd_reduce: sum dz, sum dz * xhat per channel, dz = dy where the ReLU passed) needs
+// exactly the values this kernel holds in registers when a tile is done.  The tile's zprev chunks are requested behind the next tile's
+// patch loads (they land under the remaining MFMA steps), the sums are formed from the bf16-ROUNDED outputs in the arithmetic of
+// k_bn_relu_bwd_reduce, and every workgroup stores its partial row to stats[blockIdx.x][2][64] -- the layout k_bn_bwd_finalize reads.
+// `bn` then holds the statistics / affine parameters of the layer below (in LDS: 1 KB behind the patch).  Saves one pass over
+// dL/da and zprev (2 x 205 MB per layer at B = 128, 224 px).
+template <bool STATS, int ABL = 0, bool PRE_BN = false, int NW = 4, bool BSTATS = false>
 __global__ void __launch_bounds__(64 * NW)
 k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_t* __restrict__ y, int H, int W,
-              int tiles_x, int tiles_y, int ntiles, float* __restrict__ stats, BnIn bn = BnIn{nullptr, nullptr, nullptr, nullptr}) {
+              int tiles_x, int tiles_y, int ntiles, float* __restrict__ stats, BnIn bn = BnIn{nullptr, nullptr, nullptr, nullptr},
+              const bf16_t* __restrict__ zprev = nullptr) {
+    static_assert(!(BSTATS && (STATS || PRE_BN)), "BSTATS is the input-gradient launch: no forward statistics, no input transform");
     constexpr int NTH = 64 * NW, RPW = CV_TR / NW, NPRE = (CV_NCHUNK + NTH - 1) / NTH, PSTEP = NTH / 8;     // threads, tile rows per wave, patch chunks per thread, pixels per staging sweep
     constexpr int NOUT = 2 * RPW, SL = NOUT / 4;                                                        // output chunks per lane; first step of the next tile's loads
     extern __shared__ __attribute__((aligned(16))) bf16_t cv_smem[];
@@ -89,6 +99,13 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
     for (int idx = tid; idx < CV_WELEMS / 8; idx += NTH) {
         const int row = idx >> 3, c = idx & 7;
         st16(Wl + row * CV_C + ((c ^ key_b(row & (CV_C - 1))) << 3), ld16(wp + (int64_t)idx * 8));
+    }
+    float* const bpar = reinterpret_cast<float*>(P + CV_NPIX * CV_PSTR);     // BSTATS: [mean | rstd | gamma | beta][64] of the layer below
+    if constexpr (BSTATS) {
+        if (tid < 4 * CV_C) {
+            const float* src = tid < CV_C ? bn.mean : tid < 2 * CV_C ? bn.rstd : tid < 3 * CV_C ? bn.gamma : bn.beta;
+            bpar[tid] = src[tid & (CV_C - 1)];
+        }
     }
 
     auto tile_origin = [&](int t, int& b, int& ty0, int& tx0) {
@@ -119,7 +136,9 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
         pre[i] = ld16(img + (unsigned)((gy * W + gx) * CV_C + c8));  // uniform base + 32-bit lane offset
     };
     auto patch_org = [&](int b, int ty0, int tx0) { return x + (int64_t)b * H * W * CV_C; };
-    float ssum[2][8], ssq[2][8];                 // STATS: this lane's channels 32 pr + 8 g .. +7
+    float ssum[2][8], ssq[2][8];                 // STATS / BSTATS: this lane's channels 32 pr + 8 g .. +7
+    u32x4 zq[BSTATS ? NOUT : 1];                 // BSTATS: zprev at this lane's output positions (chunk 2 i + pr)
+    float bsum[2] = {0.f, 0.f}, bsq[2] = {0.f, 0.f};        // BSTATS: running sums of the channels 32 pr + 8 g + (fr & 7), over half of this lane's 16-lane group
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
@@ -187,13 +206,25 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
         // loads of the next tile (steps 4-8): vmcnt counts loads and stores in one in-order counter, so the wait for the loads at
         // the top of the next tile also covers everything issued before them -- stores issued AFTER a load would sit in front of
         // that wait -- and the last load still has ten steps (~3 us) to land.  (One load + one store in every step: 200 us.)
+        const bf16_t* zimg = BSTATS ? zprev + (int64_t)bc * H * W * CV_C : nullptr;             // UNIFORM
+        const int zcol = min(tx0c + fr, W - 1);
+        auto zload1 = [&](int c2) {              // rows / columns beyond the image read a clamped, valid address and are not counted
+            const int row = min(ty0c + wave + NW * (c2 >> 1), H - 1);
+            zq[BSTATS ? c2 : 0] = ld16(zimg + (unsigned)((row * W + zcol) * CV_C + 32 * (c2 & 1) + 8 * g));
+        };
+        constexpr int SZ = SL + (NPRE + 3) / 4;                    // BSTATS: first step of the zprev loads (behind the patch loads)
         auto side = [&](int s) {
             if (s < SL) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) store1(4 * s + k);
-            } else if (s < SL + (NPRE + 3) / 4 && have_next) {
+            } else if (s < SZ) {
+                if (have_next) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) if (4 * (s - SL) + k < NPRE) gload1(4 * (s - SL) + k, orgn, ty0n, tx0n);
+                    for (int k = 0; k < 4; ++k) if (4 * (s - SL) + k < NPRE) gload1(4 * (s - SL) + k, orgn, ty0n, tx0n);
+                }
+            } else if (BSTATS && s < SZ + NOUT / 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) zload1(4 * (s - SZ) + k);
             }
         };
         auto compute = [&](auto full) {
@@ -244,21 +275,79 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
                 }
             }
         }
+        if constexpr (BSTATS) {
+            // 32 running sums per lane do not fit beside the pipeline's registers: a channel half's sums are temporaries, a reduce-scatter
+            // over 8 of the 16 lanes of a group (same g = same channels) leaves each lane ONE channel's pair per half to accumulate
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                f32x4 mu[2], rs[2], ga[2], be[2];
+                const float* bp = bpar + 32 * pr + 8 * g;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    mu[k] = *reinterpret_cast<const f32x4*>(bp + 4 * k);
+                    rs[k] = *reinterpret_cast<const f32x4*>(bp + CV_C + 4 * k);
+                    ga[k] = *reinterpret_cast<const f32x4*>(bp + 2 * CV_C + 4 * k);
+                    be[k] = *reinterpret_cast<const f32x4*>(bp + 3 * CV_C + 4 * k);
+                }
+                float ts[8], tq[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { ts[k] = 0.f; tq[k] = 0.f; }
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) {
+                    if (i < nrow && col_ok_prev) {
+                        float d8[8], z8[8];
+                        unpack8(outp[2 * i + pr], d8);        // what is stored: the BatchNorm backward reads the bf16 tensor
+                        unpack8(zq[2 * i + pr], z8);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float xh = (z8[k] - mu[k >> 2][k & 3]) * rs[k >> 2][k & 3];
+                            const float dz = (fmaf(xh, ga[k >> 2][k & 3], be[k >> 2][k & 3]) > 0.f) ? d8[k] : 0.f;
+                            ts[k] += dz; tq[k] += dz * xh;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int n = 4; n >= 1; n >>= 1) {   // keep the half of the index range that matches this lane's bit, add the partner's
+                    const bool up = fr & n;
+#pragma unroll
+                    for (int j = 0; j < n; ++j) {
+                        const float ks = up ? ts[n + j] : ts[j], gs = up ? ts[j] : ts[n + j];
+                        const float kq = up ? tq[n + j] : tq[j], gq = up ? tq[j] : tq[n + j];
+                        ts[j] = ks + __shfl_xor(gs, n, 64);
+                        tq[j] = kq + __shfl_xor(gq, n, 64);
+                    }
+                }
+                bsum[pr] += ts[0]; bsq[pr] += tq[0];          // channel 32 pr + 8 g + (fr & 7), the lanes fr and fr ^ 8 hold two halves of the group's sum
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         __syncthreads();                       // every wave is done with the patch before the next one overwrites it
     }
 #pragma unroll
     for (int s = 0; s < NOUT; ++s) store1(s);  // the last tile's output
-    if constexpr (STATS) {
+    if constexpr (STATS || BSTATS) {
         // lanes with the same g hold the same channels: butterfly over fr, then the 4 waves meet in LDS (the patch is free)
         float* red = reinterpret_cast<float*>(P);                    // [NW waves][2][64]
+        if constexpr (BSTATS) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const float ts = bsum[pr] + __shfl_xor(bsum[pr], 8, 64), tq = bsq[pr] + __shfl_xor(bsq[pr], 8, 64);
+                if (fr < 8) {
+                    red[(wave * 2 + 0) * CV_C + 32 * pr + 8 * g + fr] = ts;
+                    red[(wave * 2 + 1) * CV_C + 32 * pr + 8 * g + fr] = tq;
+                }
+            }
+        }
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
+                if constexpr (BSTATS) break;
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) { ssum[pr][k] += __shfl_xor(ssum[pr][k], o, 64); ssq[pr][k] += __shfl_xor(ssq[pr][k], o, 64); }
             }
-        if (fr == 0) {
+        if (fr == 0 && !BSTATS) {
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
@@ -643,6 +732,27 @@ int ap_conv3x3_c64_bn(const ap_bf16* x, const ap_bn_input* bn_in, const ap_bf16*
 #endif
     if (stats) hipLaunchKernelGGL((k_conv3x3_c64<true>), dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats);
     else hipLaunchKernelGGL((k_conv3x3_c64<false>), dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, x, w_packed, y, H, W, tiles_x, tiles_y, ntiles, stats);
+    return ap_check_launch();
+}
+
+int ap_conv3x3_c64_bwd_stats(const ap_bf16* dz, const ap_bf16* w_packed_bwd, ap_bf16* da, int B, int H, int W, const ap_bf16* z_below,
+                             const ap_bn_input* bn_below, float* stats, ap_stream_t stream) {
+    if (!dz || !w_packed_bwd || !da || !z_below || !bn_below || !stats) return AP_ERR_NULL;
+    if (!bn_below->mean || !bn_below->rstd || !bn_below->gamma || !bn_below->beta) return AP_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0) return AP_ERR_SHAPE;
+    const int tiles_x = (W + CV_TW - 1) / CV_TW, tiles_y = (H + CV_TR - 1) / CV_TR;
+    const int64_t nt64 = (int64_t)B * tiles_x * tiles_y;
+    if (nt64 > 0x7fffffff || (int64_t)H * W * CV_C > 0x7fffffff) return AP_ERR_SHAPE;
+    const int ntiles = (int)nt64;
+    static int attr_done = 0;
+    (void)hipGetLastError();
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_c64<false, 0, false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES + 1024) != hipSuccess) return AP_ERR_LAUNCH;
+        attr_done = 1;
+    }
+    const BnIn bn = {bn_below->mean, bn_below->rstd, bn_below->gamma, bn_below->beta};
+    hipLaunchKernelGGL((k_conv3x3_c64<false, 0, false, 8, true>), dim3(cv_grid(ntiles)), dim3(512), CV_LDS_BYTES + 1024, (hipStream_t)stream, dz, w_packed_bwd,
+                       da, H, W, tiles_x, tiles_y, ntiles, stats, bn, z_below);
     return ap_check_launch();
 }
 

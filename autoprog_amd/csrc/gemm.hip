@@ -443,7 +443,7 @@ struct TnGroup { TnArgs p[TN_MAX_GROUP]; int count; };
 #define TN_MAP_IDLE 0xFFFFu
 struct TnMap { unsigned short e[TN_MAP_MAX]; };
 
-template <bool BPATCH = false>
+template <bool BPATCH = false, bool BBN = false>
 __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
                                         int M, int N1, int N2, int steps_per_split, float* __restrict__ colsum, int t1, int t2, int nblocks, int block,
                                         bf16_t* sA, bf16_t* sB, const bf16_t* __restrict__ cs_weight = nullptr, float cs_scale = 1.0f,
@@ -535,19 +535,16 @@ __device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int lda, c
         const int r = srow + 16 * t;
         woff[t] = r * 128 + ((j ^ tn_swz(r)) << 3);
     }
-    // BPATCH with bbn: the B rows are relu(bn(.)) of the 64-channel map that is read; chunk j of a 128-column tile is channels 8 (j & 7) .. + 7
-    float tsc[BPATCH ? 8 : 1], tsh[BPATCH ? 8 : 1];
-    bool b_bn = false;
-    if constexpr (BPATCH) {
-        b_bn = bbn.mean != nullptr;
-        if (b_bn) bn_in_consts(bbn, (j & 7) * 8, tsc, tsh);
-    }
+    // BBN (a patch instantiation of its own: as a run-time branch its 16 registers doubled the time of EVERY patch launch, 67 -> 130 us):
+    // the B rows are relu(bn(.)) of the 64-channel map that is read; chunk j of a 128-column tile is channels 8 (j & 7) .. + 7
+    float tsc[BBN ? 8 : 1], tsh[BBN ? 8 : 1];
+    if constexpr (BBN) bn_in_consts(bbn, (j & 7) * 8, tsc, tsh);
     auto stage_and_compute = [&](u32x4* ra, u32x4* rb, u32x4* rw, int refill_step) {
         const u32x4 wcur[2] = {rw[0], rw[1]};          // this step's weights (the refill below overwrites the set)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             st16(sA + woff[i], ra[i]);
-            if constexpr (BPATCH) { if (b_bn) rb[i] = bn_in_apply(rb[i], tsc, tsh); }
+            if constexpr (BBN) rb[i] = bn_in_apply(rb[i], tsc, tsh);
             st16(sB + woff[i], rb[i]);
         }
         __syncthreads();
@@ -729,11 +726,12 @@ k_gemm_tn_8p(T8Group grp, T8Map map, TnLn ln) {
 }
 
 // one weight gradient whose B rows are patches of an NHWC feature map (PatchMap): a k x k / stride k convolution's dW
+template <bool BBN>
 __global__ void __launch_bounds__(256)
 k_gemm_tn_patch(TnArgs a, BnIn bbn) {
     __shared__ __attribute__((aligned(16))) bf16_t sA[TM * 128];
     __shared__ __attribute__((aligned(16))) bf16_t sB[TM * 128];
-    tn_tile<true>(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N1, a.N2, a.steps_per_split, a.colsum, a.t1, a.t2, a.nblocks,
+    tn_tile<true, BBN>(a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N1, a.N2, a.steps_per_split, a.colsum, a.t1, a.t2, a.nblocks,
                   (int)blockIdx.x, sA, sB, a.cs_weight, a.cs_scale, a.slab, a.splits, a.alpha, a.pb, bbn);
 }
 
@@ -1399,7 +1397,8 @@ static int tn_grouped_128(const ap_tn_problem* problems, int count, const ap_ln_
             if (problems[0].b_patch->kseg % 64 || problems[0].N2 % 64) return AP_ERR_SHAPE;         // 64-channel pixels, whole pixels per patch row
             bbn = BnIn{q->mean, q->rstd, q->gamma, q->beta};
         }
-        hipLaunchKernelGGL(k_gemm_tn_patch, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp.p[0], bbn);
+        if (problems[0].b_bn) hipLaunchKernelGGL(k_gemm_tn_patch<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp.p[0], bbn);
+        else hipLaunchKernelGGL(k_gemm_tn_patch<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp.p[0], bbn);
     } else {
         static int place = -1, cap = 0;
         if (place < 0) {

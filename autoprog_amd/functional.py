@@ -1202,19 +1202,26 @@ class PatchConvFn(torch.autograd.Function):
         g = g.contiguous()
         params = (weight, bias) if bn is None else (weight, bias, bn_gamma, bn_beta)
         bufs, sunk = _param_grad_buffers(params)
-        dwmat = torch.zeros((N, K), dtype=torch.float32, device=g.device)
-        _launch_wgrads([(g, xc, dwmat, N, K, bufs[1], None, 1.0, 1.0, ops.patch_map(H, W, C, k), bn)])
-        join_wgrad_stream()
-        bufs[0].add_(dwmat.view(N, k, k, C).permute(0, 3, 1, 2))                              # back to OIHW
         dx = None
+        b_rows, b_bn = xc, bn             # the weight gradient's B rows: the map the forward read (+ its transform)
         if ctx.needs_input_grad[0]:
             wt = torch.zeros((K, ld), dtype=BF16, device=g.device) if ld != N else torch.empty((K, N), dtype=BF16, device=g.device)
             wt[:, :N] = wmat.t()
             dx = ops.gemm_nt_patch_dgrad(g, wt, (B, H, W, C), k)
             if bn is not None:            # dL/d(relu(bn(z))) -> dL/dz and the BatchNorm's parameter gradients
-                dx = ops.bn_relu_bwd(dx, xc, bn_gamma, bn_beta, bn_mean, bn_rstd, bufs[2], bufs[3])
+                if BN_PROJ_ACT_IN_BWD:
+                    # ... and relu(bn(z)) itself, written by the dx pass (it holds z anyway) for the weight gradient below: transforming every
+                    # chunk that launch stages -- twice, there are two row tiles -- doubled its time (70 -> 141 us at B = 128, 224 px)
+                    dx, b_rows = ops.bn_relu_bwd(dx, xc, bn_gamma, bn_beta, bn_mean, bn_rstd, bufs[2], bufs[3], act_out=True)
+                    b_bn = None
+                else:
+                    dx = ops.bn_relu_bwd(dx, xc, bn_gamma, bn_beta, bn_mean, bn_rstd, bufs[2], bufs[3])
         elif bn is not None:
             raise AutoProgHipError("PatchConvFn with a BatchNorm input: the BatchNorm's parameter gradients need the input gradient")
+        dwmat = torch.zeros((N, K), dtype=torch.float32, device=g.device)
+        _launch_wgrads([(g, b_rows, dwmat, N, K, bufs[1], None, 1.0, 1.0, ops.patch_map(H, W, C, k), b_bn)])
+        join_wgrad_stream()
+        bufs[0].add_(dwmat.view(N, k, k, C).permute(0, 3, 1, 2))                              # back to OIHW
         gr = _finish_param_grads(params, bufs, sunk)
         return (dx, gr[0], gr[1], None, None, None) + ((gr[2], gr[3]) if bn is not None else (None, None))
 
@@ -1342,12 +1349,20 @@ class Stem64Fn(torch.autograd.Function):
         else:                              # dy IS dL/dz3: the consumer ran the last BatchNorm's backward (PatchConvFn with bn_*)
             dw7, dg1, db1, dw2, dg2, db2, dw3 = bufs
             dz3 = dy.contiguous()
-        da2 = ops.conv3x3_c64(dz3, wb3)
-        ops.conv3x3_c64_wgrad(z2, dz3, dw3, bn_in=(mean2, rstd2, g2, b2))
-        dz2 = ops.bn_relu_bwd(da2, z2, g2, b2, mean2, rstd2, dg2, db2)
-        da1 = ops.conv3x3_c64(dz2, wb2)
-        ops.conv3x3_c64_wgrad(z1, dz2, dw2, bn_in=(mean1, rstd1, g1, b1))
-        dz1 = ops.bn_relu_bwd(da1, z1, g1, b1, mean1, rstd1, dg1, db1)
+        if STEM_FUSE_BN_BWD_STATS:         # the first pass of each BatchNorm's backward rides in the convolution that produces its dy
+            da2, part2 = ops.conv3x3_c64_bwd_stats(dz3, wb3, z2, (mean2, rstd2, g2, b2))
+            ops.conv3x3_c64_wgrad(z2, dz3, dw3, bn_in=(mean2, rstd2, g2, b2))
+            dz2 = ops.bn_relu_bwd_partials(da2, z2, g2, b2, mean2, rstd2, part2, dg2, db2)
+            da1, part1 = ops.conv3x3_c64_bwd_stats(dz2, wb2, z1, (mean1, rstd1, g1, b1))
+            ops.conv3x3_c64_wgrad(z1, dz2, dw2, bn_in=(mean1, rstd1, g1, b1))
+            dz1 = ops.bn_relu_bwd_partials(da1, z1, g1, b1, mean1, rstd1, part1, dg1, db1)
+        else:
+            da2 = ops.conv3x3_c64(dz3, wb3)
+            ops.conv3x3_c64_wgrad(z2, dz3, dw3, bn_in=(mean2, rstd2, g2, b2))
+            dz2 = ops.bn_relu_bwd(da2, z2, g2, b2, mean2, rstd2, dg2, db2)
+            da1 = ops.conv3x3_c64(dz2, wb2)
+            ops.conv3x3_c64_wgrad(z1, dz2, dw2, bn_in=(mean1, rstd1, g1, b1))
+            dz1 = ops.bn_relu_bwd(da1, z1, g1, b1, mean1, rstd1, dg1, db1)
         ops.conv7_s2d_wgrad(xs, dz1, dw7)
         gr = list(_finish_param_grads(params, bufs, sunk))
         if not last:
@@ -1356,6 +1371,8 @@ class Stem64Fn(torch.autograd.Function):
 
 
 STEM_FUSE_BN = os.environ.get("AP_STEM_FUSE_BN", "1") != "0"
+STEM_FUSE_BN_BWD_STATS = os.environ.get("AP_STEM_FUSE_BN_BWD_STATS", "1") != "0"     # BatchNorm-backward sums in the input-gradient convolutions' epilogue
+BN_PROJ_ACT_IN_BWD = os.environ.get("AP_BN_PROJ_ACT_IN_BWD", "1") != "0"     # 0: PatchEmbed.proj's weight gradient applies relu(bn(.)) to the chunks it stages
 STEM_FUSE_BN_PROJ = os.environ.get("AP_STEM_FUSE_BN_PROJ", "1") != "0"     # the LAST BatchNorm + ReLU of the stem inside PatchEmbed.proj's patch GEMMs
 
 

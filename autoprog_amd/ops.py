@@ -654,15 +654,36 @@ def bn_relu_fwd(x, gamma, beta, running_mean, running_var, training, momentum, e
     return y, mean, rstd
 
 
-def bn_relu_bwd(dy, x, gamma, beta, mean, rstd, dgamma, dbeta):
+def bn_relu_bwd(dy, x, gamma, beta, mean, rstd, dgamma, dbeta, act_out=False):
+    """act_out: -> (dx, relu(bn(x))) -- the activation a fused forward never stored, written by the pass that holds x anyway"""
     _req(dy, BF16, "dy"); _req(x, BF16, "x")
     C = x.shape[-1]
     T = x.numel() // C
     dx = torch.empty_like(x)
     ws_bytes = lib.ap_bn_relu_workspace(T, C)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    if act_out:
+        act = torch.empty_like(x)
+        check(lib.ap_bn_relu_bwd_act(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                     dx.data_ptr(), act.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), T, C, ws.data_ptr(), ws_bytes, _stream()),
+              "ap_bn_relu_bwd_act")
+        return dx, act
     check(lib.ap_bn_relu_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                              dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), T, C, ws.data_ptr(), ws_bytes, _stream()), "ap_bn_relu_bwd")
+    return dx
+
+
+def bn_relu_bwd_partials(dy, x, gamma, beta, mean, rstd, partial, dgamma, dbeta):
+    """bn_relu_bwd whose first pass ran inside the convolution that produced dy (conv3x3_c64_bwd_stats): finalize + dx only"""
+    _req(dy, BF16, "dy"); _req(x, BF16, "x"); _req(partial, torch.float32, "partial")
+    C = x.shape[-1]
+    T = x.numel() // C
+    dx = torch.empty_like(x)
+    ws_bytes = lib.ap_bn_relu_workspace(T, C)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    check(lib.ap_bn_relu_bwd_partials(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                      partial.data_ptr(), partial.shape[0], dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), T, C,
+                                      ws.data_ptr(), ws_bytes, _stream()), "ap_bn_relu_bwd_partials")
     return dx
 
 
@@ -721,6 +742,21 @@ def conv3x3_c64(x, w_packed, want_stats=False, bn_in=None):
         check(lib.ap_conv3x3_c64(x.data_ptr(), w_packed.data_ptr(), y.data_ptr(), B, H, W,
                                  stats.data_ptr() if want_stats else None, _stream()), "ap_conv3x3_c64")
     return (y, stats) if want_stats else y
+
+
+def conv3x3_c64_bwd_stats(dz, w_packed_bwd, z_below, bn_below):
+    """the input-gradient convolution of a 64-wide stem layer, with the first pass of the BatchNorm + ReLU backward of the layer BELOW in
+    its epilogue: -> (da, partial [rows,2,64]) for bn_relu_bwd_partials(da, z_below, ..., partial, ...).  bn_below = (mean, rstd, gamma, beta)"""
+    _req(dz, BF16, "dz"); _req(w_packed_bwd, BF16, "w_packed_bwd"); _req(z_below, BF16, "z_below")
+    B, H, W, C = dz.shape
+    if C != 64 or tuple(z_below.shape) != tuple(dz.shape):
+        raise AutoProgHipError("conv3x3_c64_bwd_stats: [B,H,W,64] maps of one shape (got %s, %s)" % (tuple(dz.shape), tuple(z_below.shape)))
+    da = torch.empty_like(dz)
+    stats = torch.empty((lib.ap_conv3x3_c64_stat_rows(B, H, W), 2, 64), dtype=torch.float32, device=dz.device)
+    b = _bn_input(bn_below)
+    check(lib.ap_conv3x3_c64_bwd_stats(dz.data_ptr(), w_packed_bwd.data_ptr(), da.data_ptr(), B, H, W, z_below.data_ptr(), ctypes.byref(b),
+                                       stats.data_ptr(), _stream()), "ap_conv3x3_c64_bwd_stats")
+    return da, stats
 
 
 def conv3x3_c64_wgrad(x, dy, dw, bn_in=None):

@@ -306,6 +306,20 @@ int ap_bn_relu_bwd(const ap_bf16* dy, const ap_bf16* x, const float* gamma, cons
                    const float* rstd, ap_bf16* dx, float* dgamma, float* dbeta, int64_t T, int C,
                    void* workspace, size_t ws_bytes, ap_stream_t stream);
 
+/* (ABI version 6) ap_bn_relu_bwd that also writes act = relu(bn(x)) ([T, C] bf16, the arithmetic of ap_bn_relu_fwd): for a forward that
+ * applied the BatchNorm inside its consumer (ap_gemm_nt_patch_bn) and never stored the activation -- the weight gradient of that
+ * consumer then reads a plain tensor */
+int ap_bn_relu_bwd_act(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* beta, const float* mean,
+                       const float* rstd, ap_bf16* dx, ap_bf16* act, float* dgamma, float* dbeta, int64_t T, int C,
+                       void* workspace, size_t ws_bytes, ap_stream_t stream);
+/* (ABI version 6) ap_bn_relu_bwd whose first pass has already happened: `partial` holds n_partial rows [2][C] of per-channel partial sums
+ * (sum dz | sum dz * xhat, dz = dy where the ReLU passed) -- written by ap_conv3x3_c64_bwd_stats, the input-gradient convolution that
+ * produced dy -- so only the finalize (dgamma / dbeta +=) and the dx pass run.  Replaces the backward of nn.BatchNorm2d + nn.ReLU at
+ * reference models/volo.py:356-366 (autograd), one pass over dy and x shorter. */
+int ap_bn_relu_bwd_partials(const ap_bf16* dy, const ap_bf16* x, const float* gamma, const float* beta, const float* mean,
+                            const float* rstd, const float* partial, int n_partial, ap_bf16* dx, float* dgamma, float* dbeta,
+                            int64_t T, int C, void* workspace, size_t ws_bytes, ap_stream_t stream);
+
 /* ---- stem 3x3 convolutions in HIP (reference models/volo.py:355-367: the two
  * nn.Conv2d(hidden, hidden, 3, 1, 1, bias=False) of PatchEmbed at hidden = 64).  NHWC bf16 feature maps. */
 /* fp32 OIHW [64][64][3][3] -> the two bf16 operand layouts of ap_conv3x3_c64: w_fwd [tap][co][ci] and
@@ -331,6 +345,13 @@ int ap_conv3x3_c64_wgrad(const ap_bf16* x, const ap_bf16* dy, float* dw_oihw, in
 /* the same for a layer whose input was relu(bn(x)) of ap_conv3x3_c64_bn: x is the pre-BatchNorm tensor */
 int ap_conv3x3_c64_wgrad_bn(const ap_bf16* x, const ap_bn_input* bn_in, const ap_bf16* dy, float* dw_oihw, int B, int H, int W, void* workspace,
                             size_t ws_bytes, ap_stream_t stream);
+
+/* (ABI version 6) the INPUT-GRADIENT convolution of a stem layer (dz on w_bwd of ap_conv3x3_c64_pack -> da, as ap_conv3x3_c64) whose
+ * epilogue also runs the first pass of the backward of the BatchNorm + ReLU BELOW the layer (a = relu(bn(z_below)), reference
+ * models/volo.py:356-366): stats = float[ap_conv3x3_c64_stat_rows(B,H,W)][2][64], per-workgroup partial sums (sum dzb | sum dzb * xhat,
+ * dzb = the bf16-rounded da where bn(z_below) > 0), the `partial` argument of ap_bn_relu_bwd_partials */
+int ap_conv3x3_c64_bwd_stats(const ap_bf16* dz, const ap_bf16* w_packed_bwd, ap_bf16* da, int B, int H, int W, const ap_bf16* z_below,
+                             const ap_bn_input* bn_below, float* stats, ap_stream_t stream);
 
 /* ---- first stem convolution in HIP: 7x7 / stride 2 / pad 3, 3 -> 64, no bias (models/volo.py:355-357) on the space-to-depth input
  * xs[B, H, W, 16] (bf16; H, W = half the image size; channel (sy*2+sx)*3+c = pixel (2Y+sy, 2X+sx) channel c, 12..15 zero) */

@@ -434,8 +434,9 @@ def test_stem64_fused_batchnorm_input_is_bit_identical_to_the_chain(monkeypatch)
     torch.manual_seed(3)
     x = torch.randn(3, 3, 80, 80, device="cuda")
     res = {}
-    for fuse in (False, True):
-        monkeypatch.setattr(AF, "STEM_FUSE_BN", fuse)
+    for fuse in (False, True, "stats"):
+        monkeypatch.setattr(AF, "STEM_FUSE_BN", bool(fuse))
+        monkeypatch.setattr(AF, "STEM_FUSE_BN_BWD_STATS", fuse == "stats")     # (round 5) the BatchNorm-backward sums in the input-gradient convolutions
         torch.manual_seed(11)
         pe = PatchEmbed(stem_conv=True, stem_stride=2, patch_size=8, in_chans=3, hidden_dim=64, embed_dim=192).cuda().train()
         y = pe(x)
@@ -452,6 +453,12 @@ def test_stem64_fused_batchnorm_input_is_bit_identical_to_the_chain(monkeypatch)
     for k in res[True]:
         assert torch.equal(res[True][k], res[False][k]), k
     assert float(res[True]["g.conv.3.weight"].abs().max()) > 0 and float(res[True]["b.conv.4.running_mean"].abs().max()) > 0
+    # with the sums formed in the convolution epilogue: the forward is the same code; the gradients differ by the order of an fp32 summation
+    for k in res[True]:
+        if k.startswith("g."):
+            assert float((res["stats"][k] - res[True][k]).norm() / res[True][k].norm()) < 2e-3, k      # (bf16 dz maps downstream of 1e-7 differences)
+        else:
+            assert torch.equal(res["stats"][k], res[True][k]), k
     # kernel level
     g = torch.Generator(device="cuda").manual_seed(5)
     z = torch.randn(2, 37, 21, 64, device="cuda", generator=g).to(torch.bfloat16)

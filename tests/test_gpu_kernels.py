@@ -451,7 +451,9 @@ def test_avgpool(ops, B, H, W, C):
                                           (1, 256, 2, 32), (5, 36, 1, 32), (2, 197, 3, 64), (2, 64, 2, 64), (1, 256, 1, 64), (3, 50, 6, 64),
                                           # key/query-blocked kernels (mhsa_flash.hip): head_dim 48 of VOLO-D4/D5, N > 256 (448 px -> 784 tokens)
                                           (2, 784, 16, 48), (1, 196, 16, 48), (2, 50, 3, 48), (1, 784, 2, 32), (1, 400, 3, 64), (2, 257, 1, 32),
-                                          (1, 130, 2, 48), (3, 64, 1, 48), (1, 1025, 1, 48)])
+                                          (1, 130, 2, 48), (3, 64, 1, 48), (1, 1025, 1, 48),
+                                          # 276 / 270 items on 256 persistent workgroups (some take two); a full and a one-key last tile
+                                          (23, 196, 12, 32), (2, 208, 2, 32), (1, 193, 1, 32), (45, 144, 6, 32)])
 def test_mhsa(ops, B, N, heads, hd):
     C = heads * hd
     qkv = rnd(B * N, 3 * C, seed=1)
@@ -643,6 +645,20 @@ def test_bn_relu_fused(ops, B, H, W, C):
     bn.eval()
     ye = AF.BNReLUFn.apply(dev(x), dev(g), dev(b), rm, rv, False, 0.1, 1e-5)
     assert rel(ye, torch.relu(bn(x.double().permute(0, 3, 1, 2))).permute(0, 2, 3, 1)) < TOL_BF16
+    # (round 5) ap_bn_relu_bwd_act: the same dx / dgamma / dbeta bits, and the activation of the forward pass next to them
+    mean = dev(x).float().mean((0, 1, 2))
+    rstd = (dev(x).float().var((0, 1, 2), unbiased=False) + 1e-5).rsqrt()
+    gd, bd = dev(g).float(), dev(b).float()
+    dg0, db0, dg1, db1 = (torch.zeros(C, device="cuda") for _ in range(4))
+    dx0 = ops.bn_relu_bwd(dev(dy), dev(x), gd, bd, mean, rstd, dg0, db0)
+    dx1, act = ops.bn_relu_bwd(dev(dy), dev(x), gd, bd, mean, rstd, dg1, db1, act_out=True)
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    rme, rve = mean.clone(), (1.0 / rstd ** 2 - 1e-5)
+    ya, _, _ = ops.bn_relu_fwd(dev(x), gd, bd, rme, rve, False, 0.1, 1e-5)                 # eval mode: mean / rstd as given
+    assert float((act.float() - ya.float()).abs().max()) <= 2 ** -7 * float(ya.float().abs().max())    # (rstd through 1 / sqrt(var + eps): <= 1 bf16 step)
+    sc = rstd * gd
+    ref = torch.clamp_min(torch.addcmul(bd - mean * sc, dev(x).float(), sc), 0).to(torch.bfloat16)     # the association of k_bn_relu_apply (fma contraction aside)
+    assert (act != ref).float().mean() < 2e-3 and float((act.float() - ref.float()).abs().max()) <= 2 ** -7 * float(ref.float().abs().max())
 
 
 def test_grouped_wgrad_launch_carries_the_layernorm_reductions(ops):
@@ -682,7 +698,7 @@ def test_grouped_wgrad_launch_carries_the_layernorm_reductions(ops):
 
 @pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_MHSA_BWD_DS": "0", "AP_MHSA_FWD_P": "0"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"}, {"AP_OUTLOOK_MFMA": "0"},
                                  {"AP_STEM_HIP_CONV": "0"}, {"AP_ASYNC_WGRAD": "1"}, {"AP_GEMM_TN_PLACE": "0"}, {"AP_FUSE_LN_REDUCE": "0"}, {"AP_CONV_WGRAD_P": "0"},
-                                 {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}, {"AP_GELU_STORE_GRAD": "0"}, {"AP_GELU_STORE_GRAD": "1"}, {"AP_LN_BWD_PF": "0"}, {"AP_GEMM_BM224": "0"}, {"AP_GELU_TABLE": "0"}, {"AP_FUSE_POOL_BWD": "0"}, {"AP_STEM_FUSE_BN_PROJ": "0"}, {"AP_WGRAD_WINDOW": "0"}, {"AP_STEM_FUSE_BN": "0"},
+                                 {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}, {"AP_GELU_STORE_GRAD": "0"}, {"AP_GELU_STORE_GRAD": "1"}, {"AP_LN_BWD_PF": "0"}, {"AP_GEMM_BM224": "0"}, {"AP_GELU_TABLE": "0"}, {"AP_FUSE_POOL_BWD": "0"}, {"AP_STEM_FUSE_BN_PROJ": "0"}, {"AP_STEM_FUSE_BN_BWD_STATS": "0"}, {"AP_BN_PROJ_ACT_IN_BWD": "0"}, {"AP_WGRAD_WINDOW": "0"}, {"AP_STEM_FUSE_BN": "0"},
                                  {"AP_OUTLOOK_P": "0"}, {"AP_OUTLOOK_P": "2"}, {"AP_LN_FWD_LP": "0"}, {"AP_CONV_WAVES": "4"}])
 def test_experimental_kernel_paths_stay_parity_green(env):
     """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:
@@ -811,6 +827,37 @@ def test_conv3x3_c64_fwd_dgrad_wgrad_vs_torch_fp32(B, H, W):
     dw2 = torch.full((64, 64, 3, 3), 0.5, device="cuda")
     ops.conv3x3_c64_wgrad(x, dy, dw2)
     assert torch.equal(dw, dw2)                                           # ordered slab reduction: bit-reproducible
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 20, 37), (3, 33, 16), (1, 7, 5), (8, 112, 112)])
+def test_conv3x3_c64_input_gradient_with_the_batchnorm_backward_sums(B, H, W):
+    """ap_conv3x3_c64_bwd_stats: the input-gradient convolution whose epilogue runs the first pass of the BatchNorm + ReLU backward of the
+    layer below (models/volo.py:356-366; round 5).  The map it writes is bit-identical to the plain input-gradient launch; its partial
+    rows, summed, are the sums k_bn_relu_bwd_reduce forms from that map and z_below (fp64 check 1e-5: fp32 partial sums in another order);
+    and ap_bn_relu_bwd_partials on them gives the dx / dgamma / dbeta of ap_bn_relu_bwd (dx: bf16, equal up to the last place where the
+    1e-7 difference of the sums crosses a rounding boundary)."""
+    from autoprog_amd import ops
+    torch.manual_seed(B * 100 + W)
+    dz = torch.randn(B, H, W, 64, device="cuda").to(torch.bfloat16)
+    zb = (torch.randn(B, H, W, 64, device="cuda") * 1.5 + 0.3).to(torch.bfloat16)
+    w = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
+    gamma, beta = torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.3
+    mean = zb.float().mean((0, 1, 2))
+    rstd = (zb.float().var((0, 1, 2), unbiased=False) + 1e-5).rsqrt()
+    _, wb = ops.conv3x3_pack(w)
+    da, part = ops.conv3x3_c64_bwd_stats(dz, wb, zb, (mean, rstd, gamma, beta))
+    assert torch.equal(da, ops.conv3x3_c64(dz, wb))
+    xh = (zb.double() - mean.double()) * rstd.double()
+    m = ((zb.float() - mean) * rstd * gamma + beta > 0).double()          # the kernels' mask, in their arithmetic
+    dzm = da.double() * m
+    sums = part.double().sum(0)
+    assert rel(sums[0], dzm.sum((0, 1, 2))) < 1e-5 and rel(sums[1], (dzm * xh).sum((0, 1, 2))) < 1e-5
+    dg0, db0 = torch.full((64,), 0.25, device="cuda"), torch.full((64,), -0.5, device="cuda")
+    dg1, db1 = dg0.clone(), db0.clone()
+    dx0 = ops.bn_relu_bwd(da, zb, gamma, beta, mean, rstd, dg0, db0)
+    dx1 = ops.bn_relu_bwd_partials(da, zb, gamma, beta, mean, rstd, part, dg1, db1)
+    assert rel(dg1 - 0.25, dg0 - 0.25) < 1e-5 and rel(db1 + 0.5, db0 + 0.5) < 1e-5
+    assert rel(dx1, dx0) < 1e-4 and (dx1 != dx0).float().mean() < 1e-3
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 20, 37), (3, 33, 16), (1, 7, 5), (2, 64, 48), (5, 56, 56)])
