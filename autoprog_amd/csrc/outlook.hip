@@ -93,6 +93,8 @@ __device__ __forceinline__ void stage_probs(float* P, const bf16_t* logits, int 
 
 // chunk stride (in pixels) of the CHUNK-major patch image, padded so the four chunks of a pixel start 16 banks apart
 __device__ __host__ __forceinline__ int pad_npix(int npix) { return npix + ((4 - (npix & 15)) & 15); }
+// row stride (pixels) of the persistent kernels' LDS patch: the smallest value >= pw that is 3 (mod 4) -- see k_outlook_p
+__device__ __host__ __forceinline__ int olk_pws(int pw) { return pw + ((3 - pw) & 3); }
 
 #define OGT 256         // threads per workgroup of the two kernels below
 // One lane per (output pixel, 8-channel chunk): 16x the lanes of the former one-lane-per-quad mapping (which left
@@ -246,6 +248,9 @@ k_outlook_dlogits(const bf16_t* __restrict__ v, const bf16_t* __restrict__ dy, c
 // window reads P before it writes Z.  TP = true folds dY with the transposed probabilities (dV).
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 #define OPZ 288                  // bf16 elements of a window's P / Z slot (9 x 32)
+#define OPR 24                   // k_outlook_p: stride (bf16 elements) of the 16-element P rows inside a slot.  48 bytes: consecutive rows start 12 banks
+                                 // apart, so the 16 rows a 16-byte store (or the 9 an 8-byte operand read) touches per cycle are disjoint; at 32 bytes
+                                 // rows r and r + 8 shared their banks.  9 (+ 1 zero) rows x 48 bytes fit the 576-byte slot.
 template <bool TP>
 __global__ void __launch_bounds__(OGT)
 k_outlook_gather_mfma(const bf16_t* __restrict__ in, const bf16_t* __restrict__ logits, int ldl, bf16_t* __restrict__ out,
@@ -444,9 +449,14 @@ k_outlook_p(OlkArgs a) {
     const int H = a.H, W = a.W, heads = a.heads, SR = a.SR, ldl = a.ldl;
     const int h = (H + 1) >> 1, w = (W + 1) >> 1, C = heads * OHD, pw = 2 * w + 1;
     const int PH = 2 * SR + 3, npix = PH * pw, NWR = SR + 1;
-    const int npixc = pad_npix(npix);
-    bf16_t* const pm = reinterpret_cast<bf16_t*>(smem_raw);           // pixel-major patch [npix][32]: V (forward) / dY (backward): the MFMA operand
-    bf16_t* const pvc = pm + (size_t)npix * OHD;                        // BWD: chunk-major V patch [4][npixc][8] (16-byte reads of neighbouring pixels)
+    // LDS row stride of the patch, in pixels: = 3 (mod 4).  A pixel row of one head is 64 bytes = 16 banks, so the bank group of pixel
+    // (r, c) is (r * pws + c) mod 4 -- with pws = pw = 2 w + 1 = 29 the pixels (r, c + 1) and (r + 1, c) of a 3 x 3 window met in one
+    // group (two- and three-way conflicts in every transposed operand read: 30 % of the forward's time in the r04 counters); with
+    // pws = 3 (mod 4) the nine pixels of a window fall in groups 0 1 2 | 3 0 1 | 2 3 0: the four a 16-lane read touches are distinct
+    const int pws = olk_pws(pw), dpw = pws - pw, npixl = PH * pws;
+    const int npixc = pad_npix(npixl);
+    bf16_t* const pm = reinterpret_cast<bf16_t*>(smem_raw);           // pixel-major patch [PH][pws][32]: V (forward) / dY (backward): the MFMA operand
+    bf16_t* const pvc = pm + (size_t)npixl * OHD;                       // BWD: chunk-major V patch [4][npixc][8] (16-byte reads of neighbouring pixels)
     bf16_t* const PZ = BWD ? pvc + (size_t)npixc * OHD : pvc;           // [NWR * w][9][32]: P rows (16 used per row, + a zero row), then Z
     bf16_t* const dA = PZ + (size_t)NWR * w * OPZ;                      // BWD: [SR * w][81] bf16
     const int tid = threadIdx.x, lane = tid & 63;
@@ -473,7 +483,7 @@ k_outlook_p(OlkArgs a) {
         const int wi = wl / w, wj = wl - wi * w;
         r_wl[u] = wl; r_p[u] = p;
         r_loff[u] = wl * ldl + p * OKK;
-        r_pix[u] = (2 * wi) * pw + 2 * wj;
+        r_pix[u] = (2 * wi) * pws + 2 * wj;
     }
 
     // ---- item walk: workgroups of one XCD (blockIdx % 8) take neighbouring items in every round, so the heads of an (image, strip)
@@ -523,8 +533,9 @@ k_outlook_p(OlkArgs a) {
         for (int u = 0; u < NSU; ++u) {
             const int idx = tid + u * T;
             if (s_pr[u] >= 0 && !(OLK_ABL & 64)) {
-                st16(pm + (size_t)idx * 8, fm[u]);
-                if constexpr (BWD) st16(pvc + ((size_t)(idx & 3) * npixc + (idx >> 2)) * 8, fv[u]);
+                const int lpix = (idx >> 2) + s_pr[u] * dpw;           // pixel index with the padded row stride
+                st16(pm + (size_t)(lpix * 4 + (idx & 3)) * 8, fm[u]);
+                if constexpr (BWD) st16(pvc + ((size_t)(idx & 3) * npixc + lpix) * 8, fv[u]);
             }
         }
         float prow[NPU][OKK];
@@ -559,42 +570,72 @@ k_outlook_p(OlkArgs a) {
             for (int q = 0; q < OKK; ++q) prow[u][q] = o8[q];
             if (r < nwin * OKK) {
                 bf16_t* slot = PZ + (size_t)r_wl[u] * OPZ;
-                st16(slot + p * 16, pack8(o8));
-                st16(slot + p * 16 + 8, pack8(o8 + 8));
-                if (BWD && p == 0) { st16(slot + 144, zero4); st16(slot + 152, zero4); }      // the zero row of the transposed read
+                st16(slot + p * OPR, pack8(o8));
+                st16(slot + p * OPR + 8, pack8(o8 + 8));
+                if (BWD && p == 0) { st16(slot + 9 * OPR, zero4); st16(slot + 9 * OPR + 8, zero4); }      // the zero row of the transposed read
             }
         }
         const int next = item + G;
         if (next < a.nitems && !(OLK_ABL & 8)) request(next);
         OLK_BAR();
-        // ---- (B) Z_w = P_w (or its transpose) x pixels of the window, on the matrix pipe; wave-uniform window walk
+        // ---- (B) Z_w = P_w (or its transpose) x pixels of the window, on the matrix pipe; wave-uniform window walk, TWO windows per trip:
+        // a window is one dependent chain (LDS reads -> MFMA pair -> pack -> LDS write, ~250 clocks) and a wave has 7 of them per item --
+        // with the chains of two windows interleaved the reads of one run under the MFMAs and packs of the other
         {
             const int fr = lane & 15, g = lane >> 4, q4 = fr >> 2, p4 = fr & 3;
+            constexpr int NWV = T / 64;
+            const int kq = min(4 * g + q4, OKK - 1);
+            const int kr = (kq * 11) >> 5;                            // kq / 3 for kq < 9
+            // this lane's source pixel of the window, relative to the window's first; channel offset 8 p4 (+ 4 t): row 4 g + r of MFMA t is then
+            // channel 8 g + 4 t + r, so a lane's two results are 8 CONSECUTIVE channels of its P row -- one 16-byte LDS write instead of two
+            // 8-byte ones whose rows 0 / 4 / 8 met in the same banks (r04 counters: two thirds of the LDS pipe's cycles were conflicts)
+            const int koff = (kr * pws + (kq - 3 * kr)) * OHD + p4 * 8;
+            const int poff = BWD ? min(4 * g + q4, OKK) * OPR + p4 * 4 : min(fr, OKK - 1) * OPR + g * 4;
             int wi = 0, wj = wave;
             while (wj >= w) { wj -= w; ++wi; }
-            for (int wl = wave; wl < ((OLK_ABL & 1) ? 0 : nwin); wl += T / 64) {
-                bf16_t* slot = PZ + (size_t)wl * OPZ;
-                s16x4_t pfrag;
-                if constexpr (BWD) pfrag = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(slot + min(4 * g + q4, OKK) * 16 + p4 * 4));
-                else pfrag = *reinterpret_cast<const s16x4_t*>(slot + min(fr, OKK - 1) * 16 + g * 4);
-                const int kq = min(4 * g + q4, OKK - 1);
-                const int kr = (kq * 11) >> 5;                            // kq / 3 for kq < 9
-                const bf16_t* vpix = pm + ((2 * wi + kr) * pw + 2 * wj + (kq - 3 * kr)) * OHD + p4 * 4;
-                f32x4 z[2];
+            const int nwin_e = (OLK_ABL & 1) ? 0 : nwin;
+            for (int wl = wave; wl < nwin_e; wl += 2 * NWV) {
+                int wi2 = wi, wj2 = wj + NWV;
+                while (wj2 >= w) { wj2 -= w; ++wi2; }
+                const bool two = wl + NWV < nwin_e;                   // wave-uniform
+                bf16_t* slot0 = PZ + (size_t)wl * OPZ;
+                bf16_t* slot1 = PZ + (size_t)(two ? wl + NWV : wl) * OPZ;
+                const bf16_t* vp0 = pm + ((2 * wi) * pws + 2 * wj) * OHD + koff;
+                const bf16_t* vp1 = pm + ((2 * (two ? wi2 : wi)) * pws + 2 * (two ? wj2 : wj)) * OHD + koff;
+                s16x4_t pf0, pf1;
+                if constexpr (BWD) {
+                    pf0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(slot0 + poff));
+                    pf1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(slot1 + poff));
+                } else {
+                    pf0 = *reinterpret_cast<const s16x4_t*>(slot0 + poff);
+                    pf1 = *reinterpret_cast<const s16x4_t*>(slot1 + poff);
+                }
+                s16x4_t vf0[2], vf1[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const s16x4_t vfrag = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(vpix + t * 16));
-                    z[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vfrag, pfrag, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    vf0[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(vp0 + t * 4));
+                    vf1[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(vp1 + t * 4));
+                }
+                f32x4 z0[2], z1[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    z0[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf0[t], pf0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    z1[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf1[t], pf1, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 }
                 if (fr < OKK) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        u32x2 pk;
-                        pk[0] = pack_bf2(z[t][0], z[t][1]); pk[1] = pack_bf2(z[t][2], z[t][3]);
-                        *reinterpret_cast<u32x2*>(slot + fr * OHD + 16 * t + 4 * g) = pk;
+                    // Z row fr, channels 8 g .. 8 g + 7, at chunk g ^ (fr >> 2): the rows 0, 4, 8 (64 bytes each: the same 16 banks) take different chunks
+                    const int zoff = fr * OHD + ((g ^ (fr >> 2)) << 3);
+                    u32x4 pk;
+                    pk[0] = pack_bf2(z0[0][0], z0[0][1]); pk[1] = pack_bf2(z0[0][2], z0[0][3]);
+                    pk[2] = pack_bf2(z0[1][0], z0[1][1]); pk[3] = pack_bf2(z0[1][2], z0[1][3]);
+                    st16(slot0 + zoff, pk);
+                    if (two) {
+                        pk[0] = pack_bf2(z1[0][0], z1[0][1]); pk[1] = pack_bf2(z1[0][2], z1[0][3]);
+                        pk[2] = pack_bf2(z1[1][0], z1[1][1]); pk[3] = pack_bf2(z1[1][2], z1[1][3]);
+                        st16(slot1 + zoff, pk);
                     }
                 }
-                wj += T / 64;
+                wi = wi2; wj = wj2 + NWV;
                 while (wj >= w) { wj -= w; ++wi; }
             }
         }
@@ -607,14 +648,14 @@ k_outlook_p(OlkArgs a) {
                     const int p = r_p[u];
                     const int pr3 = (p * 11) >> 5, pc3 = p - 3 * pr3;
                     u32x4 gch[4];
-                    const bf16_t* gp = pm + (size_t)(r_pix[u] + pr3 * pw + pc3) * OHD;
+                    const bf16_t* gp = pm + (size_t)(r_pix[u] + pr3 * pws + pc3) * OHD;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) gch[c] = ld16(gp + c * 8);
                     float dP[OKK];
                     float dot = 0.f;
 #pragma unroll
                     for (int q = 0; q < OKK; ++q) {
-                        const bf16_t* vp = pvc + (size_t)(r_pix[u] + (q / 3) * pw + (q % 3)) * 8;
+                        const bf16_t* vp = pvc + (size_t)(r_pix[u] + (q / 3) * pws + (q % 3)) * 8;
                         float sacc = 0.f;
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
@@ -649,7 +690,7 @@ k_outlook_p(OlkArgs a) {
                 for (int k = 0; k < 8; ++k) acc[k] = 0.f;
                 auto add = [&](int wi, int wj, int slot9) {
                     float f[8];
-                    unpack8(ld16(PZ + ((size_t)(wi * w + wj)) * OPZ + slot9 * OHD + c * 8), f);
+                    unpack8(ld16(PZ + ((size_t)(wi * w + wj)) * OPZ + slot9 * OHD + ((c ^ (slot9 >> 2)) << 3)), f);      // (chunk swizzle of the Z rows: phase B)
 #pragma unroll
                     for (int k = 0; k < 8; ++k) acc[k] += f[k];
                 };
@@ -695,8 +736,9 @@ static int olk_pick(int H, int W, bool bwd, int T, int NSU, int NPU, size_t& lds
     for (int SR = std::min(sr_env > 0 ? sr_env : 3, h); SR >= 1; --SR) {
         const int npix = (2 * SR + 3) * pw;
         if (npix * 4 > NSU * T || (SR + 1) * w * OKK > NPU * T) continue;
-        lds = (size_t)npix * OHD * 2 + (size_t)(SR + 1) * w * OPZ * 2;
-        if (bwd) lds += (size_t)pad_npix(npix) * OHD * 2 + (((size_t)SR * w * OPP * 2 + 15) & ~(size_t)15);
+        const int npixl = (2 * SR + 3) * olk_pws(pw);
+        lds = (size_t)npixl * OHD * 2 + (size_t)(SR + 1) * w * OPZ * 2;
+        if (bwd) lds += (size_t)pad_npix(npixl) * OHD * 2 + (((size_t)SR * w * OPP * 2 + 15) & ~(size_t)15);
         if (lds <= 80 * 1024) return SR;
     }
     return 0;
