@@ -822,6 +822,8 @@ static void g8_pick(const G8Args& ga, const EpiArgs& ep, int grid, hipStream_t s
         case G8_MUL | G8_RS: g8_go<NT1, G8_MUL | G8_RS>(ga, ep, grid, st); break;
         case G8_MUL8: g8_go<NT1, G8_MUL8>(ga, ep, grid, st); break;
         case G8_MUL8 | G8_RS: g8_go<NT1, G8_MUL8 | G8_RS>(ga, ep, grid, st); break;
+        case G8_MUL8 | G8_Q8: g8_go<NT1, G8_MUL8 | G8_Q8>(ga, ep, grid, st); break;
+        case G8_MUL8 | G8_RS | G8_Q8: g8_go<NT1, G8_MUL8 | G8_RS | G8_Q8>(ga, ep, grid, st); break;
         case G8_BIAS | G8_RES: g8_go<NT1, G8_BIAS | G8_RES>(ga, ep, grid, st); break;
         case G8_BIAS | G8_RS | G8_RES: g8_go<NT1, G8_BIAS | G8_RS | G8_RES>(ga, ep, grid, st); break;
         default: g8_go<NT1, -1>(ga, ep, grid, st); break;
@@ -923,6 +925,13 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         if (ep.residual && ep.ldr < N) return AP_ERR_SHAPE;
         if ((ep.mul_by != nullptr) + (ep.dgelu_of != nullptr) + (ep.mul8 != nullptr) > 1) return AP_ERR_SHAPE;
         if (ep.gelu < 0 || ep.gelu > 3 || (ep.gelu >= 2 && !ep.preact)) return AP_ERR_SHAPE;
+        // q8_out of a bf16 launch (round 5): the output a second time as e4m3 bytes, for the fp8 input-gradient product that consumes it.
+        // Exists in the 8-phase kernel's mul_by8 flavours only (the input gradient of fc2): anything else is refused, not silently skipped
+        if (epi->q8_out) {
+            ep.q8 = epi->q8_out; ep.q8_scale = epi->q8_scale; ep.q8_amax = epi->q8_amax;
+            if (!ep.q8_scale || !ep.mul8 || ep.bias || ep.gelu || ep.residual || (ldc & 15)) return AP_ERR_UNSUPPORTED;
+            if (!use_8p(M, N, K, ldc, ep)) return AP_ERR_UNSUPPORTED;
+        }
     }
     (void)hipGetLastError();
     static int skinny = -1;

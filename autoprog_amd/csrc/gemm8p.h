@@ -78,10 +78,11 @@ struct G8Args {
 // epilogue flavour of an instantiation (EF >= 0: bits known at compile time; EF < 0: read from the arguments at run time).  The
 // generic epilogue is ~25 KB of code that a CU runs once or twice per launch, cold: an instantiation per flavour of the training
 // step keeps what is fetched to what is used (2.8 us -> see DESIGN.md on the 25088 x 384 x 1152 launch).
-enum { G8_BIAS = 1, G8_GELU = 2, G8_DGELU = 4, G8_RS = 8, G8_RES = 16, G8_MUL = 32, G8_MUL8 = 64, G8_GTAB = 128 };
+enum { G8_BIAS = 1, G8_GELU = 2, G8_DGELU = 4, G8_RS = 8, G8_RES = 16, G8_MUL = 32, G8_MUL8 = 64, G8_GTAB = 128, G8_Q8 = 256 };
 __host__ __device__ inline int g8_flavour(const EpiArgs& ep) {
     return (ep.bias ? G8_BIAS : 0) | (ep.gelu ? G8_GELU : 0) | (ep.dgelu_of ? G8_DGELU : 0) | (ep.row_scale ? G8_RS : 0) | (ep.residual ? G8_RES : 0) |
-           (ep.mul_by ? G8_MUL : 0) | (ep.mul8 ? G8_MUL8 : 0) | ((ep.gelu == 3 && ep.gelu_tab) ? G8_GTAB : 0);
+           (ep.mul_by ? G8_MUL : 0) | (ep.mul8 ? G8_MUL8 : 0) | ((ep.gelu == 3 && ep.gelu_tab) ? G8_GTAB : 0) |
+           ((ep.q8 && !ep.gelu) ? G8_Q8 : 0);        // (the fp8 GELU launches emit their e4m3 side output without a flavour bit of their own)
 }
 
 // NT1: B part 1 holds NT1 16-column tiles per wave (1: 256 x 192 block tile, 2: 256 x 256).
@@ -119,8 +120,11 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
     const bool has_res = EF < 0 ? ep.residual != nullptr : (EF & G8_RES) != 0;
     const bool has_mul = EF < 0 ? ep.mul_by != nullptr : (EF & G8_MUL) != 0;
     const bool has_mul8 = EF < 0 ? ep.mul8 != nullptr : (EF & G8_MUL8) != 0;       // the 8-bit gelu' codes of a gelu = 3 forward
-    float qmx = 0.f;                              // FP8 with ep.q8: running max |output| of this lane, and the quantisation scale
-    const float qsc = (FP8 && ep.q8) ? ep.q8_scale[0] : 1.f;
+    // Q8C: this instantiation can write its output a second time as e4m3 bytes (ep.q8): the fp8 GELU launches (the operand of fc2), and the
+    // G8_Q8 flavours of the bf16 kernel (round 5: the input gradient of fc2, dL/dh -- the operand of fc1's fp8 input-gradient product)
+    constexpr bool Q8C = FP8 || (EF >= 0 && (EF & G8_Q8) != 0);
+    float qmx = 0.f;                              // Q8C with ep.q8: running max |output| of this lane, and the quantisation scale
+    const float qsc = (Q8C && ep.q8) ? ep.q8_scale[0] : 1.f;
     constexpr int WN = 32 + 16 * NT1, BN = 4 * WN;
     constexpr int VMN = 4 + NT1;                 // DMA instructions of the three parts in flight behind a counted wait
     constexpr int KS = 49152 + 8192 * NT1;       // bytes of a K-tile buffer (A h0 | A h1 | B part 0 | B part 1); the two buffers are adjacent
@@ -657,9 +661,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                             }
                             x = pack8(f);
                         }
-                        if (rowgelu) {
-                            if constexpr (FP8) {
-                                if (ep.q8) {           // the operand of the fp8 GEMM that consumes this activation (fc2), without a pass of its own
+                        if (rowgelu || (EF >= 0 && (EF & G8_Q8) != 0)) {
+                            if constexpr (Q8C) {
+                                if (ep.q8) {           // the operand of the fp8 GEMM that consumes this tensor, without a pass of its own
                                     float r8[8];
                                     unpack8(x, r8);
                                     u32x2 o;
@@ -692,7 +696,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
                             } else *reinterpret_cast<u32x2*>(gp8) = gqv;
                         }
                     }
-                    if constexpr (FP8) {
+                    if constexpr (Q8C) {
                         if (ep.q8) {
                             // 8 bytes per lane would leave as half lines: the lane with the even chunk of a pair takes its neighbour's 8 bytes
                             // (the XOR swizzle keeps chunk pairs on lane pairs) and stores 16
@@ -713,7 +717,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_8p(G8Args ga, EpiArgs ep) {
         }
     }
     G8_VM(0);
-    if constexpr (FP8) {
+    if constexpr (Q8C) {
         if (ep.q8 && ep.q8_amax) {
             qmx = group_max<64>(qmx);
             if (lane == 0 && __float_as_int(qmx) > *reinterpret_cast<volatile int*>(ep.q8_amax)) atomicMax(reinterpret_cast<int*>(ep.q8_amax), __float_as_int(qmx));

@@ -383,7 +383,8 @@ def _gelu_side_buffer(rows, cols, device):
     return torch.empty((rows, cols), dtype=torch.uint8 if STORE_GELU_GRAD == 2 else BF16, device=device)
 
 
-def _linear_bwd(g, x_in, w, dw, db, n=None, dgelu_of=None, need_dx=True, row_scale=None, rows_per_scale=1, cs_weight=None, inv_keep=1.0, mul_by=None):
+def _linear_bwd(g, x_in, w, dw, db, n=None, dgelu_of=None, need_dx=True, row_scale=None, rows_per_scale=1, cs_weight=None, inv_keep=1.0, mul_by=None,
+                q8=None, g8=None):
     """shared backward of y = x W^T + b given g = dL/dy (bf16 [M, ld]); accumulates dw/db.
     DropPath (the branch output is scaled per sample by s = mask/keep and x_in has the rows of dropped samples zeroed): pass
     row_scale = s (the input gradient gets it in the GEMM epilogue), cs_weight = per-token 0/1 mask and inv_keep = 1/keep:
@@ -399,7 +400,11 @@ def _linear_bwd(g, x_in, w, dw, db, n=None, dgelu_of=None, need_dx=True, row_sca
     if not need_dx:
         return None
     wt = bank.get_t(w)                       # [K, ld(N)]
-    return ops.gemm_nt(g, wt, n=wt.shape[0], k=wt.shape[1], dgelu_of=dgelu_of, mul_by=mul_by, row_scale=row_scale, rows_per_scale=rows_per_scale)
+    if g8 is not None:                       # (FP8_DGRAD) g8 = (e4m3 bytes of g, dq): the input-gradient product on the transposed e4m3 weight
+        w8t, dq_w = fp8_weights.get_t(w)
+        return ops.gemm_nt_fp8(g8[0], w8t, g8[1], dq_w, n=wt.shape[0], row_scale=row_scale, rows_per_scale=rows_per_scale)
+    # q8 = (scale, amax): -> (dx, dx8), the input gradient a second time as e4m3 (the operand of the next fp8 input-gradient product)
+    return ops.gemm_nt(g, wt, n=wt.shape[0], k=wt.shape[1], dgelu_of=dgelu_of, mul_by=mul_by, row_scale=row_scale, rows_per_scale=rows_per_scale, q8=q8)
 
 
 def token_mask(keep01, n_tokens):
@@ -418,6 +423,10 @@ def token_mask(keep01, n_tokens):
 # pass, no reduction in front of it); a site's first use scales by its current amax.  Weights are quantised once per optimizer
 # step from their bf16 copies.  All scales live in three device vectors; nothing is read back to the host.
 FP8_LINEAR = os.environ.get("AP_FP8", "0") == "1"
+# Round 5: the INPUT-GRADIENT product of fc1 on e4m3 operands as well (K = the MLP's hidden width, the long reduction of the backward): dL/dh
+# leaves the fc2 input-gradient launch a second time as e4m3 bytes (its epilogue, delayed scale of its own site), the transposed weight is
+# quantised with the forward copy's scale in the per-step weight launch.  AP_FP8_DGRAD=0: forward products only (round 4).
+FP8_DGRAD = os.environ.get("AP_FP8_DGRAD", "1") != "0"
 
 
 class _Fp8Scales:
@@ -498,11 +507,29 @@ class _Fp8Weights:
         if ent is None or ent[3] is not self:
             wb = bank.get(w)
             w8, dq = fp8_scales.quantize(("w", id(w)), wb)
-            self.items.append((w, fp8_scales.slots[("w", id(w))], w8))
+            self.items.append((w, fp8_scales.slots[("w", id(w))], w8, False))
             w._ap_fp8 = (key, w8, dq, self)
             return w8, dq
         self.requantize()
         ent = w._ap_fp8
+        return ent[1], ent[2]
+
+    def get_t(self, w):
+        """e4m3 copy of the TRANSPOSED weight [in, ld(out)] (the B operand of the input-gradient product), scaled like the forward copy"""
+        key = (w.data_ptr(), w._version, _WeightBank.generation)
+        ent = w.__dict__.get("_ap_fp8_t")
+        if ent is not None and ent[0] == key:
+            return ent[1], ent[2]
+        if ent is None or ent[3] is not self:
+            self.get(w)                                                            # the forward copy owns the site
+            slot = fp8_scales.slots[("w", id(w))]
+            sc = fp8_scales
+            w8t = ops.quantize_fp8(bank.get_t(w), sc.scale[slot:slot + 1])
+            self.items.append((w, slot, w8t, True))
+            w._ap_fp8_t = (key, w8t, sc.dq[slot:slot + 1], self)
+            return w8t, sc.dq[slot:slot + 1]
+        self.requantize()
+        ent = w._ap_fp8_t
         return ent[1], ent[2]
 
     def requantize(self):
@@ -511,17 +538,21 @@ class _Fp8Weights:
             return
         sc = fp8_scales
         sc.site(("w", id(self.items[0][0])), bank.get(self.items[0][0]))          # rolls the scales when an optimizer step has passed
-        srcs = [bank.get(w) for (w, _, _) in self.items]
+        srcs = [bank.get_t(w) if tr else bank.get(w) for (w, _, _, tr) in self.items]
         ptrs = tuple(t.data_ptr() for t in srcs)
         if self.table is None or self.table_src != ptrs:
             tab = np.zeros((len(self.items), 4), dtype=np.int64)                   # ap_fp8_job: x, y, n, (slot, pad)
-            for r, ((w, slot, w8), t) in enumerate(zip(self.items, srcs)):
+            for r, ((w, slot, w8, tr), t) in enumerate(zip(self.items, srcs)):
                 tab[r] = (t.data_ptr(), w8.data_ptr(), t.numel(), slot)
             self.table = torch.from_numpy(tab).to(srcs[0].device)
             self.table_src = ptrs
         ops.quantize_fp8_multi(self.table, len(self.items), sc.scale, sc.amax)
-        for (w, slot, w8) in self.items:
-            w._ap_fp8 = ((w.data_ptr(), w._version, _WeightBank.generation), w8, sc.dq[slot:slot + 1], self)
+        for (w, slot, w8, tr) in self.items:
+            ent = ((w.data_ptr(), w._version, _WeightBank.generation), w8, sc.dq[slot:slot + 1], self)
+            if tr:
+                w._ap_fp8_t = ent
+            else:
+                w._ap_fp8 = ent
 
 
 fp8_weights = _Fp8Weights()
@@ -633,8 +664,21 @@ class TransformerBlockFn(torch.autograd.Function):
         dy2 = dy.reshape(x2.shape).contiguous()
         with wgrad_batch(sunk, params) as batch:         # the four weight gradients (and the two LayerNorm parameter gradients) launch together: on exit, or with the window's
             # MLP branch
-            dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, row_scale=rs2, rows_per_scale=N, cs_weight=tm2, inv_keep=inv_keep, **_gelu_bwd_kw(h))
-            dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b)
+            dh8 = None
+            if FP8_LINEAR and FP8_DGRAD and h.shape[1] % 16 == 0 and h.shape[1] == fc1_w.shape[0]:
+                # dL/dh as e4m3 next to its bf16 form (the weight gradient keeps reading that): from the launch's epilogue once the site has a
+                # scale (its second step on), by a pass of its own before
+                site = fp8_scales.producer(("g", id(fc1_w)), dy2.device)
+                if site is not None and ops.gemm_nt_emits_q8(dy2.shape[0], h.shape[1], dy2.shape[1], h):
+                    dh, d8 = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, row_scale=rs2, rows_per_scale=N, cs_weight=tm2, inv_keep=inv_keep,
+                                         q8=(site[0], site[1]), **_gelu_bwd_kw(h))
+                    dh8 = (d8, site[2])
+                else:
+                    dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, row_scale=rs2, rows_per_scale=N, cs_weight=tm2, inv_keep=inv_keep, **_gelu_bwd_kw(h))
+                    dh8 = fp8_scales.quantize(("g", id(fc1_w)), dh)
+            else:
+                dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, row_scale=rs2, rows_per_scale=N, cs_weight=tm2, inv_keep=inv_keep, **_gelu_bwd_kw(h))
+            dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b, g8=dh8)
             dx1 = ops.layernorm_bwd(dxn2, x1, n2w, m2, r2, dy2, dn2w, dn2b, defer=batch.ln)
             # attention branch
             do = _linear_bwd(dx1, o, proj_w, dproj_w, dproj_b, row_scale=rs1, rows_per_scale=N, cs_weight=tm1, inv_keep=inv_keep)

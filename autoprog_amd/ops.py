@@ -190,11 +190,19 @@ def _gelu_mode(gelu, preact_grad, preact_out):
     return mode
 
 
+def gemm_nt_emits_q8(M, N, K, mul_by):
+    """can a bf16 gemm_nt launch of these dimensions write its output a second time as e4m3 (q8=)?  The mul_by8 flavours of the 8-phase
+    kernel (the input gradient of fc2): see ap_gemm_nt / use_8p() in csrc/gemm.hip"""
+    return (mul_by is not None and mul_by.dtype == torch.uint8 and K % 64 == 0 and K >= 128 and M >= 4096 and N % 16 == 0
+            and (N >= 1024 or N % 192 == 0 or N % 256 == 0) and os.environ.get("AP_GEMM_8P", "1") != "0")
+
+
 def gemm_nt(a, b, n=None, k=None, bias=None, gelu=False, preact_out=None, dgelu_of=None, row_scale=None,
-            rows_per_scale=1, residual=None, out=None, ldc=None, preact_grad=False, mul_by=None):
+            rows_per_scale=1, residual=None, out=None, ldc=None, preact_grad=False, mul_by=None, q8=None):
     """out[M, :n] = epilogue(a[M, :k] @ b[:n, :k]^T); a/b bf16 2-D (row stride = shape[1]).
     preact_grad: with gelu, preact_out receives gelu'(h) instead of h (True / 1: bf16; 2: 8-bit codes, preact_out uint8); its backward
-    passes that tensor as mul_by (a uint8 tensor is taken as the codes)."""
+    passes that tensor as mul_by (a uint8 tensor is taken as the codes).
+    q8 = (scale, amax) (gemm_nt_emits_q8 launches): -> (out, out8), out8 = the e4m3 bytes of out * scale[0], amax[0] raised to max |out|"""
     _req(a, BF16, "a"); _req(b, BF16, "b")
     M = a.shape[0]
     n = b.shape[0] if n is None else n
@@ -225,9 +233,15 @@ def gemm_nt(a, b, n=None, k=None, bias=None, gelu=False, preact_out=None, dgelu_
         epi.residual = residual.data_ptr() if residual is not None else None
         epi.ldr = residual.shape[1] if residual is not None else 0
         epi_ref = ctypes.byref(epi)
+    out8 = None
+    if q8 is not None:
+        if epi_ref is None:
+            raise AutoProgHipError("gemm_nt: q8 exists for the mul_by (8-bit codes) launches only")
+        out8 = torch.empty((M, ldc), dtype=torch.uint8, device=a.device)
+        epi.q8_out, epi.q8_scale, epi.q8_amax = out8.data_ptr(), q8[0].data_ptr(), (q8[1].data_ptr() if q8[1] is not None else None)
     check(lib.ap_gemm_nt(a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1], out.data_ptr(), ldc, M, n, k,
                          epi_ref, _stream()), "ap_gemm_nt")
-    return out
+    return out if q8 is None else (out, out8)
 
 
 FP8_MAX = 448.0          # OCP e4m3

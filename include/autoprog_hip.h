@@ -125,7 +125,9 @@ typedef struct ap_gemm_epilogue {
                                  * multiplication instead of ~18 instructions per element; not together with dgelu_of.  (ABI version 3) */
     const unsigned char* mul_by8; /* (ABI version 6) as mul_by with the 8-bit codes a gelu = 3 forward stored: out = v * (mul_by8[m,n] - 26) / 202, ld = ldc
                                  * bytes; not together with mul_by / dgelu_of */
-    unsigned char* q8_out;      /* ap_gemm_nt_fp8 with gelu only (ABI version 4): the output a second time as OCP e4m3 bytes [M, ldc] --     */
+    unsigned char* q8_out;      /* ap_gemm_nt_fp8 with gelu (ABI version 4), ap_gemm_nt with mul_by8 and nothing else but row_scale (version 6:   */
+                                /* the input gradient of fc2, operand of fc1's fp8 input-gradient product; AP_ERR_UNSUPPORTED for any other launch */
+                                /* or one the 8-phase kernel does not take): the output a second time as OCP e4m3 bytes [M, ldc] --             */
     const float* q8_scale;      /* q8_out = sat(out * q8_scale[0]), q8_amax[0] = max(q8_amax[0], max |out|) (nullable) -- the operand of the */
     float* q8_amax;             /* fp8 GEMM that consumes this activation, without a quantisation pass.  Launches of the 8-phase kernel only */
                                 /* (M >= 4096, K % 128 == 0, N as for ap_gemm_nt): AP_ERR_UNSUPPORTED otherwise; ap_gemm_nt ignores them.   */

@@ -1073,6 +1073,25 @@ def test_fp8_producers_match_the_quantiser(ops):
     o0, lse0 = ops.mhsa_fwd(qkv, B, N, heads, hd ** -0.5, out_row_scale=keep)
     assert torch.equal(o, o0) and torch.equal(lse, lse0)
     assert torch.equal(o8, ops.quantize_fp8(o0, scale, amax_ref)) and float(amax) == float(amax_ref) > 0
+    # (d) (round 5) the input gradient of fc2 -- a bf16 launch that multiplies by the 8-bit gelu' codes -- a second time as e4m3: the operand
+    # of fc1's fp8 input-gradient product; with and without the DropPath row scale, 256 x 256 and 256 x 192 tiles
+    for M, N, K, with_rs in [(4352, 1152, 384, False), (4100, 3072, 768, True), (4096, 576, 192, True)]:
+        torch.manual_seed(N)
+        g = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+        wt = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
+        codes = torch.randint(0, 256, (M, N), device="cuda", dtype=torch.uint8)
+        rps = max(1, M // 2)
+        kw = dict(row_scale=torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9], device="cuda"), rows_per_scale=rps) if with_rs else {}
+        assert ops.gemm_nt_emits_q8(M, N, K, codes)
+        scale, amax, amax_ref = torch.tensor([71.0], device="cuda"), torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+        d0 = ops.gemm_nt(g, wt, mul_by=codes, **kw)
+        d1, d8 = ops.gemm_nt(g, wt, mul_by=codes, q8=(scale, amax), **kw)
+        assert torch.equal(d0, d1)
+        assert torch.equal(d8, ops.quantize_fp8(d0, scale, amax_ref)) and float(amax) == float(amax_ref) > 0
+    with pytest.raises(Exception):          # refused, not silently skipped: q8 without the codes / on a launch the 8-phase kernel does not take
+        ops.gemm_nt(g, wt, row_scale=kw["row_scale"], rows_per_scale=rps, q8=(scale, amax))
+    with pytest.raises(Exception):
+        ops.gemm_nt(g[:512], wt, mul_by=codes[:512].contiguous(), q8=(scale, amax))
     sizes = [(1152, 384), (384, 384), (64, 16), (3072, 768)]
     ws = [dev(rnd(n, k, scale=0.05 * (i + 1), seed=10 + i)) for i, (n, k) in enumerate(sizes)]
     scales = torch.tensor([100.0, 300.0, 50.0, 1000.0, 7.0], device="cuda")

@@ -328,26 +328,32 @@ def test_volo_d5_shapes_448_vs_oracle():
     _d5_shapes_vs_oracle(out_tol=3e-2, loss_tol=3e-3, grad_tol=6e-2, stem_tol=0.14, tag="bf16")
 
 
-def test_volo_d5_shapes_448_fp8_vs_oracle(monkeypatch):
+@pytest.mark.parametrize("fp8_dgrad", [False, True])
+def test_volo_d5_shapes_448_fp8_vs_oracle(monkeypatch, fp8_dgrad):
     """The same D5-shape network under functional.FP8_LINEAR (configs[4]: "mixed MFMA fp8 GEMM / bf16 accum"): the
     forward Linear products of its transformer blocks run on e4m3 operands at the D5 shapes (K = 768 / 3072, head_dim 48 blocked
     attention emitting its e4m3 output) -- compared with the fp64 ORACLE, not with the bf16 HIP path.  e4m3 keeps 3 mantissa bits
     (2^-4 relative per element, ~1/sqrt(K) of it after a K-long dot product), so the bounds are wider than the bf16 test's: outputs
     <= 8e-2, loss <= 1e-2 relative, parameter gradients <= 0.12 per tensor (0.2 in the conv stem, whose BatchNorm backward amplifies
     the perturbation of everything above it).  Measured (round 4): outputs 4.8e-2 / 6.0e-2, loss 4.0e-3, gradients median 3.6e-2, max
-    0.103 (patch_embed.conv.1.weight); the bf16 run of the same network: 7.0e-3 / 8.4e-3, 7e-5, 7.4e-3, 9.8e-2."""
+    0.103 (patch_embed.conv.1.weight); the bf16 run of the same network: 7.0e-3 / 8.4e-3, 7e-5, 7.4e-3, 9.8e-2.
+    fp8_dgrad (round 5, functional.FP8_DGRAD): the INPUT-GRADIENT product of fc1 (K = 3072) on e4m3 operands as well -- dL/dh quantised with a
+    per-tensor scale, the transposed weight with the forward copy's -- under the same bounds (the gradients are then fp8 GRADIENTS against the
+    fp64 oracle)."""
     from autoprog_amd import functional as AF, ops
     AF.reset_fp8_state()
     monkeypatch.setattr(AF, "FP8_LINEAR", True)
     calls = []
     real = ops.gemm_nt_fp8
     monkeypatch.setattr(ops, "gemm_nt_fp8", lambda *a, **k: (calls.append(tuple(a[0].shape)), real(*a, **k))[1])
+    monkeypatch.setattr(AF, "FP8_DGRAD", fp8_dgrad)
     try:
-        _d5_shapes_vs_oracle(out_tol=8e-2, loss_tol=1e-2, grad_tol=0.12, stem_tol=0.2, tag="fp8 forward GEMMs")
+        _d5_shapes_vs_oracle(out_tol=8e-2, loss_tol=1e-2, grad_tol=0.12, stem_tol=0.2, tag="fp8 forward GEMMs" + (" + fc1 input gradient" if fp8_dgrad else ""))
     finally:
         AF.reset_fp8_state()
-    # two transformer blocks x (qkv, proj, fc1, fc2) at 784 tokens: K = 768 (x3) and 3072
-    assert len(calls) == 8 and sorted({s[1] for s in calls}) == [768, 3072], calls
+    # two transformer blocks x (qkv, proj, fc1, fc2) at 784 tokens: K = 768 (x3) and 3072; + the input-gradient product of fc1 (K = 3072)
+    assert len(calls) == (10 if fp8_dgrad else 8) and sorted({s[1] for s in calls}) == [768, 3072], calls
+    assert sum(1 for s in calls if s[1] == 3072) == (4 if fp8_dgrad else 2)
 
 
 def test_volo_d5_full_depth_448_smoke():
@@ -815,15 +821,19 @@ def test_hip_stem_eval_and_elastic_resolution_vs_oracle():
     assert rel(y, y2) < 2e-2, rel(y, y2)
 
 
-def test_fp8_forward_gemms_inside_the_transformer_block(monkeypatch):
+@pytest.mark.parametrize("fp8_dgrad", [False, True])
+def test_fp8_forward_gemms_inside_the_transformer_block(monkeypatch, fp8_dgrad):
     """BASELINE configs[4] ('mixed MFMA fp8 GEMM'): with functional.FP8_LINEAR the four Linear layers of a transformer block run their
     forward product on e4m3 operands -- the fp8 instantiation of the 8-phase kernel at this size (M = 4096, K % 128 == 0) -- with
-    per-tensor delayed scaling; the backward stays bf16.  Against the bf16 block on the same weights and input: output <= 3e-2,
+    per-tensor delayed scaling; the backward stays bf16 (fp8_dgrad = False) or runs fc1's input-gradient product on e4m3 operands too
+    (functional.FP8_DGRAD, round 5: in the first step dL/dh is quantised by a pass of its own, in the second by the epilogue of the launch
+    that produces it -- the mul_by8 + q8 flavour of the bf16 8-phase kernel).  Against the bf16 block on the same weights and input: output <= 3e-2,
     weight gradients <= 8e-2 (e4m3 keeps 3 mantissa bits; the residual stream is not quantised).  The second step quantises with the
     scales rolled from the first step's amax (no reduction pass in front of the quantiser) and stays as close."""
     from autoprog_amd import functional as AF, ops
     from autoprog_amd.models.volo import Transformer
     AF.reset_fp8_state()
+    monkeypatch.setattr(AF, "FP8_DGRAD", fp8_dgrad)
     torch.manual_seed(0)
     B, N, C, heads = 16, 256, 256, 8
     blk = Transformer(C, heads, mlp_ratio=3.0).cuda().train()
@@ -844,7 +854,7 @@ def test_fp8_forward_gemms_inside_the_transformer_block(monkeypatch):
     y16, g16, dx16 = run(False)
     assert not calls
     y8, g8, dx8 = run(True)
-    assert len(calls) == 4 and all(s[0] == B * N for s in calls)
+    assert len(calls) == (5 if fp8_dgrad else 4) and all(s[0] == B * N for s in calls)
     rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
     e_y = rel(y8, y16)
     e_g = {n: rel(g8[n], g16[n]) for n in g16}
@@ -857,7 +867,11 @@ def test_fp8_forward_gemms_inside_the_transformer_block(monkeypatch):
     amax_seen = float(sc.amax[i])
     assert amax_seen > 0
     AF._WeightBank.generation += 1
+    emitted = []
+    real_nt = ops.gemm_nt
+    monkeypatch.setattr(ops, "gemm_nt", lambda *a, **k: (emitted.append(k.get("q8") is not None), real_nt(*a, **k))[1])
     y8b, g8b, _ = run(True)
+    assert any(emitted) == fp8_dgrad                     # dL/dh left its launch as e4m3 (no quantisation pass) iff the fp8 input gradient is on
     assert abs(float(sc.scale[i]) - ops.FP8_MAX / amax_seen) < 1e-3 * float(sc.scale[i]) and float(sc.amax[i]) > 0
     assert rel(y8b, y16) < 3e-2 and max(rel(g8b[n], g16[n]) for n in g16) < 8e-2
 
