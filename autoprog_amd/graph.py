@@ -129,12 +129,14 @@ class GraphedStep:
                 self._prepare()
                 self._step_body()
         torch.cuda.current_stream().wait_stream(s)
+        rng = np.random.get_state()            # the capture prepares a step it does not run: its mix-token draw is handed back
         self._prepare()
         count = self.opt.step_count
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._step_body()
         self.opt.step_count = count            # the capture recorded a step, it did not run one
+        np.random.set_state(rng)
         return self
 
     def step(self, images=None, target=None):

@@ -30,7 +30,7 @@ def _sync():
 class AutoProgDriver:
     def __init__(self, model, loss_fn, optimizer, reducer, get_batch, r_list, l_list, dp_list, grow_epochs, steps_per_epoch,
                  search_epochs=2, auto_grow=True, probe_batches=4, time_steps=4, seed=0, log=None, original_batch_splits=1,
-                 r_max=None, dist_bn=""):
+                 r_max=None, dist_bn="", use_graphs=False, graph_after=2):
         """model: supernet sized for l_list[-1] (e.g. volo_h12_l18); optimizer: FlatAdamWEma over it; reducer: its
         GradientBucketReducer; r_list / l_list / dp_list / grow_epochs: the stage schedule (prog/progressive.py:4-31);
         get_batch(r): a training batch (images at ANY size -- the stem resizes to r -- and a token-label target for r // 16).
@@ -40,7 +40,15 @@ class AutoProgDriver:
         A search runs every candidate at `original_batch_splits` (main_prog.py:807-810: batch_size = original_batch_size //
         original_batch_splits for the whole search), timing and probes included.
         dist_bn: "reduce" | "broadcast" | "" -- the reference's --dist-bn: after every epoch the BatchNorm running statistics are
-        averaged over the ranks or taken from rank 0 (main_prog.py:883-887)."""
+        averaged over the ranks or taken from rank 0 (main_prog.py:883-887).
+        use_graphs (single rank, one micro-batch per update): the training steps of an epoch replay ONE HIP graph per stage
+        configuration (autoprog_amd/graph.py: the per-step host scalars live in device memory) -- the early AutoProg stages
+        (main_prog.py:973-974: every batch resized to the stage's r) are launch-gap bound on an MI355X, stage (9, 128) runs 5.9 -> 4.3 ms
+        per step.  The first `graph_after` steps at a configuration run eagerly (lazy initialisations, the allocator's pools), the next
+        one is captured; a stage transition drops the graphs.  The steps of a search (a different sub-network every step) stay eager.
+        With DropPath off a graphed run is bit-identical to the eager one; with it the masks come from the same generator at replay time."""
+        self.use_graphs, self.graph_after = bool(use_graphs), int(graph_after)
+        self._graphs, self._eager_seen = {}, {}
         self.original_batch_splits = int(original_batch_splits)
         self.dist_bn = dist_bn
         self.r_max = r_max if r_max is not None else max(r_list)
@@ -71,6 +79,7 @@ class AutoProgDriver:
         from the last EMA copy), shallower (a search picked a sub-network of its supernet) -> load='super' (model from the
         trained supernet); the optimizer restarts either way."""
         new_mask = ActiveLayerMask(l, self.l_min, self.l_max)
+        self._drop_graphs()                                           # (a graph holds the kernels of ONE configuration and optimizer layout)
         if self.mask is not None and (l != self.current_l or dp != self.current_dp):
             self.opt.grow(self.mask, new_mask, model_source="ema_last" if l >= self.current_l else "model")
         self.mask = self._activate(l, r, dp)
@@ -96,11 +105,42 @@ class AutoProgDriver:
         dist.all_reduce(t, group=self.reducer.group)
         return (t / world).tolist()
 
+    def _drop_graphs(self):
+        for gs in self._graphs.values():
+            gs.release()
+        self._graphs.clear()
+        self._eager_seen.clear()
+
+    def _graph_step(self, l, r, dp):
+        """the epoch loop's step from a HIP graph; None: not (yet) -- the caller runs the eager step"""
+        key = (l, r, dp)
+        gs = self._graphs.get(key)
+        if gs is not None:
+            images, target = self.get_batch(r)
+            return gs.step(images, target).detach().clone()       # (the graph's loss tensor is overwritten by the next replay)
+        seen = self._eager_seen.get(key, 0)
+        if seen < self.graph_after:
+            self._eager_seen[key] = seen + 1
+            return None
+        from ..graph import GraphedStep
+        images, target = self.get_batch(r)
+        self.reducer.zero_grad()
+        self._set_splits(1)
+        gs = GraphedStep(self.model, self.loss_fn, self.reducer, self.opt, images, target).capture(warmup=0)
+        self._graphs[key] = gs
+        return gs.step().detach().clone()                          # the batch the graph was built on is this step's batch
+
     def _train_step(self, l, r, dp, splits=None):
         """one optimizer update = `splits` micro-batches, backward on loss / splits each (main_prog.py:1019 `loss / args.batch_splits`),
         the gradient exchange and the optimizer on the last one (`update`, main_prog.py:971,1026).  -> mean loss (device scalar)"""
         self._activate(l, r, dp)
         k = self.splits_for(l, r) if splits is None else splits
+        if (self.use_graphs and splits is None and k == 1 and getattr(self.reducer, "world", 1) == 1 and torch.cuda.is_available()):
+            loss = self._graph_step(l, r, dp)
+            if loss is not None:
+                return loss
+        if self._graphs and getattr(self.model, "step_scalars", None) is not None:
+            self.model.step_scalars = None                            # an eager step between replays: host scalars again
         self.reducer.zero_grad()                  # (closes whatever update was open: the split count may change now)
         self._set_splits(k)
         total = None

@@ -119,3 +119,51 @@ def test_graph_replay_with_droppath_and_clipping(monkeypatch):
     assert be == bg
     assert all(np.isfinite(lg)) and len(set(lg)) == len(lg)
     assert abs(le[0] - lg[0]) < 0.05 * abs(le[0])
+
+
+def test_driver_epochs_from_graphs_reproduce_the_eager_driver(monkeypatch):
+    """prog/driver.py with use_graphs ("replay in ... prog/driver.py"): a two-stage scheduled run (no search) whose epoch
+    steps are replayed from one HIP graph per stage configuration after two eager steps -- DropPath off, deterministic weight gradients, a
+    fresh random batch every step: per-epoch losses, final weights and EMA copies equal the eager driver's BIT FOR BIT, graphs were really
+    used (one per stage) and dropped at the stage transition."""
+    from autoprog_amd import ops
+    from autoprog_amd.dist import GradientBucketReducer
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    from autoprog_amd.models import create_model
+    from autoprog_amd.optim import FlatAdamWEma
+    from autoprog_amd.prog.driver import AutoProgDriver
+    from autoprog_amd import graph as G
+    monkeypatch.setattr(ops, "deterministic", True)
+    replays = []
+    real_step = G.GraphedStep.step
+    monkeypatch.setattr(G.GraphedStep, "step", lambda self, *a, **k: (replays.append(1), real_step(self, *a, **k))[1])
+    out = {}
+    for use_graphs in (False, True):
+        torch.manual_seed(0)
+        model = create_model("model_variant", variant="volo_h2_l6", num_classes=16, img_size=96, stem_hidden_dim=64).cuda().train()
+        red = GradientBucketReducer(list(model.parameters()), world_size=1, defer_mean=True)
+        red.install_sink(model)
+        opt = FlatAdamWEma(model, red, lr=1e-3, weight_decay=0.05, ema_decays=[0.9, 0.99])
+        loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=16)
+        g = torch.Generator().manual_seed(1)
+
+        def get_batch(r):
+            x = torch.randn(8, 3, 96, 96, generator=g).cuda()
+            return x, torch.softmax(torch.randn(8, 16, 2 + (r // 16) ** 2, generator=g) * 2, dim=1).cuda()
+
+        drv = AutoProgDriver(model, loss_fn, opt, red, get_batch, r_list=[64, 96], l_list=[3, 6], dp_list=[0.0, 0.0], grow_epochs=[0, 2],
+                             steps_per_epoch=5, auto_grow=False, use_graphs=use_graphs, graph_after=2)
+        try:
+            np.random.seed(3)
+            n0 = len(replays)
+            hist = drv.run(4)
+            out[use_graphs] = ([h["loss"] for h in hist], opt.p.clone(), [e.clone() for e in opt.ema], len(replays) - n0, len(drv._graphs))
+        finally:
+            red.remove()
+    le, pe, ee, ne, _ = out[False]
+    lg, pg, eg, ng, live = out[True]
+    print("eager :", le)
+    print("graph :", lg)
+    assert ne == 0 and ng == 2 * (2 * 5 - 2) and live == 1        # per stage: 2 epochs x 5 steps, the first two eager; the last stage's graph is live
+    assert le == lg, (le, lg)
+    assert torch.equal(pe, pg) and all(torch.equal(a, b) for a, b in zip(ee, eg))
