@@ -22,12 +22,13 @@ others)
       e=$(python bench.py --variant $1 --res $2 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | grep -oE "\"ms_per_step\": [0-9.]+")
       g=$(python bench.py --variant $1 --res $2 --graph --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | grep -oE "\"ms_per_step\": [0-9.]+")
       echo "$1 $2 px: eager $e | graph $g"; done; } > gpurun_out/${R}_exp_graph.txt
+  timeout 600 python tools/soak.py 300 2>&1 | grep -v amdgpu | tail -16 > gpurun_out/${R}_soak_300.txt
   for w in stages stages_blocks stages_blocks_graph deit_base d5_448 d5_fp8; do python - <<PY
 import json
 d=json.load(open("gpurun_out/${R}_bench_$w.json"))
 print("$w", d["value"], d["ms_per_step"], (d.get("roofline") or {}).get("frac"), (d.get("roofline") or {}).get("fp8_launches_per_step"))
 PY
-  done; cat gpurun_out/${R}_exp_graph.txt ;;
+  done; cat gpurun_out/${R}_exp_graph.txt; tail -4 gpurun_out/${R}_soak_300.txt ;;
 d5prof)
   for f in "" "--fp8"; do
     tag=d5_bf16; [ -n "$f" ] && tag=d5_fp8
