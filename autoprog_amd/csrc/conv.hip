@@ -49,6 +49,12 @@ k_conv3x3_pack(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __r
     wb[((8 - tap) * CV_C + ci) * CV_C + co] = v;
 }
 
+// Swizzle key of the weight image (rows of 128 bytes: a row's bank base is (row & 1) * 32).  The 16 rows a ds_read_b128 lane group reads are
+// 8 q + 4 b + p (q, p = 0 .. 3): their parity is p & 1, so the eight rows of one parity need eight different chunks -- key = (p >> 1) | q << 1.
+// (Rounds 2 - 4 used the GEMM's key_b = p | (q & 1) << 2: rows q and q + 2 shared chunk AND parity, a two-way conflict on every weight
+// fragment read -- the "27 % LDS-conflict share" of these kernels in the round-4 counters.)
+__device__ __forceinline__ int key_cv(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
+
 // Input transform (PRE_BN): the kernel reads the PRE-BatchNorm output z of the previous convolution and applies
 // relu((z - mean) * rstd * gamma + beta) -- in the arithmetic of k_bn_relu_apply, rounded to bf16 -- to every chunk on its way from the
 // staging registers to LDS; pixels outside the image stay zero (the padding is of the ACTIVATION).  The activation tensor between two
@@ -83,7 +89,7 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
     constexpr int NTH = 64 * NW, RPW = CV_TR / NW, NPRE = (CV_NCHUNK + NTH - 1) / NTH, PSTEP = NTH / 8;     // threads, tile rows per wave, patch chunks per thread, pixels per staging sweep
     constexpr int NOUT = 2 * RPW, SL = NOUT / 4;                                                        // output chunks per lane; first step of the next tile's loads
     extern __shared__ __attribute__((aligned(16))) bf16_t cv_smem[];
-    bf16_t* Wl = cv_smem;                       // [9][64 co][64 ci], chunk ^ key_b(co)
+    bf16_t* Wl = cv_smem;                       // [9][64 co][64 ci], chunk ^ key_cv(co)
     bf16_t* P = cv_smem + CV_WELEMS;            // [612 px][64 ci + 8 pad]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, g = lane >> 4;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -93,12 +99,12 @@ k_conv3x3_c64(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16_
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int r = 32 * (q >> 1) + 8 * (fr >> 2) + 4 * (q & 1) + (fr & 3);       // N-permuted rows: see gemm.hip "direct epilogue"
-        wbase[q][0] = r * CV_C + ((g ^ key_b(r)) << 3);
-        wbase[q][1] = r * CV_C + (((4 + g) ^ key_b(r)) << 3);
+        wbase[q][0] = r * CV_C + ((g ^ key_cv(r)) << 3);
+        wbase[q][1] = r * CV_C + (((4 + g) ^ key_cv(r)) << 3);
     }
     for (int idx = tid; idx < CV_WELEMS / 8; idx += NTH) {
         const int row = idx >> 3, c = idx & 7;
-        st16(Wl + row * CV_C + ((c ^ key_b(row & (CV_C - 1))) << 3), ld16(wp + (int64_t)idx * 8));
+        st16(Wl + row * CV_C + ((c ^ key_cv(row & (CV_C - 1))) << 3), ld16(wp + (int64_t)idx * 8));
     }
     float* const bpar = reinterpret_cast<float*>(P + CV_NPIX * CV_PSTR);     // BSTATS: [mean | rstd | gamma | beta][64] of the layer below
     if constexpr (BSTATS) {

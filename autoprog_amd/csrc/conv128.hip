@@ -60,7 +60,9 @@ k_conv3x3_c128(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16
     // fragment bases (elements): pixel (tile row 4 pg + pt + ky, column fr + kx), K chunk g of the slab's 64 channels; weight row 64 ch + 16 cot + fr
     const int pbase = (4 * pg * C8_PW + fr) * C8_PSTR + g * 8;
     const int wrow = ch * 64 + fr;
-    const int wb0 = wrow * 64 + ((g ^ (fr & 7)) << 3), wb1 = wrow * 64 + (((4 + g) ^ (fr & 7)) << 3);
+    // (swizzle key (row >> 1) & 7: rows of 128 bytes alternate between the two halves of the banks, so the eight rows of one parity that a
+    // 16-lane ds_read_b128 group reads need eight different chunks; row & 7 gave rows fr and fr + 8 the same chunk AND parity: two-way conflicts)
+    const int wb0 = wrow * 64 + ((g ^ ((fr >> 1) & 7)) << 3), wb1 = wrow * 64 + (((4 + g) ^ ((fr >> 1) & 7)) << 3);
     // staging assignment: 16-byte chunk c16 of pixel p0 + 32 i (patch: i < 11; output tile: i < 8)
     const int c16 = tid & 15;
     int p0 = tid >> 4;                           // laundered once per tile: the 11 per-chunk (row, column) pairs are 3 VALU each; hoisted out of
@@ -70,7 +72,7 @@ k_conv3x3_c128(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, bf16
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int idx = tid + 512 * j, row = idx >> 3, c = idx & 7;
-        wdst[j] = row * 64 + ((c ^ (row & 7)) << 3);
+        wdst[j] = row * 64 + ((c ^ ((row >> 1) & 7)) << 3);
     }
     auto tile_origin = [&](int t, int& b, int& ty0, int& tx0) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;

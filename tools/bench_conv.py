@@ -19,3 +19,4 @@ def tm(fn, n=12):
     return e0.elapsed_time(e1) * 1e3 / n
 print("forward + stats      plain %6.1f us   bn input %6.1f us" % (tm(lambda i: ops.conv3x3_c64(xs[i], wf, True)), tm(lambda i: ops.conv3x3_c64(xs[i], wf, True, bn_in=bn))))
 print("weight gradient      plain %6.1f us   bn input %6.1f us" % (tm(lambda i: ops.conv3x3_c64_wgrad(xs[i], dy, dw)), tm(lambda i: ops.conv3x3_c64_wgrad(xs[i], dy, dw, bn_in=bn))))
+print("input gradient       plain %6.1f us   + BatchNorm-backward sums %6.1f us" % (tm(lambda i: ops.conv3x3_c64(xs[i], wb)), tm(lambda i: ops.conv3x3_c64_bwd_stats(dy, wb, xs[i], bn))))
