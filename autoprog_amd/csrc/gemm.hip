@@ -24,6 +24,7 @@
 #include <type_traits>
 #include "gemm_epi.h"
 #include "gemm8p.h"
+#include "gemm_ws.h"
 #include "gemm_tn8p.h"
 // (the measured-and-rejected kernels of rounds 1 and 2 -- LDS-DMA rings, persistent 256-row tiles, the ring weight-gradient kernel -- and
 // their AP_GEMM_NT_P / _RING / _DMA, AP_GEMM_TN_RING switches live under tools/gemm_lab/rejected/, outside the product library)
@@ -911,6 +912,39 @@ static int use_8p(int M, int N, int K, int ldc, const EpiArgs& ep) {          //
 
 extern "C" {
 
+// -> 1: not a launch of the weight-stationary kernel (the caller goes on); otherwise the launch's status.  AP_GEMM_WS=0: never
+static int ws_try(const bf16_t* A, int lda, const bf16_t* B, int ldb, bf16_t* C, int ldc, int M, int N, int K, EpiArgs& ep, hipStream_t st) {
+    static int on = -1, ncu = 0;
+    if (on < 0) {
+        const char* e = getenv("AP_GEMM_WS"); on = (e && e[0] == '0') ? 0 : 1;
+        int dev = 0; hipDeviceProp_t pr;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    if (!on || K != WS_K || N % WS_BN || M % WS_BM || M < 16384 || (ldc & 15) || (lda & 7) || (ldb & 7)) return 1;
+    if (ep.dgelu_of || ep.mul_by || ep.row_scale || ep.residual || ep.q8) return 1;
+    int epi = -1;
+    if (ep.gelu == 3 && ep.preact && !ep.mul8) {
+        ep.gelu_tab = g8_gelu_table_ptr(st);
+        if (ep.gelu_tab) epi = 0;
+    } else if (!ep.gelu && ep.mul8 && !ep.bias) epi = 1;
+    if (epi < 0) return 1;
+    WsArgs a;
+    a.A = A; a.lda = lda; a.W = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N;
+    a.n_slices = N / WS_BN; a.n_items = M / WS_BM;
+    if (a.n_slices > ncu / 8) return 1;
+    a.per_xcd = (ncu / 8) / a.n_slices;                           // tile streams per XCD: 10 for three slices on 32 CUs (two CUs per XCD stay idle)
+    const int grid = ncu & ~7;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_gemm_nt_ws<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES(0));
+        (void)hipFuncSetAttribute((const void*)k_gemm_nt_ws<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES(1));
+        attr = true; (void)hipGetLastError();
+    }
+    if (epi == 0) hipLaunchKernelGGL(k_gemm_nt_ws<0>, dim3(grid), dim3(512), WS_LDS_BYTES(0), st, a, ep);
+    else hipLaunchKernelGGL(k_gemm_nt_ws<1>, dim3(grid), dim3(512), WS_LDS_BYTES(1), st, a, ep);
+    return ap_check_launch();
+}
+
 int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C, int ldc, int M, int N, int K,
                const ap_gemm_epilogue* epi, ap_stream_t stream) {
     if (!A || !B || !C) return AP_ERR_NULL;
@@ -943,6 +977,8 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
         hipLaunchKernelGGL(k_gemm_nt_skinny, dim3((N + 31) / 32, (M + 63) / 64), dim3(512), lds, (hipStream_t)stream, A, lda, B, ldb, C, ldc, M, N, K, ep);
         return ap_check_launch();
     }
+    // K = 192 with a GELU-table or a stored-derivative epilogue at many rows (the Outlooker's MLP): the weight-stationary kernel (gemm_ws.h)
+    if (const int rc = ws_try(A, lda, B, ldb, C, ldc, M, N, K, ep, (hipStream_t)stream); rc != 1) return rc;
     // tile selection (measured on the VOLO-D1 shape list, tools/bench_gemm.py): AP_GEMM_NT_TILE forces a variant
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("AP_GEMM_NT_TILE"); forced = e ? atoi(e) : 0; }

@@ -559,7 +559,7 @@ def main():
         except (OSError, ValueError):
             pass
         hbm_bound = ai < ridge
-        roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": "ap_gemm_nt launches (k_gemm_nt_8p<...> + k_gemm_nt<...>)",
+        roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": "ap_gemm_nt launches (k_gemm_nt_8p<...> + k_gemm_nt_ws<...> + k_gemm_nt<...>)",
                     "achieved": round(tbs * 1e3 if hbm_bound else tflops, 2), "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else round(peak_mfma, 1),
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
                     "frac": round(tbs / PEAK_HBM_TBS if hbm_bound else tflops / peak_mfma, 4), "traffic": traffic,

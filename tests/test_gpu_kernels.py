@@ -231,6 +231,46 @@ def test_gemm_nt_224_row_tiles(ops, M, K):
     assert torch.equal(out.cpu()[dropped], res[dropped])            # dropped samples pass the residual through exactly
 
 
+@pytest.mark.parametrize("M,N", [(16384, 576), (25088 * 4, 576), (20480, 192), (16448, 384)])
+def test_gemm_nt_weight_stationary_k192(ops, M, N):
+    """round 5: csrc/gemm_ws.h, the weight-stationary kernel for K = 192 (the Outlooker's MLP, models/volo.py:156-163 at the 192-channel
+    stage: fc1 + GELU with the 8-bit derivative codes, and the input gradient of fc2 times those codes), taken from 16384 rows on.  Against
+    fp64 (outputs TOL_BF16, codes within one step of the fp64 derivative) -- and BIT-EQUAL to the 8-phase kernel, which the same problem
+    cut into 8192-row pieces still runs on: same K order, same rounding points."""
+    import torch.nn.functional as F
+    K = 192
+    a, w = rnd(M, K, seed=1), rnd(N, K, scale=K ** -0.5, seed=2)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3)) * 0.3
+    da, dw_, db = dev(a), dev(w), dev(bias)
+    codes = torch.empty(M, N, device="cuda", dtype=torch.uint8)
+    y = ops.gemm_nt(da, dw_, bias=db, gelu=True, preact_out=codes, preact_grad=2)
+    h = (a.double() @ w.double().t() + bias.double()).to(torch.bfloat16).double()
+    assert rel(y, F.gelu(h)) < TOL_BF16
+    hg = h.clone().requires_grad_(True)
+    F.gelu(hg).sum().backward()
+    want = torch.clamp(torch.round(hg.grad * ops.GELU_CODE_SCALE) + ops.GELU_CODE_ZERO, 0, 255)
+    # the kernel rounds its own fp32 accumulation of h to bf16: where that lands on the other side of a rounding tie the fp64 code differs by more
+    dcode = (codes.cpu().double() - want).abs()
+    assert float((dcode <= 1).double().mean()) > 0.999 and float(dcode.max()) < 6
+    mul = torch.randint(0, 256, (M, N), dtype=torch.uint8, generator=torch.Generator().manual_seed(4))
+    dmul = dev(mul)
+    d = ops.gemm_nt(da, dw_, mul_by=dmul)
+    assert rel(d, (a.double() @ w.double().t()) * ((mul.double() - ops.GELU_CODE_ZERO) / ops.GELU_CODE_SCALE)) < TOL_BF16
+    # the same problem in pieces below the kernel's row threshold (-> the 8-phase kernel, unless an environment-switch run has taken it away)
+    if os.environ.get("AP_GEMM_8P", "1") == "0":
+        return
+    ys, cs, ds = [], [], []
+    cuts = list(range(0, M, 8192)) + [M]
+    if cuts[-1] - cuts[-2] < 4096:            # (a last piece of fewer than 4096 rows would leave the 8-phase kernel too: it joins the one before)
+        del cuts[-2]
+    for m0, m1 in zip(cuts[:-1], cuts[1:]):
+        c = torch.empty(m1 - m0, N, device="cuda", dtype=torch.uint8)
+        ys.append(ops.gemm_nt(da[m0:m1].contiguous(), dw_, bias=db, gelu=True, preact_out=c, preact_grad=2))
+        cs.append(c)
+        ds.append(ops.gemm_nt(da[m0:m1].contiguous(), dw_, mul_by=dmul[m0:m1].contiguous()))
+    assert torch.equal(y, torch.cat(ys)) and torch.equal(codes, torch.cat(cs)) and torch.equal(d, torch.cat(ds))
+
+
 @pytest.mark.parametrize("M,N1,N2", [(1024, 128, 128), (1000, 192, 576), (3000, 486, 192), (25088 // 8, 1152, 384), (130, 1000, 384),
                                      (77, 32, 96), (500, 16, 64)])
 def test_gemm_tn_acc(ops, M, N1, N2):
@@ -698,7 +738,7 @@ def test_grouped_wgrad_launch_carries_the_layernorm_reductions(ops):
 
 @pytest.mark.parametrize("env", [{"AP_MHSA_FLASH": "1"}, {"AP_MHSA_BWD_DS": "0", "AP_MHSA_FWD_P": "0"}, {"AP_GEMM_LDS_EPI": "1"}, {"AP_GEMM_LDS_EPI": "0"}, {"AP_OUTLOOK_MFMA": "0"},
                                  {"AP_STEM_HIP_CONV": "0"}, {"AP_ASYNC_WGRAD": "1"}, {"AP_GEMM_TN_PLACE": "0"}, {"AP_FUSE_LN_REDUCE": "0"}, {"AP_CONV_WGRAD_P": "0"},
-                                 {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}, {"AP_GELU_STORE_GRAD": "0"}, {"AP_GELU_STORE_GRAD": "1"}, {"AP_LN_BWD_PF": "0"}, {"AP_GEMM_BM224": "0"}, {"AP_GELU_TABLE": "0"}, {"AP_FUSE_POOL_BWD": "0"}, {"AP_STEM_FUSE_BN_PROJ": "0"}, {"AP_STEM_FUSE_BN_BWD_STATS": "0"}, {"AP_BN_PROJ_ACT_IN_BWD": "0"}, {"AP_WGRAD_WINDOW": "0"}, {"AP_STEM_FUSE_BN": "0"},
+                                 {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}, {"AP_GELU_STORE_GRAD": "0"}, {"AP_GELU_STORE_GRAD": "1"}, {"AP_LN_BWD_PF": "0"}, {"AP_GEMM_BM224": "0"}, {"AP_GEMM_WS": "0"}, {"AP_GELU_TABLE": "0"}, {"AP_FUSE_POOL_BWD": "0"}, {"AP_STEM_FUSE_BN_PROJ": "0"}, {"AP_STEM_FUSE_BN_BWD_STATS": "0"}, {"AP_BN_PROJ_ACT_IN_BWD": "0"}, {"AP_WGRAD_WINDOW": "0"}, {"AP_STEM_FUSE_BN": "0"},
                                  {"AP_OUTLOOK_P": "0"}, {"AP_OUTLOOK_P": "2"}, {"AP_LN_FWD_LP": "0"}, {"AP_CONV_WAVES": "4"}])
 def test_experimental_kernel_paths_stay_parity_green(env):
     """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:

@@ -33,14 +33,14 @@ txt = open("gpurun_out/%s_pmc_counters.txt" % R).read()
 blocks = re.split(r"\n(?=\S)", txt)
 fetch = write = n = 0.0
 for b in blocks:
-    if b.startswith("void k_gemm_nt<") or b.startswith("void k_gemm_nt_8p<") or b.startswith("k_gemm_nt_skinny"):
+    if b.startswith("void k_gemm_nt<") or b.startswith("void k_gemm_nt_8p<") or b.startswith("void k_gemm_nt_ws<") or b.startswith("k_gemm_nt_skinny"):
         mf = re.search(r"FETCH_SIZE\s+avg\s+([\d.]+)\s+over (\d+)", b); mw = re.search(r"WRITE_SIZE\s+avg\s+([\d.]+)", b)
         if mf and mw:
             k = int(mf.group(2)); fetch += float(mf.group(1)) * k; write += float(mw.group(1)) * k; n += k
 if n:
     per = (2.0 * fetch + write) / n * 1024.0
     import bench
-    json.dump({"kernel": "k_gemm_nt_8p + k_gemm_nt (all instantiations)", "hbm_bytes_per_launch": round(per), "launches": int(n),
+    json.dump({"kernel": "k_gemm_nt_8p + k_gemm_nt_ws + k_gemm_nt (all instantiations)", "hbm_bytes_per_launch": round(per), "launches": int(n),
                "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB per dispatch, dispatch-weighted over the k_gemm_nt* instantiations",
                "source": "profiles/%s_pmc_counters.txt" % R, "src_sha256": bench.kernel_source_hash()}, open("gpurun_out/gemm_nt_traffic.json", "w"))
 PY
