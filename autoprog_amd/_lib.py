@@ -19,6 +19,14 @@ class GemmEpilogue(Structure):
                 ("mul_by8", c_void_p), ("q8_out", c_void_p), ("q8_scale", c_void_p), ("q8_amax", c_void_p)]
 
 
+class MlpFusedArgs(Structure):
+    """ap_mlp_fused_args (include/autoprog_hip.h)"""
+    _fields_ = [("x", c_void_p), ("ldx", c_int), ("wa", c_void_p), ("ldwa", c_int), ("wb", c_void_p), ("ldwb", c_int), ("out", c_void_p), ("ldo", c_int),
+                ("hidden_out", c_void_p), ("ldh", c_int), ("codes", c_void_p), ("bias1", c_void_p), ("bias2", c_void_p),
+                ("row_scale_hidden", c_void_p), ("row_scale_out", c_void_p), ("rows_per_scale", c_int), ("residual", c_void_p), ("ldr", c_int),
+                ("m", c_int), ("c", c_int), ("hidden", c_int), ("backward", c_int)]
+
+
 class TnProblem(Structure):
     """ap_tn_problem (include/autoprog_hip.h)"""
     _fields_ = [("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int), ("C", c_void_p), ("ldc", c_int),
@@ -127,8 +135,12 @@ _SIGNATURES["ap_conv3x3_c128_wgrad"] = (_I, [_P, _P, _P, _I, _I, _I, _P, ctypes.
 # ap_sum_reps_acc(x, out, n, reps, stream)
 _SIGNATURES["ap_sum_reps_acc"] = (_I, [_P, _P, _L, _I, _P])
 
+_SIGNATURES["ap_mlp_fused"] = (_I, [POINTER(MlpFusedArgs), _P])
+_SIGNATURES["ap_calib_copy"] = (_I, [_P, _P, _L, _P])
+_SIGNATURES["ap_calib_mfma"] = (_I, [_P, _P, _I, _P])
+
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
-EXPECTED_ABI = 6                     # ap_abi_version() of the library these ctypes Structures mirror (include/autoprog_hip.h)
+EXPECTED_ABI = 7                     # ap_abi_version() of the library these ctypes Structures mirror (include/autoprog_hip.h)
 
 
 class AutoProgHipError(RuntimeError):

@@ -401,9 +401,45 @@ k_droppath_masks(const float* __restrict__ u, const float* __restrict__ keep, fl
     }
 }
 
+__device__ __forceinline__ bf16x8 as_bf16x8_calib(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+// ---- in-process calibration of the box a benchmark runs on (bench.py `calibration`): the boxes of a pool differ by
+// +-2-4 % in step time, so a bench line carries what THIS device delivers on two fixed probes -- a float4 copy (HBM) and a register-only
+// MFMA loop on random operands (matrix pipe at the clock the chip holds under load) -- and round-over-round changes are quoted against them.
+__global__ void __launch_bounds__(256) k_calib_copy(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int64_t n16) {
+    // a workgroup per 16 KB: four 16-byte loads per lane in flight, then the four stores
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    u32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (base + j * 256 < n16) v[j] = __builtin_nontemporal_load(src + base + j * 256);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (base + j * 256 < n16) __builtin_nontemporal_store(v[j], dst + base + j * 256);
+}
+// one wave per SIMD, 16 independent accumulators, operands in registers: 16 x v_mfma_f32_16x16x32_bf16 per trip
+__global__ void __launch_bounds__(256, 1) k_calib_mfma(const bf16_t* __restrict__ seed, float* __restrict__ sink, int iters) {
+    const int lane = threadIdx.x & 63;
+    u32x4 a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const u32x4*>(seed + (i * 64 + lane) * 8);
+        b[i] = *reinterpret_cast<const u32x4*>(seed + ((2 + i) * 64 + lane) * 8);
+    }
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8_calib(a[i & 1]), as_bf16x8_calib(b[(i >> 1) & 1]), acc[i], 0, 0, 0);
+    }
+    f32x4 s = acc[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) s += acc[i];
+    if (s[0] + s[1] + s[2] + s[3] == 123456.789f) sink[0] = s[0];        // (keeps the loop alive; never true on the seeds bench.py passes)
+}
+
 extern "C" {
 
-int ap_abi_version(void) { return 6; }
+int ap_abi_version(void) { return 7; }
 
 const char* ap_error_string(int code) {
     switch (code) {
@@ -574,6 +610,21 @@ int ap_colsum_acc(const ap_bf16* A, int lda, float* out, int M, int N, ap_stream
     const int rows_per_block = (M + gy - 1) / gy;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_colsum_acc, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, A, lda, out, M, N, rows_per_block);
+    return ap_check_launch();
+}
+
+int ap_calib_copy(const void* src, void* dst, int64_t bytes, ap_stream_t stream) {
+    if (!src || !dst) return AP_ERR_NULL;
+    if (bytes <= 0 || (bytes & 15)) return AP_ERR_SHAPE;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_calib_copy, dim3((unsigned)((bytes / 16 + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (u32x4*)dst, bytes / 16);
+    return ap_check_launch();
+}
+int ap_calib_mfma(const ap_bf16* seed, float* sink, int iters, ap_stream_t stream) {
+    if (!seed || !sink) return AP_ERR_NULL;
+    if (iters <= 0) return AP_ERR_SHAPE;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_calib_mfma, dim3(256), dim3(256), 0, (hipStream_t)stream, seed, sink, iters);
     return ap_check_launch();
 }
 

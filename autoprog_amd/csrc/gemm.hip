@@ -20,6 +20,7 @@
 // fragments are fetched with ds_read_b64_tr_b16 (hardware transpose) from row-major [64 tok][128]
 // LDS tiles; the chunk swizzle f(row) keeps those transposed reads conflict free.  The token range
 // is split across blockIdx.z and partial tiles are added with fp32 atomics (few MB per call).
+#include <mutex>
 #include "common.h"
 #include <type_traits>
 #include "gemm_epi.h"
@@ -766,17 +767,29 @@ __global__ void __launch_bounds__(256) k_build_gelu_table(unsigned* tab) {
     const unsigned idx = blockIdx.x * 256 + threadIdx.x;
     if (idx < 2 * GQ_TAB_N) tab[idx] = gq_tab_entry(idx);
 }
-static const unsigned* g8_gelu_table_ptr(hipStream_t st) {
-    static int state = 0;                       // 0: not built, 1: built, -1: switched off
-    static unsigned* ptr = nullptr;
-    if (state == 0) {
+// (not static: csrc/mlp_fused.hip reads the same table; declared in gemm_epi.h)
+// Built once per device, synchronously (the build used to be enqueued on the stream of its first use -- if that first use sat inside
+// a stream capture the kernel was only RECORDED and later eager launches read an unbuilt table; launches on another stream had no dependency
+// on it).  While `st` is capturing nothing can be built or waited for: the caller gets nullptr and takes the arithmetic path for that launch.
+const unsigned* g8_gelu_table_ptr(hipStream_t st) {
+    static std::mutex mu;
+    static int state[16] = {0};                 // per device -- 0: not built, 1: built, -1: switched off
+    static unsigned* ptr[16] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lock(mu);
+    if (state[dev] == 0) {
         const char* e = getenv("AP_GELU_TABLE");
-        if (e && e[0] == '0') { state = -1; return nullptr; }
-        if (hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(g8_gelu_table)) != hipSuccess || !ptr) { (void)hipGetLastError(); state = -1; return nullptr; }
-        hipLaunchKernelGGL(k_build_gelu_table, dim3(2 * GQ_TAB_N / 256), dim3(256), 0, st, ptr);
-        state = 1;
+        if (e && e[0] == '0') { state[dev] = -1; return nullptr; }
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs != hipStreamCaptureStatusNone) return nullptr;
+        if (hipGetSymbolAddress(reinterpret_cast<void**>(&ptr[dev]), HIP_SYMBOL(g8_gelu_table)) != hipSuccess || !ptr[dev]) { (void)hipGetLastError(); state[dev] = -1; return nullptr; }
+        hipLaunchKernelGGL(k_build_gelu_table, dim3(2 * GQ_TAB_N / 256), dim3(256), 0, st, ptr[dev]);
+        if (hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); state[dev] = -1; return nullptr; }
+        state[dev] = 1;
     }
-    return state == 1 ? ptr : nullptr;
+    return state[dev] == 1 ? ptr[dev] : nullptr;
 }
 
 // launch of the persistent 8-phase kernel (gemm8p.h): one instantiation per epilogue flavour of the training step, a generic one
@@ -1026,6 +1039,9 @@ int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C,
     }
     // variants 20 / 21: the persistent 8-phase kernel of gemm8p.h with 256 x 192 / 256 x 256 tiles (whole 8-column chunks only)
     if ((variant == 20 || variant == 21) && ((K & 63) || (N & 7) || (ldc & 7) || (ep.residual && (ep.ldr & 7)))) variant = 1;
+    // q8_out exists in the 8-phase kernel's G8_Q8 flavours only: a forced tile (AP_GEMM_NT_TILE), a rule (AP_GEMM_NT_RULE), AP_GEMM_NT_192 or
+    // the fallback above may have picked a kernel that never writes it -- refused here, AFTER the choice, not silently skipped
+    if (ep.q8 && variant != 20 && variant != 21) return AP_ERR_UNSUPPORTED;
     if (variant == 20 || variant == 21) {
         if (ep.gelu == 3) ep.gelu_tab = g8_gelu_table_ptr((hipStream_t)stream);
         return g8_launch(variant == 20 ? 192 : 256, A, lda, B, ldb, C, ldc, M, N, K, ep, (hipStream_t)stream);

@@ -94,6 +94,8 @@ __device__ __forceinline__ unsigned gq_tab_entry(unsigned idx) {
     const float gp = fmaf(h * 0.39894228040143268f, e, c);
     return ((__float_as_uint(c) + 0x80u) & 0xffffff00u) | gq_code(gp);
 }
+// the table in global memory (built on first use, csrc/gemm.hip); nullptr: AP_GELU_TABLE=0, or `st` is being captured before a first build
+const unsigned* g8_gelu_table_ptr(hipStream_t st);
 // table index of a bf16 bit pattern held in bits [SH, SH + 16) of w
 template <int SH>
 __device__ __forceinline__ int gq_tab_index(unsigned w) {

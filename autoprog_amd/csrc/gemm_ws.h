@@ -7,9 +7,10 @@
 // launch is its epilogue, and a persistent launch runs K loop and epilogue one after the other in every CU at once.  Here the WEIGHTS stay:
 // a wave keeps its 48 columns of a 192-column slice of W as MFMA fragments in registers for the whole kernel and the workgroup streams
 // 64-row tiles of A through them -- rows two tiles ahead in flight, the finished tile leaving through an LDS staging pass as whole 16-byte
-// row chunks.  Measured (tools/check_ws.py, rotating buffers, bit-identical results): 100352 x 576 fc1 + GELU 66 -> 66 us, times the codes
-// 63 -> 56; 16384 x 192 14.1 -> 10.8 / 11.4 -> 9.6; 32768 .. 73728 x 576 (the early AutoProg stages) -5 % .. +12 %; 204800 x 576 147 -> 137 /
-// 113 -> 104; D1 step 11.97 / 11.98 / 11.98 -> 11.91 / 11.92 / 11.91 ms (this kernel needs 64 - 72 KB of LDS, not all 160: the next launch starts
+// row chunks.  Measured with the three workgroups of a 64-row tile on ONE XCD (tools/check_ws.py, rotating buffers, bit-identical results;
+// DESIGN.md section 3 "Round 5"): 100352 x 576 fc1 + GELU 66.0 -> 62.1 us, times the codes 63.9 -> 52.7; 16384 x 192 14.1 -> 10.7 / 11.4 -> 8.5;
+// 32768 and 73728 x 576 (the early AutoProg stages) 26.0 -> 25.8 / 22.5 -> 18.6 and 50.5 -> 48.6 / 48.1 -> 41.2; 204800 x 576 145.8 -> 133.4 /
+// 113.2 -> 96.3; in the D1 step 72.0 -> 59.4 and 61.5 -> 50.8 us (this kernel needs 64 - 72 KB of LDS, not all 160: the next launch starts
 // on a CU before the last workgroup has left it).  What it did NOT do is reach the 35 us the 212 MB of the large shape need: with loads,
 // stores, MFMAs and table lookups ablated one by one (WS_ABL) no single one is worth more than 15 us and the bare skeleton is 35 -- the
 // row phase and the staging pass through LDS cost what they cost in the 8-phase kernel.

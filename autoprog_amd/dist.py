@@ -233,11 +233,14 @@ def reduce_scalar_mean(t, world_size, group=None):
     return rt
 
 
-def distribute_bn(model, world_size, reduce=False, group=None):
+def distribute_bn(model, world_size, reduce=False, group=None, named_buffers=None):
     """timm.utils.distribute_bn as main_prog.py:883-887 calls it after every epoch (`--dist-bn reduce | broadcast`): every rank gets the
     same BatchNorm running means / variances -- averaged over the ranks (reduce) or rank 0's (broadcast).  timm issues one collective
-    per buffer; here the buffers (six vectors of the stem's width for VOLO) travel as ONE flat message and are scattered back."""
-    bufs = [b for n, b in model.named_buffers() if ("running_mean" in n or "running_var" in n)]
+    per buffer; here the buffers (six vectors of the stem's width for VOLO) travel as ONE flat message and are scattered back.
+    named_buffers: (name, tensor) pairs to use instead of model.named_buffers() -- the EMA copies of the buffers live in the flat
+    optimizer (FlatAdamWEma.ema_buffers), not in modules of their own (main_prog.py:899, 1650-1654: distribute_bn(model_ema_list[idx]))."""
+    src = model.named_buffers() if named_buffers is None else named_buffers
+    bufs = [b for n, b in src if ("running_mean" in n or "running_var" in n)]
     if world_size <= 1 or not bufs:
         return
     flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
@@ -252,4 +255,3 @@ def distribute_bn(model, world_size, reduce=False, group=None):
             n = b.numel()
             b.copy_(flat[off:off + n].view_as(b).to(b.dtype))
             off += n
-

@@ -374,6 +374,12 @@ def _launch_wgrads(problems, ln=None):
 STORE_GELU_GRAD = int(os.environ.get("AP_GELU_STORE_GRAD", "2"))
 
 
+# Round 6: the MLP of a transformer block as ONE launch per direction (csrc/mlp_fused.hip; C = 384, whole 128-row blocks).  Bit-identical to the
+# two launches it replaces and, measured, SLOWER than them (DESIGN.md section 3 "Round 6": 111 against 80 us forward, 81 against 65 backward at
+# 25088 rows): off by default, kept behind AP_FUSED_MLP=1 with its parity tests.
+FUSED_MLP = os.environ.get("AP_FUSED_MLP", "0") == "1"
+
+
 def _gelu_bwd_kw(h):
     return {"mul_by": h} if STORE_GELU_GRAD else {"dgelu_of": h}
 
@@ -641,9 +647,17 @@ class TransformerBlockFn(torch.autograd.Function):
             o, lse = ops.mhsa_fwd(qkv, B, N, heads, scale, out_row_scale=k1)                   # rows of dropped samples: zeros
         x1 = _linear_fwd(o, proj_w, x8=oq, bias=proj_b, row_scale=rs1, rows_per_scale=N, residual=x2)
         xn2, m2, r2, xq = _ln_fwd_for(x1, n2w, n2b, eps, fc1_w)
-        h = _gelu_side_buffer(B * N, fc1_w.shape[0], x.device)
-        a, aq = _linear_fwd(xn2, fc1_w, x8=xq, emit_for=fc2_w, bias=fc1_b, gelu=True, preact_out=h, preact_grad=STORE_GELU_GRAD, row_scale=k2, rows_per_scale=N)
-        y = _linear_fwd(a, fc2_w, x8=aq, bias=fc2_b, row_scale=rs2, rows_per_scale=N, residual=x1)
+        fused = None
+        if FUSED_MLP and STORE_GELU_GRAD == 2 and not FP8_LINEAR and ops.mlp_fused_ok(B * N, C, fc1_w.shape[0]):
+            # fc1 -> GELU -> fc2 (+ DropPath scale + residual) in ONE launch (csrc/mlp_fused.hip): bit-identical to the two launches below
+            fused = ops.mlp_fused(xn2, bank.get(fc1_w), bank.get(fc2_w), bias1=fc1_b, bias2=fc2_b, row_scale_hidden=k2, row_scale_out=rs2,
+                                  rows_per_scale=N, residual=x1)
+        if fused is not None:
+            y, a, h = fused
+        else:
+            h = _gelu_side_buffer(B * N, fc1_w.shape[0], x.device)
+            a, aq = _linear_fwd(xn2, fc1_w, x8=xq, emit_for=fc2_w, bias=fc1_b, gelu=True, preact_out=h, preact_grad=STORE_GELU_GRAD, row_scale=k2, rows_per_scale=N)
+            y = _linear_fwd(a, fc2_w, x8=aq, bias=fc2_b, row_scale=rs2, rows_per_scale=N, residual=x1)
         if rs1 is not None and tm1 is None:
             tm1 = token_mask(k1, N)
         if rs2 is not None and tm2 is None:
@@ -665,6 +679,7 @@ class TransformerBlockFn(torch.autograd.Function):
         with wgrad_batch(sunk, params) as batch:         # the four weight gradients (and the two LayerNorm parameter gradients) launch together: on exit, or with the window's
             # MLP branch
             dh8 = None
+            dxn2 = None
             if FP8_LINEAR and FP8_DGRAD and h.shape[1] % 16 == 0 and h.shape[1] == fc1_w.shape[0]:
                 # dL/dh as e4m3 next to its bf16 form (the weight gradient keeps reading that): from the launch's epilogue once the site has a
                 # scale (its second step on), by a pass of its own before
@@ -677,8 +692,18 @@ class TransformerBlockFn(torch.autograd.Function):
                     dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, row_scale=rs2, rows_per_scale=N, cs_weight=tm2, inv_keep=inv_keep, **_gelu_bwd_kw(h))
                     dh8 = fp8_scales.quantize(("g", id(fc1_w)), dh)
             else:
-                dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, row_scale=rs2, rows_per_scale=N, cs_weight=tm2, inv_keep=inv_keep, **_gelu_bwd_kw(h))
-            dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b, g8=dh8)
+                fused = None
+                if FUSED_MLP and h.dtype == torch.uint8 and ops.mlp_fused_ok(dy2.shape[0], dy2.shape[1], h.shape[1]):
+                    # both input-gradient products of the MLP in one launch; the weight gradients read dL/dh and dL/dy as before
+                    fused = ops.mlp_fused(dy2, bank.get_t(fc2_w), bank.get_t(fc1_w), backward=True, codes=h, row_scale_hidden=rs2, rows_per_scale=N)
+                if fused is not None:
+                    dxn2, dh, _ = fused
+                    _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, need_dx=False, cs_weight=tm2, inv_keep=inv_keep)
+                    _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b, need_dx=False)
+                else:
+                    dh = _linear_bwd(dy2, a, fc2_w, dfc2_w, dfc2_b, row_scale=rs2, rows_per_scale=N, cs_weight=tm2, inv_keep=inv_keep, **_gelu_bwd_kw(h))
+            if dxn2 is None:
+                dxn2 = _linear_bwd(dh, xn2, fc1_w, dfc1_w, dfc1_b, g8=dh8)
             dx1 = ops.layernorm_bwd(dxn2, x1, n2w, m2, r2, dy2, dn2w, dn2b, defer=batch.ln)
             # attention branch
             do = _linear_bwd(dx1, o, proj_w, dproj_w, dproj_b, row_scale=rs1, rows_per_scale=N, cs_weight=tm1, inv_keep=inv_keep)

@@ -30,14 +30,36 @@ class StepScalars:
          int32 [0..3]  mix-token box on the token-label grid: bbx1, bbx2, bby1, bby2 (rows [bbx1, bbx2), columns [bby1, bby2))
          fp32  [4]     lam of the loss = 1 - box area / N
          fp32  [5..7]  learning rate, 1 - beta1^t, sqrt(1 - beta2^t)
-       The host side is a pinned buffer; push() is one asynchronous copy on the current stream."""
+       The host side is a RING of pinned 64-byte slots: push() is one asynchronous copy of the slot being prepared, and a pinned
+       copy reads its source when it EXECUTES on the GPU, not when it is enqueued -- with one slot the host, which runs many replays
+       ahead of the GPU (a replay costs it tens of microseconds, the step milliseconds), would overwrite step t's scalars with
+       step t + k's before the copy of step t has run.  begin() takes the next slot and waits for the event recorded
+       behind that slot's last copy, so the host runs at most SLOTS - 1 steps ahead of the copies."""
+    SLOTS = 8
 
     def __init__(self, device):
-        self.host = torch.zeros(16, dtype=torch.int32).pin_memory()
+        self.ring = torch.zeros(self.SLOTS, 16, dtype=torch.int32).pin_memory()
+        self.events = [None] * self.SLOTS
+        self.slot = 0
         self.dev = torch.zeros(16, dtype=torch.int32, device=device)
-        self._hf = self.host.view(torch.float32)
+        self._bind()
         self._hf[4] = 1.0
         self.push()
+
+    def _bind(self):
+        self.host = self.ring[self.slot]
+        self._hf = self.host.view(torch.float32)
+
+    def begin(self):
+        """start preparing a step: the next slot of the ring, once the copy that last read it has executed; the values of the
+        previous step carry over (a caller may set only the box or only the optimizer scalars)"""
+        prev = self.host
+        self.slot = (self.slot + 1) % self.SLOTS
+        ev = self.events[self.slot]
+        if ev is not None:
+            ev.synchronize()
+        self._bind()
+        self.host.copy_(prev)
 
     @property
     def box_ptr(self):
@@ -66,6 +88,11 @@ class StepScalars:
 
     def push(self):
         self.dev.copy_(self.host, non_blocking=True)
+        if self.dev.is_cuda:
+            ev = self.events[self.slot]
+            if ev is None:
+                ev = self.events[self.slot] = torch.cuda.Event()
+            ev.record()
 
 
 class DeviceBox:
@@ -107,6 +134,7 @@ class GraphedStep:
         self.scalars.set_box(box, n)
 
     def _prepare(self):
+        self.scalars.begin()
         self._draw()
         o = self.opt
         self.scalars.set_adam(o.param_groups[0]["lr"], o.betas[0], o.betas[1], o.step_count + 1)
@@ -122,6 +150,8 @@ class GraphedStep:
 
     def capture(self, warmup=3):
         self.model.step_scalars = self.scalars
+        if self.clip_grad is not None and float(self.clip_grad) > 0 and self.clip_mode == "norm":
+            self.opt._clip_workspace(self.images.device)          # (never first allocated inside the capture: optim.FlatAdamWEma._clip_workspace)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):

@@ -51,6 +51,24 @@ def round_up(v, m):
     return (v + m - 1) // m * m
 
 
+# ------------------------------------------------------------------------------- calibration probes (bench.py `calibration`)
+def calib_copy(src, dst):
+    """dst <- src, 16 bytes per lane (the float4 copy the HBM figure of MI355X_MICROARCH.md is quoted on)"""
+    if not (src.is_cuda and dst.is_cuda and src.is_contiguous() and dst.is_contiguous()) or src.numel() * src.element_size() != dst.numel() * dst.element_size():
+        raise AutoProgHipError("calib_copy: two contiguous CUDA tensors of equal size")
+    check(lib.ap_calib_copy(src.data_ptr(), dst.data_ptr(), src.numel() * src.element_size(), _stream()), "ap_calib_copy")
+
+
+def calib_mfma(seed, sink, iters):
+    """register-only bf16 MFMA loop on every CU; -> FLOP of the launch"""
+    _req(seed, BF16, "seed")
+    _req(sink, torch.float32, "sink")
+    if seed.numel() < 2048:
+        raise AutoProgHipError("calib_mfma: seed holds at least 2048 bf16")
+    check(lib.ap_calib_mfma(seed.data_ptr(), sink.data_ptr(), int(iters), _stream()), "ap_calib_mfma")
+    return 256.0 * 4 * iters * 16 * 16384
+
+
 # ------------------------------------------------------------------------------------ casts
 def cast_bf16(src):
     _req(src, torch.float32, "src")
@@ -188,6 +206,52 @@ def _gelu_mode(gelu, preact_grad, preact_out):
     if mode != 3 and preact_out is not None and preact_out.dtype != BF16:
         raise AutoProgHipError("gemm_nt: preact_out must be bf16 (uint8 only with preact_grad = 2)")
     return mode
+
+
+def mlp_fused_ok(M, C, hidden):
+    """does ap_mlp_fused take this MLP?  (csrc/mlp_fused.hip: C = 384, hidden = 3 C, whole 128-row blocks)"""
+    return C == 384 and hidden == 3 * C and M % 128 == 0 and M > 0
+
+
+def mlp_fused(x, wa, wb, backward=False, bias1=None, bias2=None, row_scale_hidden=None, row_scale_out=None, rows_per_scale=1,
+              residual=None, codes=None):
+    """the MLP of a block in one launch (include/autoprog_hip.h ap_mlp_fused).
+    forward : x [M, C], wa = fc1 weight [H, C], wb = fc2 weight [C, H] -> (out [M, C], a [M, H] = gelu(.) * row_scale_hidden, codes [M, H] uint8)
+    backward: x = dL/dout, wa = fc2 weight^T copy [H, ld(C)], wb = fc1 weight^T copy [C, ld(H)], codes = the forward's -> (dL/dx [M, C], dL/dh [M, H], codes)
+    -> None when the library does not take the launch (the caller issues the two ap_gemm_nt launches)"""
+    from ._lib import MlpFusedArgs
+    _req(x, BF16, "x"); _req(wa, BF16, "wa"); _req(wb, BF16, "wb")
+    M, C = x.shape
+    H = wa.shape[0]
+    if not mlp_fused_ok(M, C, H):
+        return None
+    out = torch.empty((M, C), dtype=BF16, device=x.device)
+    hid = torch.empty((M, H), dtype=BF16, device=x.device)
+    if backward:
+        _req(codes, torch.uint8, "codes")
+    else:
+        codes = torch.empty((M, H), dtype=torch.uint8, device=x.device)
+    a = MlpFusedArgs()
+    a.x, a.ldx = x.data_ptr(), x.shape[1]
+    a.wa, a.ldwa = wa.data_ptr(), wa.shape[1]
+    a.wb, a.ldwb = wb.data_ptr(), wb.shape[1]
+    a.out, a.ldo = out.data_ptr(), C
+    a.hidden_out, a.ldh = hid.data_ptr(), H
+    a.codes = codes.data_ptr()
+    a.bias1 = _req(bias1, torch.float32, "bias1").data_ptr() if bias1 is not None else None
+    a.bias2 = _req(bias2, torch.float32, "bias2").data_ptr() if bias2 is not None else None
+    a.row_scale_hidden = _req(row_scale_hidden, torch.float32, "row_scale_hidden").data_ptr() if row_scale_hidden is not None else None
+    a.row_scale_out = _req(row_scale_out, torch.float32, "row_scale_out").data_ptr() if row_scale_out is not None else None
+    a.rows_per_scale = int(rows_per_scale)
+    if residual is not None:
+        _req(residual, BF16, "residual")
+        a.residual, a.ldr = residual.data_ptr(), residual.shape[1]
+    a.m, a.c, a.hidden, a.backward = M, C, H, 1 if backward else 0
+    code = lib.ap_mlp_fused(ctypes.byref(a), _stream())
+    if code == -2:                    # AP_ERR_UNSUPPORTED (e.g. the GELU table cannot be built inside a stream capture)
+        return None
+    check(code, "ap_mlp_fused")
+    return out, hid, codes
 
 
 def gemm_nt_emits_q8(M, N, K, mul_by):

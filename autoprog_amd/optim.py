@@ -126,6 +126,16 @@ class FlatAdamWEma:
             check(lib.ap_batched_transpose_bf16(self.p16.data_ptr(), self.p16_t.data_ptr(), self._tr_desc.data_ptr(), self._tr_count,
                                                 self._tr_tiles, ops._stream()), "ap_batched_transpose_bf16")
 
+    def _clip_workspace(self, device):
+        """the norm's workspace, allocated OUTSIDE any stream capture: a tensor first allocated while a step is being captured
+        (GraphedStep(clip_grad=...).capture(warmup=0)) would come from that graph's private pool and then be shared with eager steps
+        and other graphs through this cache -- GraphedStep.capture() calls this before it starts capturing"""
+        if getattr(self, "_sumsq_ws", None) is None:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FlatAdamWEma: the clip-norm workspace must exist before a step is captured (call _clip_workspace first)")
+            self._sumsq_ws = torch.empty(lib.ap_sumsq_workspace() // 8, dtype=torch.float64, device=device)
+            self._gnorm_sq = torch.zeros(1, dtype=torch.float32, device=device)
+
     def step(self, clip_grad=None, clip_mode="norm", scalars=None):
         """one AdamW + EMA update from the gradient slab.  clip_grad / clip_mode: the reference's `--clip-grad` / `--clip-mode`
         (main_prog.py:129-132; prog/scaler.py:60-68 calls timm's dispatch_clip_grad between backward and optimizer.step()):
@@ -147,9 +157,7 @@ class FlatAdamWEma:
         gnorm_ptr, max_norm, clip_value = None, 0.0, 0.0
         if clip_grad is not None and float(clip_grad) > 0:
             if clip_mode == "norm":
-                if getattr(self, "_sumsq_ws", None) is None:
-                    self._sumsq_ws = torch.empty(lib.ap_sumsq_workspace() // 8, dtype=torch.float64, device=g.device)
-                    self._gnorm_sq = torch.zeros(1, dtype=torch.float32, device=g.device)
+                self._clip_workspace(g.device)
                 check(lib.ap_sumsq_f32(g.data_ptr(), g.numel(), self._gnorm_sq.data_ptr(), self._sumsq_ws.data_ptr(), self._sumsq_ws.numel() * 8,
                                        ops._stream()), "ap_sumsq_f32")
                 gnorm_ptr, max_norm = self._gnorm_sq.data_ptr(), float(clip_grad)

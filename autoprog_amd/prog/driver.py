@@ -30,7 +30,7 @@ def _sync():
 class AutoProgDriver:
     def __init__(self, model, loss_fn, optimizer, reducer, get_batch, r_list, l_list, dp_list, grow_epochs, steps_per_epoch,
                  search_epochs=2, auto_grow=True, probe_batches=4, time_steps=4, seed=0, log=None, original_batch_splits=1,
-                 r_max=None, dist_bn="", use_graphs=False, graph_after=2):
+                 r_max=None, dist_bn="", use_graphs=False, graph_after=2, clip_grad=None, clip_mode="norm"):
         """model: supernet sized for l_list[-1] (e.g. volo_h12_l18); optimizer: FlatAdamWEma over it; reducer: its
         GradientBucketReducer; r_list / l_list / dp_list / grow_epochs: the stage schedule (prog/progressive.py:4-31);
         get_batch(r): a training batch (images at ANY size -- the stem resizes to r -- and a token-label target for r // 16).
@@ -45,9 +45,13 @@ class AutoProgDriver:
         configuration (autoprog_amd/graph.py: the per-step host scalars live in device memory) -- the early AutoProg stages
         (main_prog.py:973-974: every batch resized to the stage's r) are launch-gap bound on an MI355X, stage (9, 128) runs 5.9 -> 4.3 ms
         per step.  The first `graph_after` steps at a configuration run eagerly (lazy initialisations, the allocator's pools), the next
-        one is captured; a stage transition drops the graphs.  The steps of a search (a different sub-network every step) stay eager.
-        With DropPath off a graphed run is bit-identical to the eager one; with it the masks come from the same generator at replay time."""
+        one is captured; a stage transition drops the graphs.  The steps of a search (a different sub-network every step, main_prog.py:1824-1837)
+        replay one graph per candidate drawn (<= 9 per search), captured on the search supernet's slabs the same way.
+        With DropPath off a graphed run is bit-identical to the eager one; with it the masks come from the same generator at replay time.
+        clip_grad / clip_mode: the reference's --clip-grad / --clip-mode (main_prog.py:129-132, prog/scaler.py:60-68), applied inside the fused
+        optimizer step (FlatAdamWEma.step) of every update, eager or replayed."""
         self.use_graphs, self.graph_after = bool(use_graphs), int(graph_after)
+        self.clip_grad, self.clip_mode = clip_grad, clip_mode
         self._graphs, self._eager_seen = {}, {}
         self.original_batch_splits = int(original_batch_splits)
         self.dist_bn = dist_bn
@@ -126,7 +130,7 @@ class AutoProgDriver:
         images, target = self.get_batch(r)
         self.reducer.zero_grad()
         self._set_splits(1)
-        gs = GraphedStep(self.model, self.loss_fn, self.reducer, self.opt, images, target).capture(warmup=0)
+        gs = GraphedStep(self.model, self.loss_fn, self.reducer, self.opt, images, target, clip_grad=self.clip_grad, clip_mode=self.clip_mode).capture(warmup=0)
         self._graphs[key] = gs
         return gs.step().detach().clone()                          # the batch the graph was built on is this step's batch
 
@@ -135,12 +139,14 @@ class AutoProgDriver:
         the gradient exchange and the optimizer on the last one (`update`, main_prog.py:971,1026).  -> mean loss (device scalar)"""
         self._activate(l, r, dp)
         k = self.splits_for(l, r) if splits is None else splits
-        if (self.use_graphs and splits is None and k == 1 and getattr(self.reducer, "world", 1) == 1 and torch.cuda.is_available()):
+        # one micro-batch per update, one rank: the step replays from the HIP graph of its configuration -- the epoch loop's (l, r), and (round 6)
+        # every candidate of a search, which draws a different sub-network per step (main_prog.py:1824-1837): one graph per (l, r) drawn, at most
+        # len(rs) * len(ls) <= 9 per search, all on the search supernet's slabs; the first `graph_after` steps at a configuration stay eager
+        if (self.use_graphs and k == 1 and getattr(self.reducer, "world", 1) == 1 and torch.cuda.is_available()):
             loss = self._graph_step(l, r, dp)
             if loss is not None:
                 return loss
-        if self._graphs and getattr(self.model, "step_scalars", None) is not None:
-            self.model.step_scalars = None                            # an eager step between replays: host scalars again
+        self._eager()
         self.reducer.zero_grad()                  # (closes whatever update was open: the split count may change now)
         self._set_splits(k)
         total = None
@@ -150,8 +156,14 @@ class AutoProgDriver:
             (loss if k == 1 else loss / k).backward()
             self.reducer.finish()
             total = loss.detach() if total is None else total + loss.detach()
-        self.opt.step()
+        self.opt.step(clip_grad=self.clip_grad, clip_mode=self.clip_mode)
         return total if k == 1 else total / k
+
+    def _eager(self):
+        """an eager forward between replays (a step at a configuration without a graph yet, a probe, a timing pass): the mix-token box and
+        lam come from the host again, not from the device scalars of the last replayed graph"""
+        if self._graphs and getattr(self.model, "step_scalars", None) is not None:
+            self.model.step_scalars = None
 
     def _set_splits(self, k):
         if hasattr(self.reducer, "set_accumulate_steps"):
@@ -168,6 +180,7 @@ class AutoProgDriver:
     def _probe(self, cands, ema_index=0):
         """train-mode, no-grad loss of EMA copy `ema_index` on `probe_batches` batches per candidate (the reference's taylor0)"""
         out = {}
+        self._eager()
         with self.opt.ema_weights(ema_index), torch.no_grad():
             for (r, l) in cands:
                 self._activate(l, r, 0.0)
@@ -185,6 +198,7 @@ class AutoProgDriver:
         micro-batch.  Every timed pass is an update of ONE micro-batch whatever split count the last training step left in the
         reducer: each candidate's time then includes the gradient exchange, and the reducer is left between updates."""
         out = {}
+        self._eager()
         self.reducer.zero_grad()
         self._set_splits(1)
         for (r, l) in cands:
@@ -223,6 +237,7 @@ class AutoProgDriver:
                 for _ in range(per):
                     r, l = self.rng.choice(rs), self.rng.choice(ls)   # one config per step, identical on every rank (seeded)
                     self._train_step(l, r, dp_final, splits=self.original_batch_splits)     # main_prog.py:807: the search's split count
+            self._distribute_bn()                                     # main_prog.py:1634-1637: after every epoch of the search as well
         losses.append(self._probe(cands))
         mean_loss = {"r%d_l%d" % c: sum(p[c] for p in losses) / len(losses) for c in cands}
         step_time = {"r%d_l%d" % c: times[c] for c in cands}
@@ -263,8 +278,14 @@ class AutoProgDriver:
         return self.history
 
     def _distribute_bn(self):
-        """main_prog.py:883-887: `if args.distributed and args.dist_bn in ('broadcast', 'reduce')` after every training epoch"""
+        """main_prog.py:883-887: `if args.distributed and args.dist_bn in ('broadcast', 'reduce')` after every training epoch, :1634-1637
+        after every epoch of a search; and the same for each EMA copy (:895-899, :1650-1654 `distribute_bn(model_ema_list[idx], ...)`):
+        here the EMA copies of the BatchNorm buffers are tensors of the flat optimizer, one flat message per copy."""
         world = getattr(self.reducer, "world", 1)
         if world > 1 and self.dist_bn in ("broadcast", "reduce"):
             from ..dist import distribute_bn
-            distribute_bn(self.model, world, reduce=self.dist_bn == "reduce", group=self.reducer.group)
+            red = self.dist_bn == "reduce"
+            distribute_bn(self.model, world, reduce=red, group=self.reducer.group)
+            names = [n for n, _ in getattr(self.opt, "_float_buffers", [])]
+            for bufs in getattr(self.opt, "ema_buffers", []):
+                distribute_bn(None, world, reduce=red, group=self.reducer.group, named_buffers=list(zip(names, bufs)))

@@ -249,6 +249,55 @@ class GemmProbe:
         return len(self.records), ms, flops
 
 
+def calibrate(dev):
+    """what THIS device delivers on three fixed probes, measured in-process in front of the timed region (HIP events on the launch stream,
+    medians): the boxes of the pool differ by +-2-4 % in step time with identical code, so round-over-round changes are quoted against
+    these.  (a) a float4 copy of 512 MiB (HBM; MI355X_MICROARCH.md quotes 6.29 TB/s for it), (b) a register-only
+    v_mfma_f32_16x16x32_bf16 loop on random operands, one wave per SIMD on all 256 CUs (the matrix pipe at the clock the chip holds),
+    (c) the plain 25088 x 384 x 1152 product of the step (qkv of a transformer block) over a rotating set of operands (> 256 MiB)."""
+    from autoprog_amd import ops
+
+    def timed(fn, reps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        ev[0].record()
+        for i in range(reps):
+            fn(i)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
+        return ts[len(ts) // 2], ts[0]
+
+    t0 = time.perf_counter()
+    g = torch.Generator().manual_seed(7)
+    n = 512 << 20
+    src = torch.empty(n // 4, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    ops.calib_copy(src, dst)
+    copy_med, copy_min = timed(lambda i: ops.calib_copy(src, dst), 7)
+    del src, dst
+    seed = torch.randn(2048, generator=g).to(dev).to(torch.bfloat16)
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    iters = 4096
+    for _ in range(3):
+        flop = ops.calib_mfma(seed, sink, iters)
+    mfma_med, mfma_min = timed(lambda i: ops.calib_mfma(seed, sink, iters), 7)
+    M, N, K, R = 25088, 1152, 384, 6
+    a = [(torch.randn(M, K, generator=g) * 0.5).to(dev).to(torch.bfloat16) for _ in range(2)]
+    a = [a[i % 2].clone() for i in range(R)]
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dev).to(torch.bfloat16)
+    outs = [torch.empty(M, N, dtype=torch.bfloat16, device=dev) for _ in range(R)]      # 6 x (19 + 58) MB: every launch starts cold
+    for i in range(R):
+        ops.gemm_nt(a[i], w, out=outs[i])
+    gemm_med, gemm_min = timed(lambda i: ops.gemm_nt(a[i % R], w, out=outs[i % R]), 18)
+    torch.cuda.synchronize()
+    return {"float4_copy_tbs": round(2.0 * n / (copy_med * 1e-3) / 1e12, 3), "float4_copy_tbs_best": round(2.0 * n / (copy_min * 1e-3) / 1e12, 3),
+            "mfma_loop_tflops": round(flop / (mfma_med * 1e-3) / 1e12, 1), "mfma_loop_tflops_best": round(flop / (mfma_min * 1e-3) / 1e12, 1),
+            "gemm_25088x384x1152_plain_us": round(gemm_med * 1e3, 2), "gemm_25088x384x1152_plain_us_best": round(gemm_min * 1e3, 2),
+            "seconds": round(time.perf_counter() - t0, 2),
+            "how": "HIP events on the launch stream, medians (best beside them): 512 MiB float4 copy x7; 256 CUs x 4 waves x 4096 trips of 16 "
+                   "v_mfma_f32_16x16x32_bf16 on random operands x7; ap_gemm_nt 25088x1152x384 plain over 6 rotating operand sets x18"}
+
+
 def self_launch(n, argv):
     """start `torch.distributed.run --nproc-per-node n bench.py <argv>` as a child and return its exit code"""
     import socket
@@ -315,6 +364,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+loss+backward only")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous + gradient exchange only (CPU/gloo), no GPU work")
+    ap.add_argument("--prewarm-s", type=float, default=2.0,
+                    help="seconds of the SAME step run in front of the counted --warmup steps (reported as prewarm_s): a fresh lease starts "
+                         "with cold clocks and allocator pools, and 5 warm-up steps are 60 ms; never part of the timed region")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the in-process box calibration (copy / MFMA loop / one GEMM)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -475,20 +528,44 @@ def main():
             loss_fn(model(images), targets[r_]).backward()
             reducer.finish()
             reducer.take_pending_scale()
+    # ---- disclosed pre-warm: >= --prewarm-s seconds of the same step (untimed, reported), then the box calibration, then the counted warm-up
+    prewarm_steps, prewarm_s = 0, 0.0
+    if args.prewarm_s > 0:
+        tp = time.perf_counter()
+        while True:
+            for _ in range(8):
+                step()
+            prewarm_steps += 8
+            torch.cuda.synchronize()
+            prewarm_s = time.perf_counter() - tp
+            if prewarm_s >= args.prewarm_s:
+                break
+        if args.workload == "stages":
+            counter[0] = 0                       # (the stage walk of the timed region starts where it always did)
+            if args.graph:
+                gcount[0] = 0
+    calibration = None
+    if rank == 0 and not args.no_calibration:
+        calibration = calibrate(dev)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # per-step HIP-event times beside the wall clock (events on the stream the step launches on: one record per step)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_ev[0].record()
+    for i_ in range(args.steps):
         loss = step()
+        step_ev[i_ + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(step_ev[i_].elapsed_time(step_ev[i_ + 1]) for i_ in range(args.steps))
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -599,6 +676,9 @@ def main():
                   else "images/sec/GPU (fwd+bwd) VOLO-D1 224px AutoProg step")
         line = {"metric": metric, "value": round(value, 2), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+                "ms_per_step_min": round(step_ms[0], 3), "ms_per_step_median": round(step_ms[len(step_ms) // 2], 3), "ms_per_step_max": round(step_ms[-1], 3),
+                "ms_per_step_how": "value / ms_per_step: wall clock over the timed steps; min / median / max: HIP events recorded behind every step on the launch stream (rank 0)",
+                "prewarm_s": round(prewarm_s, 2), "prewarm_steps": prewarm_steps, "calibration": calibration,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "fp8 (e4m3 forward GEMMs) / bf16" if (args.fp8 and args.workload == "d5") else "bf16", "data": "synthetic",
                 "value_semantics": "whole-job aggregate over n_gpus (per-GPU rate in images_per_sec_per_gpu)",

@@ -40,6 +40,13 @@ enum {
 int ap_abi_version(void);
 const char* ap_error_string(int code);
 
+/* ---- calibration probes of the device a measurement runs on (no reference call site: bench.py `calibration`, next to the timing
+ * loop of main_prog.py:1007-1008,1061-1064).  ap_calib_copy: dst[0:bytes) = src[0:bytes) with 16 bytes per lane (bytes % 16 == 0);
+ * ap_calib_mfma: 256 workgroups x 4 waves, each `iters` trips of 16 independent v_mfma_f32_16x16x32_bf16 on operands read once from
+ * seed (>= 2048 bf16) -- 256 * 4 * iters * 16 * 16384 FLOP; sink receives nothing unless a sum hits a sentinel (keeps the loop alive) */
+int ap_calib_copy(const void* src, void* dst, int64_t bytes, ap_stream_t stream);
+int ap_calib_mfma(const ap_bf16* seed, float* sink, int iters, ap_stream_t stream);
+
 /* ---- precision plumbing (apex O1 casts, main_prog.py:491: fp32 master -> 16-bit) ------- */
 int ap_cast_f32_bf16(const float* src, ap_bf16* dst, int64_t n, ap_stream_t stream);
 int ap_cast_bf16_f32(const ap_bf16* src, float* dst, int64_t n, ap_stream_t stream);
@@ -130,10 +137,39 @@ typedef struct ap_gemm_epilogue {
                                 /* or one the 8-phase kernel does not take): the output a second time as OCP e4m3 bytes [M, ldc] --             */
     const float* q8_scale;      /* q8_out = sat(out * q8_scale[0]), q8_amax[0] = max(q8_amax[0], max |out|) (nullable) -- the operand of the */
     float* q8_amax;             /* fp8 GEMM that consumes this activation, without a quantisation pass.  Launches of the 8-phase kernel only */
-                                /* (M >= 4096, K % 128 == 0, N as for ap_gemm_nt): AP_ERR_UNSUPPORTED otherwise; ap_gemm_nt ignores them.   */
+                                /* (M >= 4096, K % 128 == 0, N as for ap_gemm_nt): AP_ERR_UNSUPPORTED otherwise -- also from ap_gemm_nt, which  */
+                                /* since ABI version 6 takes q8_out on its mul_by8 launches and refuses it on any launch whose kernel cannot     */
+                                /* write it (a forced tile variant included)                                                                     */
 } ap_gemm_epilogue;
 int ap_gemm_nt(const ap_bf16* A, int lda, const ap_bf16* B, int ldb, ap_bf16* C, int ldc,
                int M, int N, int K, const ap_gemm_epilogue* epi, ap_stream_t stream);
+/* ---- (ABI version 7) the MLP of a block in ONE launch: Mlp.forward, models/volo.py:147-167 (fc1 -> GELU -> fc2) with the residual add and
+ * DropPath scale of its call sites (:143 Outlooker, :233 Transformer), and -- the same kernel, backward = 1 -- the two input-gradient products
+ * of its backward pass.  The hidden activation never makes the trip to memory and back between the two products; it still LEAVES (the weight
+ * gradients read it).  Rounding points and K order are those of the two ap_gemm_nt launches it replaces: results are bit-identical to
+ *     forward : a = ap_gemm_nt(x, wa, bias1, gelu = 3 -> codes, row_scale_hidden);  out = ap_gemm_nt(a, wb, bias2, row_scale_out, residual)
+ *     backward: dh = ap_gemm_nt(x = dL/dout, wa = fc2.weight^T copy, mul_by8 = codes, row_scale_hidden);  out = ap_gemm_nt(dh, wb = fc1.weight^T copy)
+ * Built for c = 384, hidden = 3 c, m % 128 == 0 (VOLO-D1's transformer stages at any batch of 128-row blocks): AP_ERR_UNSUPPORTED otherwise,
+ * and for a forward launch while the GELU table cannot be had (AP_GELU_TABLE=0; a stream capture in front of its first build) -- the caller
+ * then issues the two launches. */
+typedef struct ap_mlp_fused_args {
+    const ap_bf16* x; int ldx;               /* [m, c] */
+    const ap_bf16* wa; int ldwa;             /* [hidden, c] */
+    const ap_bf16* wb; int ldwb;             /* [c, hidden] */
+    ap_bf16* out; int ldo;                   /* [m, c] */
+    ap_bf16* hidden_out; int ldh;            /* [m, hidden]: forward gelu(h) * row_scale_hidden, backward dL/dh */
+    unsigned char* codes;                    /* [m, hidden] bytes, row stride ldh: 8-bit gelu' codes (ap_gemm_epilogue.gelu = 3) -- written by the
+                                              * forward, read by the backward */
+    const float* bias1; const float* bias2;  /* forward: [hidden], [c] (nullable); backward: NULL */
+    const float* row_scale_hidden;           /* [ceil(m / rows_per_scale)] or NULL: forward the 0/1 DropPath mask on a, backward mask / keep on dL/dh */
+    const float* row_scale_out;              /* forward: mask / keep on the branch output (before the residual); backward: NULL */
+    int rows_per_scale;
+    const ap_bf16* residual; int ldr;        /* forward: [m, c] or NULL; backward: NULL */
+    int m, c, hidden;
+    int backward;
+} ap_mlp_fused_args;
+int ap_mlp_fused(const ap_mlp_fused_args* args, ap_stream_t stream);
+
 /* ---- fp8 forward GEMM (BASELINE configs[4] "mixed MFMA fp8 GEMM"): OCP e4m3 operands, fp32 accumulation, bf16 output.
  * y = sat(x * scale[0]) -> e4m3, n % 16 == 0; amax (nullable): amax[0] = max(amax[0], max |x|) for the next step's scale */
 int ap_quantize_fp8(const ap_bf16* x, unsigned char* y, int64_t n, const float* scale, float* amax, ap_stream_t stream);

@@ -571,7 +571,8 @@ def mix_token_swap(x, box, scale: int):
 
 def volo_forward(p: Params, img, layers, embed_dims, num_heads, train: bool, mix=None,
                  skip: Optional[List[List[int]]] = None, dp_masks: Optional[dict] = None,
-                 drop_path_rate: float = 0.0, patch_size: int = 8, pooling_scale: int = 2, bf16_points: bool = False, **_):
+                 drop_path_rate: float = 0.0, patch_size: int = 8, pooling_scale: int = 2, bf16_points: bool = False,
+                 bn_train: Optional[bool] = None, **_):
     """VOLO.forward, models/volo.py:644-694, for the model_variant/volo_d* families
     (outlook stage -> downsample -> transformer stages -> 2 class blocks -> heads).
 
@@ -579,6 +580,9 @@ def volo_forward(p: Params, img, layers, embed_dims, num_heads, train: bool, mix
     skip     per-stage identity-layer indices (set_sample_config), default none.
     dp_masks {(stage, idx): (mask1, mask2)} per-sample keep masks for DropPath; the keep
              probability follows models/volo.py:428-437.
+    bn_train None: the stem's BatchNorm follows ``train``; False with train=True: a training forward (mix-token, DropPath, the two
+             heads) on the RUNNING statistics -- the samples of a batch are then independent, which the full-size slice tests use
+             (model.train(); model.patch_embed.eval() on the module side).
     Returns (x_cls, x_aux, box) in train mode, fused logits in eval mode.
     bf16_points (train mode, DropPath off): the whole network with the rounding points of the MI355X pipeline -- patch_embed(bf16_points),
     outlooker_ / transformer_ / class_block_bf16_points, the downsample and head GEMMs, the position embedding added as a bf16 tensor, the
@@ -629,7 +633,7 @@ def volo_forward(p: Params, img, layers, embed_dims, num_heads, train: bool, mix
             nc = x_aux.shape[-1]
             x_aux = mix_token_swap(x_aux.reshape(B, H, W, nc), box, 1).reshape(B, H * W, nc)
         return x_cls, x_aux, box
-    x = patch_embed(img, p, train, patch_size)
+    x = patch_embed(img, p, train if bn_train is None else bn_train, patch_size)
     box = (0, 0, 0, 0)
     if train and mix is not None:
         box = tuple(int(v) for v in mix[1])

@@ -426,3 +426,124 @@ def _window_worker(rank, world, port, q):
 def test_weight_gradient_window_lets_buckets_leave_before_backward_ends_world_size_2():
     out = _spawn(_window_worker)
     assert all(msg == "ok" for _, msg in out), out
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# world size 8 (one node's worth of ranks): elastic skip + 3-way accumulation + the weight-gradient window in ONE
+# update, bucket order identical on every rank; the driver's distribute_bn over the model AND the EMA copies of the BatchNorm buffers.
+def _ws8_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from autoprog_amd import functional as AF, ops
+        from autoprog_amd.dist import GradientBucketReducer
+
+        def cpu_grouped(problems, ln=None):
+            for prob in problems:
+                a, b, c, n1, n2, colsum = prob[:6]
+                c += a[:, :n1].float().t() @ b[:, :n2].float()
+                if colsum is not None:
+                    colsum += a[:, :n1].float().sum(0)
+        ops.gemm_tn_acc_grouped = cpu_grouped
+        AF.WGRAD_WINDOW = 4
+        T, C, NB, K = 512, 192, 9, 3                    # 9 blocks, the elastic configuration skips blocks 3 and 6; 3 micro-batches per update
+
+        class Block(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w, b):
+                ctx.save_for_backward(x, w)
+                ctx.params = (w, b)
+                return (x.float() @ w.t() + b).to(torch.bfloat16)
+
+            @staticmethod
+            def backward(ctx, dy):
+                x, w = ctx.saved_tensors
+                bufs, sunk = AF._param_grad_buffers(ctx.params)
+                with AF.wgrad_batch(sunk=True, params=ctx.params) as batch:
+                    AF._wgrad_batch.append((dy.contiguous(), x, bufs[0], C, C, bufs[1]))
+                AF._finish_param_grads(ctx.params, bufs, sunk, deferred=True)
+                return (dy.float() @ w).to(torch.bfloat16), None, None
+
+        torch.manual_seed(0)
+        ws = [torch.nn.Parameter(torch.randn(C, C) * 0.05) for _ in range(NB)]
+        bs = [torch.nn.Parameter(torch.zeros(C)) for _ in range(NB)]
+        params = [p for pair in zip(ws, bs) for p in pair]
+        active = [i for i in range(NB) if i not in (3, 6)]
+        red = GradientBucketReducer(params, bucket_bytes=2 * (C * C + C) * 4, world_size=world, accumulate_steps=K)
+        red.install_sink()
+        torch.manual_seed(900 + rank)
+        xs = [(torch.randn(T, C) * 0.5).to(torch.bfloat16) for _ in range(K)]
+        red.zero_grad()
+        for i, x in enumerate(xs):
+            h = x.clone().requires_grad_(True)
+            for j in active:
+                h = Block.apply(h, ws[j], bs[j])
+            (h.float().pow(2).mean() / K).backward()
+            if i < K - 1:
+                assert not any(red._launched), "a bucket left on a micro-batch that only accumulates"
+            log = list(red.launch_log)
+            red.finish()
+        order = ([b for b, _ in log], [b for b, _ in red.launch_log])      # buckets that left during the last backward pass; all of them
+        acc = [torch.zeros_like(p) for p in params]
+        for r in range(world):
+            torch.manual_seed(900 + r)
+            for _ in range(K):
+                h = (torch.randn(T, C) * 0.5).to(torch.bfloat16)
+                for j in active:
+                    h = (h.float() @ ws[j].t() + bs[j]).to(torch.bfloat16)
+                gs = torch.autograd.grad(h.float().pow(2).mean() / K, params, allow_unused=True)
+                for a, g in zip(acc, gs):
+                    if g is not None:
+                        a += g / world
+        for i, (p, want) in enumerate(zip(params, acc)):
+            assert torch.allclose(p.grad, want, rtol=2e-2, atol=2e-4), (rank, "ws8 gradient", i)
+        for j in (3, 6):
+            assert float(ws[j].grad.abs().max()) == 0.0, "a skipped block received a gradient"
+        red.remove()
+
+        # the driver's distribute_bn: the model's BatchNorm statistics and every EMA copy of them, after a search epoch as after a training epoch
+        from autoprog_amd.prog.driver import AutoProgDriver
+        model = torch.nn.Sequential(torch.nn.BatchNorm2d(4), torch.nn.Conv2d(4, 4, 1), torch.nn.BatchNorm2d(4))
+
+        class _Opt:
+            def __init__(self, m):
+                self._float_buffers = [(n, b) for n, b in m.named_buffers() if b.dtype.is_floating_point]
+                self.ema_buffers = [[b.detach().clone() for _, b in self._float_buffers] for _ in range(2)]
+
+        class _Red:
+            def __init__(self):
+                self.world, self.group, self.flat = world, None, torch.zeros(4)
+        opt = _Opt(model)
+        for k, mod in enumerate((model[0], model[2])):
+            mod.running_mean.fill_(float(rank + k)); mod.running_var.fill_(float(2 * rank + k + 1))
+        for e, bufs in enumerate(opt.ema_buffers):
+            for b in bufs:
+                b.fill_(float(10 * e + rank))
+        drv = AutoProgDriver(model=model, loss_fn=None, optimizer=opt, reducer=_Red(), get_batch=None, r_list=[64, 96], l_list=[3, 6],
+                             dp_list=[0.0, 0.1], grow_epochs=[0, 2], steps_per_epoch=1, dist_bn="reduce")
+        drv._distribute_bn()
+        mean_rank = (world - 1) / 2
+        assert torch.allclose(model[0].running_mean, torch.full((4,), mean_rank)) and torch.allclose(model[2].running_var, torch.full((4,), 2 * mean_rank + 2))
+        for e, bufs in enumerate(opt.ema_buffers):
+            for b in bufs:
+                assert torch.allclose(b, torch.full_like(b, 10 * e + mean_rank)), (rank, "EMA BatchNorm buffers", e)
+        q.put((rank, "ok", order))
+    except Exception as e:                          # pragma: no cover
+        import traceback
+        q.put((rank, "fail: %r %s" % (e, traceback.format_exc()), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_elastic_skip_accumulation_and_window_world_size_8():
+    """eight ranks (gloo): blocks skipped by the elastic configuration, three micro-batches per update and the weight-gradient window in
+    one update -- gradients equal the mean over 8 x 3 micro-batches, the skipped blocks stay zero, every rank launched its buckets in the
+    SAME order (a rank that reduced bucket i against another rank's bucket j would hang or mix gradients), and the driver's
+    distribute_bn averages the model's and the EMA copies' BatchNorm statistics (main_prog.py:883-899, 1634-1654)."""
+    out = _spawn(_ws8_worker, world=8)
+    assert all(o[1] == "ok" for o in out), out
+    orders = [o[2] for o in out]
+    # buckets without a skipped member left during the backward pass of the last micro-batch, the other two in finish(): same order everywhere
+    assert all(o == orders[0] for o in orders), orders
+    assert orders[0][0] == [0, 3, 4] and sorted(orders[0][1]) == [0, 1, 2, 3, 4] and orders[0][1][:3] == [0, 3, 4], orders[0]

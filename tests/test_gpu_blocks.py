@@ -288,6 +288,42 @@ def test_transformer_block_kernels_vs_fp64_with_the_same_rounding_points():
         assert not bad, (tag, bad)
 
 
+def test_transformer_block_with_the_fused_mlp_is_the_block_bit_for_bit(monkeypatch):
+    """AP_FUSED_MLP (functional.FUSED_MLP; csrc/mlp_fused.hip, round 6): a D1-shaped transformer block (32 x 14 x 14 x 384 = 6272 rows, 12 heads,
+    DropPath factors on both branches) with its MLP as one launch per direction -- output, input gradient and EVERY parameter gradient equal
+    the unfused block's bit for bit (deterministic weight gradients), and the fused launches really ran."""
+    from autoprog_amd import functional as AF, ops
+    from autoprog_amd.models import volo as V
+    monkeypatch.setattr(ops, "deterministic", True)
+    calls = []
+    real = ops.mlp_fused
+
+    def counted(*a, **kw):
+        out = real(*a, **kw)
+        calls.append(out is not None)
+        return out
+    monkeypatch.setattr(ops, "mlp_fused", counted)
+    torch.manual_seed(31)
+    blk = V.Transformer(384, 12, mlp_ratio=3.0, drop_path=0.2).cuda().train()
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(32, 14, 14, 384, generator=g).to(torch.bfloat16).cuda()
+    dy = torch.randn(32, 14, 14, 384, generator=g).to(torch.bfloat16).cuda()
+    outs = {}
+    for fused in (False, True):
+        monkeypatch.setattr(AF, "FUSED_MLP", fused)
+        blk.zero_grad(set_to_none=True)
+        torch.manual_seed(5)                      # the same DropPath draws
+        xg = x.clone().requires_grad_(True)
+        y = blk(xg)
+        y.backward(dy)
+        outs[fused] = (y.detach().clone(), xg.grad.clone(), {n: p_.grad.clone() for n, p_ in blk.named_parameters()})
+    assert calls == [True, True], calls           # one forward and one backward launch, in the fused pass only
+    (y0, dx0, g0), (y1, dx1, g1) = outs[False], outs[True]
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+
+
 def test_outlooker_block_kernels_vs_fp64_with_the_same_rounding_points():
     """The outlooker block's kernels (LayerNorm, the v / logits / proj / MLP GEMMs, the 2 x 2 average pool and its backward, the outlook
     attention core forward and its fused backward) against oracle/ref_cpu.py outlooker_bf16_points: the reference block in fp64 with the

@@ -44,7 +44,7 @@ def dev(t):
 # ------------------------------------------------------------------------------------------
 def test_abi_loaded(ops):
     from autoprog_amd._lib import lib, LIB_PATH
-    assert lib.ap_abi_version() == 6
+    assert lib.ap_abi_version() == 7
     assert LIB_PATH.endswith("libautoprog_hip.so")
 
 
@@ -269,6 +269,53 @@ def test_gemm_nt_weight_stationary_k192(ops, M, N):
         cs.append(c)
         ds.append(ops.gemm_nt(da[m0:m1].contiguous(), dw_, mul_by=dmul[m0:m1].contiguous()))
     assert torch.equal(y, torch.cat(ys)) and torch.equal(codes, torch.cat(cs)) and torch.equal(d, torch.cat(ds))
+
+
+@pytest.mark.parametrize("M,drop", [(6272, False), (6272, True), (25088, True)])
+def test_mlp_fused_is_the_two_launches_bit_for_bit(ops, M, drop):
+    """round 6: csrc/mlp_fused.hip -- fc1 -> GELU -> fc2 (+ DropPath scale + residual) of a transformer block (models/volo.py:147-167, :233) in ONE
+    launch, and the two input-gradient products of its backward pass in one launch.  Same K order and rounding points as the two ap_gemm_nt
+    launches each replaces: hidden activation, gelu' codes, dL/dh and both outputs BIT-IDENTICAL to them (with and without DropPath factors), and
+    within bf16 tolerance of fp64.  (The kernel is slower than the launches it replaces -- DESIGN.md section 3 "Round 6" -- and off by default:
+    this test and the block test below keep it honest.)"""
+    import torch.nn.functional as F
+    if os.environ.get("AP_GEMM_8P", "1") == "0" or os.environ.get("AP_GELU_TABLE", "1") == "0":
+        pytest.skip("bit equality is against the 8-phase kernel's table path")
+    C, H, N = 384, 1152, 196
+    x, w1, w2 = rnd(M, C, seed=1), rnd(H, C, scale=C ** -0.5, seed=2), rnd(C, H, scale=H ** -0.5, seed=3)
+    g = torch.Generator().manual_seed(4)
+    b1, b2 = torch.randn(H, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    res, dy = rnd(M, C, seed=5), rnd(M, C, seed=6)
+    keep = (torch.rand(M // N, generator=g) < 0.8).float()
+    k2, rs2 = (dev(keep), dev(keep / 0.8)) if drop else (None, None)
+    dx_, dw1, dw2, db1, db2, dres, ddy = dev(x), dev(w1), dev(w2), dev(b1), dev(b2), dev(res), dev(dy)
+    # forward
+    codes0 = torch.empty(M, H, device="cuda", dtype=torch.uint8)
+    a0 = ops.gemm_nt(dx_, dw1, bias=db1, gelu=True, preact_out=codes0, preact_grad=2, row_scale=k2, rows_per_scale=N)
+    y0 = ops.gemm_nt(a0, dw2, bias=db2, row_scale=rs2, rows_per_scale=N, residual=dres)
+    got = ops.mlp_fused(dx_, dw1, dw2, bias1=db1, bias2=db2, row_scale_hidden=k2, row_scale_out=rs2, rows_per_scale=N, residual=dres)
+    assert got is not None, "ap_mlp_fused refused a launch it is built for"
+    y1, a1, codes1 = got
+    assert torch.equal(a0, a1) and torch.equal(codes0, codes1) and torch.equal(y0, y1)
+    rows = torch.arange(0, M, 37)
+    h = (x[rows].double() @ w1.double().t() + b1.double()).to(torch.bfloat16).double()
+    kk = keep[rows // N].double()[:, None] if drop else 1.0
+    aref = F.gelu(h) * kk
+    assert rel(a1[rows.cuda()], aref) < TOL_BF16
+    yref = (aref.to(torch.bfloat16).double() @ w2.double().t() + b2.double()) * (kk / 0.8 if drop else 1.0) + res[rows].double()
+    assert rel(y1[rows.cuda()], yref) < TOL_BF16
+    # backward: dL/dh = (dy W2) gelu'(code) rs, dL/dx = dL/dh W1
+    w2t, w1t = dev(w2.t().contiguous()), dev(w1.t().contiguous())
+    dh0 = ops.gemm_nt(ddy, w2t, mul_by=codes0, row_scale=rs2, rows_per_scale=N)
+    dx0 = ops.gemm_nt(dh0, w1t)
+    dx1, dh1, _ = ops.mlp_fused(ddy, w2t, w1t, backward=True, codes=codes0, row_scale_hidden=rs2, rows_per_scale=N)
+    assert torch.equal(dh0, dh1) and torch.equal(dx0, dx1)
+    gp = (codes0[rows.cuda()].cpu().double() - ops.GELU_CODE_ZERO) / ops.GELU_CODE_SCALE
+    dhref = (dy[rows].double() @ w2.double()) * gp * (kk / 0.8 if drop else 1.0)
+    assert rel(dh1[rows.cuda()], dhref) < TOL_BF16
+    assert rel(dx1[rows.cuda()], dhref.to(torch.bfloat16).double() @ w1.double()) < TOL_BF16
+    # launches outside what the kernel is built for are refused, not mis-computed
+    assert ops.mlp_fused(dx_[:1000].contiguous(), dw1, dw2) is None
 
 
 @pytest.mark.parametrize("M,N1,N2", [(1024, 128, 128), (1000, 192, 576), (3000, 486, 192), (25088 // 8, 1152, 384), (130, 1000, 384),
