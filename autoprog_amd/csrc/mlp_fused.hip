@@ -32,10 +32,14 @@
 #include "common.h"
 #include "gemm_epi.h"
 #include <type_traits>
+#include <cstdlib>
 
 #define MF_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
 #define MF_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 
+#ifndef MF_EPI_PRIO
+#define MF_EPI_PRIO 2
+#endif
 #ifndef MF_ABL
 #define MF_ABL 0          // timing-only ablations (lab builds): 1 no MFMA, 2 no fragment reads, 4 no DMA, 8 no epilogue-1 arithmetic, 16 no hidden stores
 #endif
@@ -88,6 +92,11 @@ constexpr int mf_issuing_after(int SPC, int NSL, int tc, int after) {
 }
 
 template <int N> __device__ __forceinline__ void mf_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void mf_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); }
+// ds_read_b128 with the constant part of the address in the instruction's offset field (one address register for all fragments of a K block)
+template <int OFF> __device__ __forceinline__ u32x4 mf_lds_ld16(unsigned adr) {
+    u32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(adr), "n"(OFF) : "memory"); return v;
+}
 template <int I, int N, class F> __device__ __forceinline__ void mf_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); mf_for<I + 1, N>(f); }
 }
@@ -421,6 +430,435 @@ __global__ void __launch_bounds__(256, 1) k_mlp_fused(MlpArgs a) {
 }
 
 #ifdef MF_LAB
+// lab builds: s_memtime stamps of workgroup MF_STAMP_WG, waves 0 (role A) and 4 (role B): [role][period][slot][0: behind the barrier, 1: slot's work done]
+__device__ unsigned long long mf_stamps[2 * 32 * 4 * 2];
+#ifndef MF_STAMP_WG
+#define MF_STAMP_WG 3
+#endif
+#define MF_STAMP(role, t, q, k) do { if (blockIdx.x == MF_STAMP_WG && lane == 0 && (wave & 3) == 0) mf_stamps[(((role) * 32 + (t)) * 4 + (q)) * 2 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MF_STAMP(role, t, q, k) do {} while (0)
+#endif
+
+// =====================================================================================================================================
+// Version 2: the same product with TWO waves per SIMD in two roles (round 6, second structure).  What version 1 measures (tools/mlp_lab.py,
+// profiles/r06_mlp_fused.txt): one wave per SIMD cannot overlap anything -- its MFMAs, its fragment-read latencies, the GELU arithmetic and
+// the DMA issue add up (78 us for a lone workgroup whose MFMAs take 26), and at 512 registers hipcc folds the fragment double buffer away.
+//
+//   workgroup : 512 threads = 8 waves; waves 0-3 are PRODUCERS (role A), waves 4-7 CONSUMERS (role B); waves w and w + 4 share a SIMD and the
+//               32 rows 32 (w & 3) .. of the block
+//   role A    : keeps its rows of X as fragments (96 registers), runs phase 1 of chunk t (the hidden chunk's 32 x 64 accumulators), then the
+//               chunk's epilogue (bias, GELU + code from the table / times the stored codes, DropPath factor, bf16), stores the chunk for the
+//               backward pass and hands it to its partner through 4 KB of LDS in phase-2 fragment order
+//   role B    : keeps the 32 x C output accumulators (192 registers), runs phase 2 of chunk t - 1 while A is in the epilogue of chunk t --
+//               the matrix pipe of the SIMD alternates between the two waves, the vector pipe works beside it -- and issues EVERY LDS-DMA of
+//               the weight stream (it idles while A multiplies), so that only B counts vmcnt
+//   period t  : four ring slots of three 8-KB pieces in consumption order: Wa(t) pieces 0-2 | Wa(t) 3-5 | Wb(t - 1) 0-2 | Wb(t - 1) 3-5; one
+//               barrier in front of each slot (B: s_waitcnt vmcnt(12) first -- its six DMA instructions of each of the two younger slots), the
+//               DMA of slot s + 3 behind it into the ring slot that slot s - 2 left; NCH + 1 periods (B has nothing in period 0, A nothing in
+//               the last one; the slots without a chunk are loaded from the neighbouring chunk so that every count stays constant)
+//   LDS       : ring 5 x 24 KB | hidden chunk hand-off 16 KB | GELU table 16 KB | fc1 bias
+// (the table sits at LDS address 0: a table entry's byte offset is then the whole address of its ds_read_b32)
+constexpr int M2_TAB = 0, M2_BIAS = 16384, M2_A = 21504, M2_RING = M2_A + 16384, M2_LDS_BYTES = M2_RING + MF_RING;
+static_assert(M2_LDS_BYTES <= 163840 && M2_BIAS + 4608 <= M2_A, "LDS");
+
+// LDS byte offsets of the table entries of the two bf16 values packed in w (gq_tab_index<0> / <16> times four), with packed 16-bit arithmetic:
+// eight vector instructions per pair instead of twelve
+__device__ __forceinline__ void mf_tab_addr2(unsigned w, unsigned& a0, unsigned& a1) {
+    unsigned m = w & 0x7fff7fffu;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(m) : "v"(m), "s"((unsigned)((GQ_TAB_LO << 16) | GQ_TAB_LO)));      // max(mag - LO, 0)
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(m), "s"((unsigned)(((GQ_TAB_N - 1) << 16) | (GQ_TAB_N - 1))));
+    const unsigned idx4 = (m << 2) | ((w >> 2) & 0x20002000u);        // sign (bit 15) -> entry 2048 + ., times four
+    a0 = idx4 & 0xffffu;
+    a1 = idx4 >> 16;
+}
+
+template <int C, bool BWD>
+__global__ void __launch_bounds__(512, 2) k_mlp_fused2(MlpArgs a) {
+    static_assert(C == 384, "version 2 is written for C = 384 (six pieces per phase, two slots per phase)");
+    constexpr int PP = C / 64, NCH = 3 * C / 64, KS = C / 32, NT2 = C / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool roleB = wave >= 4;
+    const int rg = wave & 3;
+    const int fr = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * MF_BM + rg * 32;
+    const int64_t hrow[2] = {(int64_t)(m0 + fr) * a.ldh + g * 8, (int64_t)(m0 + 16 + fr) * a.ldh + g * 8};
+
+    if constexpr (!BWD) {                        // the fc1 bias into LDS, before any DMA is in flight
+        float* lb = reinterpret_cast<float*>(mf_smem + M2_BIAS);
+        for (int i = tid; i < a.Hd; i += 512) lb[i] = a.bias1 ? a.bias1[i] : 0.f;
+        __syncthreads();
+    }
+    const int lane_off0 = fr * 128 + ((g ^ (fr & 7)) << 4), lane_off1 = fr * 128 + (((4 + g) ^ (fr & 7)) << 4);
+    auto ring_of = [](int s) { return M2_RING + (s % MF_NSLOT) * MF_SLOT; };
+    auto lds_ld16 = [](unsigned adr) { u32x4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(adr) : "memory"); return v; };
+    auto lds_ld4 = [](unsigned adr) { unsigned v; asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(adr) : "memory"); return v; };
+    auto lds_st16 = [](unsigned adr, const u32x4& v) { asm volatile("ds_write_b128 %0, %1" :: "v"(adr), "v"(v) : "memory"); };
+    const unsigned smem_a = (unsigned)(size_t)(const __attribute__((address_space(3))) void*)mf_smem;
+    if (smem_a != 0) __builtin_trap();           // (no static LDS in this kernel: the dynamic block starts at 0, and mf_tab_addr2 relies on it)
+    const unsigned abuf_a = smem_a + M2_A + rg * 4096 + lane * 16;        // + (mt * 2 + kb) * 1024
+    auto mma = [&](const u32x4& w, const u32x4& x, f32x4 c) -> f32x4 {
+        if (MF_ABL & 1) { asm volatile("" :: "v"(w), "v"(x)); return c; }
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(w), as_bf16x8(x), c, 0, 0, 0);
+    };
+    // fragment (nt, kb) of piece pc of the ring slot at byte offset rb
+    auto frag = [&](int rb, int pc, int nt, int kb) -> u32x4 {
+        if (MF_ABL & 2) return (u32x4){lane * 3u + 1u, 5u, 7u, 11u};
+        return ld16(mf_smem + rb + pc * MF_PIECE + nt * 2048 + (kb ? lane_off1 : lane_off0));
+    };
+
+    if (!roleB) {
+        // ================================================================ role A: phase 1 + the chunk's epilogue
+        u32x4 xf[2][KS];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const bf16_t* xp = a.X + (int64_t)(m0 + mt * 16 + fr) * a.ldx + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xf[mt][ks]) : "v"(xp + ks * 32) : "memory");
+        }
+        u32x2 c0[2][2], c1[2][2];                 // the gelu' codes (backward) of the even / odd chunks, requested a period ahead: they come from memory
+                                                  // (28.9 MB per launch, read once) and a slot or two do not cover that latency under load.  Two
+                                                  // buffers that trade places (the period loop is unrolled by two), never a copy: see load_codes
+        // ("+v", and no copy of a buffer anywhere: the destination IS the loop-carried register.  With "=v", or with `cj = cn` behind the wait, hipcc
+        // loaded into a fresh register and copied it into the carried one right behind the load -- before the data had landed: an asm's result is
+        // "there" for the compiler the moment the asm is issued)
+        auto load_codes = [&](u32x2 (&c)[2][2], int j) {
+            if constexpr (BWD) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(c[mt][b]) : "v"(a.G + hrow[mt] + j * 64 + b * 32) : "memory");
+            }
+        };
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { c0[mt][b] = (u32x2){0u, 0u}; c1[mt][b] = (u32x2){0u, 0u}; }
+        load_codes(c0, 0);
+        float rs1v[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) rs1v[mt] = a.rs1 ? a.rs1[(m0 + mt * 16 + fr) / a.rows_per_scale] : 1.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xf[mt][ks]));
+            asm volatile("" : "+v"(rs1v[mt]));
+        }
+        f32x4 hacc[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hacc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned bias_a = smem_a + M2_BIAS + g * 32;
+        u32x4 bq[2][2];                          // fc1 bias of the lane's 2 x 8 units of the chunk: requested at the start of the chunk's first slot
+
+        // the epilogue of m-tile mt of chunk j: -> the two phase-2 fragments o[kb] of the tile (rows fr, units 32 kb + 8 g ..)
+        auto epi = [&](int j, int mt, u32x4 (&o)[2], const u32x2 (&cj)[2][2]) {
+            const float rs = rs1v[mt];
+            if constexpr (!BWD) {
+                u32x4 hb[2];
+                unsigned e[2][8];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = hacc[mt][2 * b][r]; v[4 + r] = hacc[mt][2 * b + 1][r]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[q] += __uint_as_float(bq[b][0][q]); v[4 + q] += __uint_as_float(bq[b][1][q]); }
+                    hb[b] = pack8(v);            // the bf16-rounded pre-activation: gelu(h) = h Phi(h), and the code of gelu'(h), from the table
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned a0, a1;
+                        mf_tab_addr2(hb[b][q], a0, a1);
+                        e[b][2 * q] = lds_ld4(a0);
+                        e[b][2 * q + 1] = lds_ld4(a1);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    // the first half's eight entries have landed once at most the second half's eight reads are outstanding
+                    if (b == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(e[b][q]));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        o[b][q] = pack_bf2(bf_lo(hb[b][q]) * __uint_as_float(e[b][2 * q]) * rs, bf_hi(hb[b][q]) * __uint_as_float(e[b][2 * q + 1]) * rs);
+                    u32x2 gq;
+                    gq[0] = __builtin_amdgcn_perm(e[b][1], e[b][0], 0x0c0c0400u) | (__builtin_amdgcn_perm(e[b][3], e[b][2], 0x0c0c0400u) << 16);
+                    gq[1] = __builtin_amdgcn_perm(e[b][5], e[b][4], 0x0c0c0400u) | (__builtin_amdgcn_perm(e[b][7], e[b][6], 0x0c0c0400u) << 16);
+                    if (!(MF_ABL & 16)) {
+                        st16_nt(a.Hout + hrow[mt] + j * 64 + b * 32, o[b]);
+                        *reinterpret_cast<u32x2*>(a.G + hrow[mt] + j * 64 + b * 32) = gq;
+                    } else asm volatile("" :: "v"(gq));
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float v[8], d[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = hacc[mt][2 * b][r]; v[4 + r] = hacc[mt][2 * b + 1][r]; }
+                    gq_unpack4(cj[mt][b][0], d); gq_unpack4(cj[mt][b][1], d + 4);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] *= d[q];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] *= rs;
+                    o[b] = pack8(v);
+                    if (!(MF_ABL & 16)) st16_nt(a.Hout + hrow[mt] + j * 64 + b * 32, o[b]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hacc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        };
+
+        auto period = [&](int t, u32x2 (&cj)[2][2], u32x2 (&cn)[2][2]) {
+            mf_for<0, 4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                const int rb = ring_of(4 * t + q);
+                __builtin_amdgcn_s_barrier();
+                MF_STAMP(0, t, q, 0);
+                if constexpr (q < 2) {
+                    // phase 1, pieces 3 q .. 3 q + 2 of Wa(t): 24 fragments in (piece, kb, nt) order through a rolling buffer of eight.  The
+                    // reads are inline asm with counted waits: left to itself hipcc sinks every read to its use (two fragments in flight, a
+                    // full LDS latency per four MFMAs -- and this wave is the only one of its SIMD that multiplies during this slot)
+                    u32x4 w[8];
+                    const unsigned fa = smem_a + rb;
+                    const unsigned fk[2] = {fa + (unsigned)lane_off0, fa + (unsigned)lane_off1};
+                    if constexpr (!BWD && q == 0) {
+                        // this chunk's bias: older than every fragment read below, so the first counted wait retires it
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) { bq[b][0] = lds_ld16(bias_a + (t * 64 + b * 32) * 4); bq[b][1] = lds_ld16(bias_a + (t * 64 + b * 32) * 4 + 16); }
+                        if (MF_ABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    if (!(MF_ABL & 2)) {
+                        mf_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; w[i] = mf_lds_ld16<(i >> 3) * MF_PIECE + (i & 3) * 2048>(fk[(i >> 2) & 1]); });
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) w[i] = (u32x4){lane * 3u + 1u, 5u, 7u, 11u};
+                    }
+                    mf_for<0, 24>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        constexpr int pc = i >> 3, kb = (i >> 2) & 1, nt = i & 3;
+                        if (!(MF_ABL & 2)) { mf_lgkmcnt<(23 - i < 7 ? 23 - i : 7)>(); __builtin_amdgcn_sched_barrier(0); }
+                        asm volatile("" : "+v"(w[i & 7]));
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) hacc[mt][nt] = mma(w[i & 7], xf[mt][2 * (3 * q + pc) + kb], hacc[mt][nt]);
+                        if constexpr (i + 8 < 24) {
+                            constexpr int n = i + 8;
+                            if (!(MF_ABL & 2)) w[i & 7] = mf_lds_ld16<(n >> 3) * MF_PIECE + (n & 3) * 2048>(fk[(n >> 2) & 1]);
+                        }
+                    });
+                    if constexpr (BWD && q == 0) {
+                        // chunk t's codes were requested a period ago (younger: the last chunk's four stores): take them over, then request chunk
+                        // t + 1's -- HERE, behind this slot's MFMAs: at the start of a slot the consumer waves issue their DMA, and these strided
+                        // 8-byte loads in front of it cost them a third of the slot
+                        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (younger: the last chunk's four stores)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) asm volatile("" : "+v"(cj[mt][b]));
+                        load_codes(cn, min(t + 1, NCH - 1));
+                    }
+                } else {
+                    // The chunk's epilogue, and the chunk into the hand-off buffer: B took chunk t - 1 out of it while this wave multiplied
+                    // (second slot of this period).  Forward: tile 0 in this period's third slot, tile 1 in the fourth (the GELU is as long as
+                    // B's MFMAs of a slot); backward: both tiles in the third (a fraction of B's slot), nothing in the fourth.
+                    constexpr bool both = BWD;
+                    if constexpr (q == 2 || !both) {
+                        if constexpr (!BWD) __builtin_amdgcn_s_setprio(MF_EPI_PRIO);   // the GELU's vector instructions in front of the partner's MFMAs in the SIMD's issue arbitration
+                        u32x4 o[2];
+                        if constexpr (q == 2) {
+                            epi(t, 0, o, cj);
+                            lds_st16(abuf_a, o[0]); lds_st16(abuf_a + 1024, o[1]);
+                        }
+                        if constexpr (q == 3 || both) {
+                            epi(t, 1, o, cj);
+                            lds_st16(abuf_a + 2048, o[0]); lds_st16(abuf_a + 3072, o[1]);
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_setprio(0);
+                    }
+                }
+                MF_STAMP(0, t, q, 1);
+            });
+        };
+        static_assert(NCH % 2 == 0, "the period loop is unrolled by two");
+        for (int t = 0; t < NCH; t += 2) { period(t, c0, c1); period(t + 1, c1, c0); }
+        for (int q = 0; q < 4; ++q) { __builtin_amdgcn_s_barrier(); MF_STAMP(0, NCH, q, 0); MF_STAMP(0, NCH, q, 1); }      // the last period is B's alone
+        return;
+    }
+
+    // ==================================================================== role B: the weight stream and phase 2
+    const int wb = wave - 4;
+    const int sr = lane >> 3;
+    const int srcchunk = ((lane & 7) ^ sr) * 8;
+    const int lunit = (sr >> 2) * 8 + (sr & 3);
+    const unsigned voffA = (unsigned)(lunit * a.ldwa + srcchunk) * 2u, voffB = (unsigned)(lunit * a.ldwb + srcchunk) * 2u;
+    int dpc[MF_DMA], ddst[MF_DMA], dunit[MF_DMA];
+#pragma unroll
+    for (int i = 0; i < MF_DMA; ++i) {
+        const int id = wb * MF_DMA + i;
+        dpc[i] = id >> 3;
+        const int sub = id & 7;
+        ddst[i] = dpc[i] * MF_PIECE + sub * 1024;
+        dunit[i] = (sub >> 2) * 32 + (sub & 1) * 16 + ((sub >> 1) & 1) * 4;
+    }
+    // slot q of period t: q < 2 pieces 3 q .. of Wa(t); q >= 2 pieces 3 (q - 2) .. of Wb(t - 1); chunks outside [0, NCH) are taken from the nearest one.
+    // buffer_load ... lds through one descriptor per weight matrix: the instruction's address is a scalar offset (piece, rows) + this lane's
+    // constant 32-bit offset -- no per-instruction vector arithmetic, half the address bits of the global_load form
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.Wa), 0, a.Hd * a.ldwa * 2, 0x00020000);
+    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.Wb), 0, C * a.ldwb * 2, 0x00020000);
+    auto dma_slot = [&](int s) {
+        if (MF_ABL & 4) return;
+        const int t = s >> 2, q = s & 3;
+        unsigned char* dst = mf_smem + ring_of(s);
+        if (q < 2) {
+            const int j = min(t, NCH - 1);
+            const int base = (j * 64 * a.ldwa + 3 * q * 64) * 2;
+#pragma unroll
+            for (int i = 0; i < MF_DMA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, MF_LDS(dst + ddst[i]), 16, voffA, base + (dunit[i] * a.ldwa + dpc[i] * 64) * 2, 0, 0);
+        } else {
+            const int j = max(t - 1, 0);
+            const int base = (3 * (q - 2) * 64 * a.ldwb + j * 64) * 2;
+#pragma unroll
+            for (int i = 0; i < MF_DMA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, MF_LDS(dst + ddst[i]), 16, voffB, base + (dpc[i] * 64 + dunit[i]) * a.ldwb * 2, 0, 0);
+        }
+    };
+    float rs2v[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) rs2v[mt] = a.rs2 ? a.rs2[(m0 + mt * 16 + fr) / a.rows_per_scale] : 1.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) asm volatile("" : "+v"(rs2v[mt]));
+    if constexpr (!BWD) {                        // the GELU table in front of the weight stream (16 one-KB pieces, four per B wave)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(MF_GLB(a.gelu_tab + (wb * 4 + i) * 256 + lane * 4), MF_LDS(mf_smem + M2_TAB + (wb * 4 + i) * 1024), 16, 0, 0);
+    }
+    dma_slot(0); dma_slot(1); dma_slot(2);
+    f32x4 oacc[2][NT2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) oacc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 af[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) af[mt][kb] = (u32x4){0u, 0u, 0u, 0u};
+    constexpr int NSLOTS = 4 * (NCH + 1);
+    for (int t = 0; t <= NCH; ++t) {
+        mf_for<0, 4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const int s = 4 * t + q;
+            const int rb = ring_of(s);
+            // DMA schedule: slots s + 3 AND s + 4 go out behind the barrier of the period's first slot (the two ring slots the last period's
+            // phase 2 left; this wave idles while A multiplies), s + 3 behind the second and the third, none behind the fourth: the wave issues
+            // six instead of twelve DMA instructions in front of its own MFMAs.  In flight behind the wait for slot s: two younger slots at
+            // the period's first barrier, three at the others (all of them landed in the last two periods, where nothing is issued any more).
+            if (t == NCH) mf_vmcnt<0>();
+            else if constexpr (q == 0) mf_vmcnt<2 * MF_DMA>();
+            else mf_vmcnt<3 * MF_DMA>();
+            __builtin_amdgcn_s_barrier();
+            MF_STAMP(1, t, q, 0);
+            if constexpr (q == 0) { if (s + 3 < NSLOTS) dma_slot(s + 3); if (s + 4 < NSLOTS) dma_slot(s + 4); }
+            if constexpr (q == 1) {
+                if (s + 4 < NSLOTS) dma_slot(s + 4);
+                if (t >= 1) {
+                    // chunk t - 1 out of the hand-off buffer, while A multiplies (A wrote it in the last period's third and fourth slots and
+                    // writes the next chunk from this period's third slot on: barriers on both sides)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb) af[mt][kb] = lds_ld16(abuf_a + (mt * 2 + kb) * 1024);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb) asm volatile("" : "+v"(af[mt][kb]));
+                    // (measured and dropped: B also STORING the chunk from these fragments, to take four store instructions per period off A --
+                    // this slot became B's longest, 1200 - 2100 cycles against A's 1050: forward 77.4 -> 80.2 us, backward 66.4 -> 67.3)
+                }
+            }
+            if constexpr (q == 2) { if (t < 1 && s + 4 < NSLOTS) dma_slot(s + 4); }          // (period 0 has no phase 2; otherwise see below)
+            if constexpr (q >= 2) {
+                if (t >= 1) {
+                    // phase 2, output pieces 3 (q - 2) .. + 2: 24 fragments in (piece, kb, nt) order through a rolling buffer of six (asm reads
+                    // with counted waits, as in role A)
+                    constexpr int RB = 6;
+                    u32x4 w[RB];
+                    const unsigned fa = smem_a + rb;
+                    const unsigned fk[2] = {fa + (unsigned)lane_off0, fa + (unsigned)lane_off1};
+                    if (!(MF_ABL & 2)) {
+                        mf_for<0, RB>([&](auto ic) { constexpr int i = decltype(ic)::value; w[i] = mf_lds_ld16<(i >> 3) * MF_PIECE + (i & 3) * 2048>(fk[(i >> 2) & 1]); });
+                        // (the slot's one DMA batch goes out HERE, under the latency of the first fragment reads)
+                        if constexpr (q == 2) { if (s + 4 < NSLOTS) dma_slot(s + 4); }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < RB; ++i) w[i] = (u32x4){lane * 3u + 1u, 5u, 7u, 11u};
+                        if constexpr (q == 2) { if (s + 4 < NSLOTS) dma_slot(s + 4); }
+                    }
+                    constexpr int nb0 = 3 * (q - 2);
+                    mf_for<0, 24>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        constexpr int pc = i >> 3, kb = (i >> 2) & 1, nt = i & 3;
+                        if (!(MF_ABL & 2)) { mf_lgkmcnt<(23 - i < RB - 1 ? 23 - i : RB - 1)>(); __builtin_amdgcn_sched_barrier(0); }
+                        asm volatile("" : "+v"(w[i % RB]));
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) oacc[mt][(nb0 + pc) * 4 + nt] = mma(w[i % RB], af[mt][kb], oacc[mt][(nb0 + pc) * 4 + nt]);
+                        if constexpr (i + RB < 24) {
+                            constexpr int n = i + RB;
+                            if (!(MF_ABL & 2)) w[i % RB] = mf_lds_ld16<(n >> 3) * MF_PIECE + (n & 3) * 2048>(fk[(n >> 2) & 1]);
+                        }
+                    });
+                }
+            }
+            MF_STAMP(1, t, q, 1);
+        });
+    }
+    // ---- out: lane (fr, g) holds columns 32 tp + 8 g .. + 7 of row fr (tiles 2 tp, 2 tp + 1)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int64_t row = m0 + mt * 16 + fr;
+#pragma unroll
+        for (int tp = 0; tp < C / 32; ++tp) {
+            const int col = tp * 32 + g * 8;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = oacc[mt][2 * tp][r]; v[4 + r] = oacc[mt][2 * tp + 1][r]; }
+            if constexpr (!BWD) {
+                if (a.bias2) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(a.bias2 + col), b1 = *reinterpret_cast<const float4*>(a.bias2 + col + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                const float rs = rs2v[mt];
+                if (a.res) {
+                    const u32x4 r8 = ld16(a.res + row * a.ldr + col);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[2 * q] = __builtin_fmaf(v[2 * q], rs, bf_lo(r8[q])); v[2 * q + 1] = __builtin_fmaf(v[2 * q + 1], rs, bf_hi(r8[q])); }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] *= rs;
+                }
+            }
+            st16_nt(a.Out + row * a.ldo + col, pack8(v));
+        }
+    }
+    MF_STAMP(1, NCH + 1, 0, 0);
+}
+
+#ifdef MF_LAB
+extern "C" int mf_lab_read_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mf_stamps), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+#ifdef MF_LAB
 // lab builds (tools/mlp_lab.py: this file alone as a shared object, one per MF_ABL value): a table of their own
 __global__ void k_mf_lab_table(unsigned* tab) { const unsigned idx = blockIdx.x * 256 + threadIdx.x; if (idx < 2 * GQ_TAB_N) tab[idx] = gq_tab_entry(idx); }
 const unsigned* g8_gelu_table_ptr(hipStream_t st) {
@@ -436,9 +874,16 @@ const unsigned* g8_gelu_table_ptr(hipStream_t st) {
 
 template <int C, bool BWD>
 static int mf_launch(const MlpArgs& a, hipStream_t st) {
+    static int version = 0;                  // AP_MLP_FUSED_V = 1: the one-wave-per-SIMD kernel; default 2: producer / consumer waves
+    if (!version) { const char* e = getenv("AP_MLP_FUSED_V"); version = (e && e[0] == '1') ? 1 : 2; }
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_mlp_fused<C, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES); attr = true; (void)hipGetLastError(); }
-    hipLaunchKernelGGL((k_mlp_fused<C, BWD>), dim3(a.M / MF_BM), dim3(256), MF_LDS_BYTES, st, a);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_mlp_fused<C, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)k_mlp_fused2<C, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, M2_LDS_BYTES);
+        attr = true; (void)hipGetLastError();
+    }
+    if (version == 1) hipLaunchKernelGGL((k_mlp_fused<C, BWD>), dim3(a.M / MF_BM), dim3(256), MF_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((k_mlp_fused2<C, BWD>), dim3(a.M / MF_BM), dim3(512), M2_LDS_BYTES, st, a);
     return ap_check_launch();
 }
 

@@ -116,13 +116,17 @@ class GraphedStep:
         self.scalars = StepScalars(self.images.device)
         self.graph = None
         self.loss = None
+        # the resolution of the elastic configuration this graph is built on (the model's at construction): a replay's mix-token draw is for THIS
+        # configuration's token grid whatever configuration the model object was switched to since (a search replays a different graph every step)
+        pe = getattr(model, "patch_embed", None)
+        self._res = (getattr(pe, "resize_to", None) or self.images.shape[-1]) if pe is not None else self.images.shape[-1]
 
     # ---- host side of a step: the draws VOLO.forward makes (models/volo.py:649-653: beta, then rand_bbox's two randint calls)
     def _draw(self):
         m = self.model
         if getattr(m, "mix_token", False) and m.training:
             from .models.volo import rand_bbox
-            r = m.patch_embed.resize_to or self.images.shape[-1]
+            r = self._res
             pe = m.patch_embed
             patch = pe.proj.kernel_size[0] * (pe.conv[0].stride[0] if pe.stem_conv else 1)
             g1 = r // patch                                       # token grid in front of the first stage (patch size 8 in every VOLO)

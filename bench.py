@@ -499,10 +499,24 @@ def main():
 
     eager_step = step
     if args.graph:
-        if world > 1 or args.no_optimizer or args.workload not in ("d1", "stages") or args.search_mix:
-            raise SystemExit("--graph: one rank, d1 or stages (fixed schedule), with the optimizer")
+        if world > 1 or args.no_optimizer or args.workload not in ("d1", "stages"):
+            raise SystemExit("--graph: one rank, d1 or stages, with the optimizer")
         from autoprog_amd.graph import GraphedStep
-        if args.workload == "stages":
+        if args.workload == "stages" and args.search_mix:
+            # the supernet search (main_prog.py:1824-1837): a different (l, r) every step -- one graph per candidate, 16 here (the driver's
+            # searches have at most 9), captured up front; the step draws its candidate as the eager search step does
+            graphs = {}
+            for l_ in l_list:
+                for r_ in r_list:
+                    model.set_sample_config(dict(layer_num=l_, min_layer_num=l_list[0], max_layer_num=l_list[-1], input_size=r_))
+                    model.set_drop_path_rate(0.1)
+                    graphs[(l_, r_)] = GraphedStep(model, loss_fn, reducer, opt, images, targets[r_]).capture()
+            gcount = [0]
+
+            def step():
+                gcount[0] += 1
+                return graphs[(random.choice(l_list), random.choice(r_list))].step()
+        elif args.workload == "stages":
             graphs = []
             for l_, r_, dp_ in STAGES:       # one graph per elastic configuration: set_sample_config decides which kernels a step launches
                 model.set_sample_config(dict(layer_num=l_, min_layer_num=STAGES[0][0], max_layer_num=STAGES[-1][0], input_size=r_))
@@ -607,7 +621,7 @@ def main():
         probe.install()
         nprobe = 3 if args.workload == "d1" else 4
         if args.graph:                 # (the probe wraps the Python launch functions: the eager step of the same configuration sequence)
-            for g_ in (graphs if args.workload == "stages" else [graph1]):
+            for g_ in ((graphs.values() if isinstance(graphs, dict) else graphs) if args.workload == "stages" else [graph1]):
                 g_.release()
             if args.workload == "stages":
                 counter[0] = args.warmup + args.steps          # the probe steps take the stages in turn

@@ -224,3 +224,57 @@ def test_driver_epochs_from_graphs_reproduce_the_eager_driver(monkeypatch):
     assert ne == 0 and ng == 2 * (2 * 5 - 2) and live == 1        # per stage: 2 epochs x 5 steps, the first two eager; the last stage's graph is live
     assert le == lg, (le, lg)
     assert torch.equal(pe, pg) and all(torch.equal(a, b) for a, b in zip(ee, eg))
+
+
+def test_driver_search_from_graphs_reproduces_the_eager_search(monkeypatch):
+    """round 6: the steps of a SEARCH -- a different sub-network (l, r) every step, main_prog.py:1824-1837 -- replay one HIP graph
+    per candidate drawn (at most len(rs) * len(ls) per search), captured on the search supernet's slabs after two eager steps at that candidate;
+    probes and timing passes between them stay eager.  DropPath off, deterministic weight gradients, fresh random batches: the search's probe
+    losses, its decision, the per-epoch losses after it and the final weights / EMA copies equal the eager driver's bit for bit."""
+    from autoprog_amd import ops
+    from autoprog_amd.dist import GradientBucketReducer
+    from autoprog_amd.loss import TokenLabelCrossEntropy
+    from autoprog_amd.models import create_model
+    from autoprog_amd.optim import FlatAdamWEma
+    from autoprog_amd.prog.driver import AutoProgDriver
+    from autoprog_amd import graph as G
+    monkeypatch.setattr(ops, "deterministic", True)
+    replays = []
+    real_step = G.GraphedStep.step
+    monkeypatch.setattr(G.GraphedStep, "step", lambda self, *a, **k: (replays.append(self._res), real_step(self, *a, **k))[1])
+    out = {}
+    for use_graphs in (False, True):
+        torch.manual_seed(0)
+        model = create_model("model_variant", variant="volo_h2_l6", num_classes=16, img_size=96, stem_hidden_dim=64).cuda().train()
+        red = GradientBucketReducer(list(model.parameters()), world_size=1, defer_mean=True)
+        red.install_sink(model)
+        opt = FlatAdamWEma(model, red, lr=1e-3, weight_decay=0.05, ema_decays=[0.9, 0.99])
+        loss_fn = TokenLabelCrossEntropy(dense_weight=0.5, cls_weight=1.0, classes=16)
+        g = torch.Generator().manual_seed(1)
+
+        def get_batch(r):
+            x = torch.randn(8, 3, 96, 96, generator=g).cuda()
+            return x, torch.softmax(torch.randn(8, 16, 2 + (r // 16) ** 2, generator=g) * 2, dim=1).cuda()
+
+        # one search at epoch 0 over r in {64, 96} x l in {3, 6} (2 search epochs of 12 steps: every candidate is drawn often enough to get its graph)
+        drv = AutoProgDriver(model, loss_fn, opt, red, get_batch, r_list=[64, 96], l_list=[3, 6], dp_list=[0.0, 0.0], grow_epochs=[0, 3],
+                             steps_per_epoch=12, search_epochs=2, auto_grow=True, probe_batches=1, time_steps=1, seed=4,
+                             use_graphs=use_graphs, graph_after=2)
+        try:
+            np.random.seed(3)
+            n0 = len(replays)
+            # the timing pass decides nothing here: equal times on both runs (wall-clock times differ from run to run and would change the ranking)
+            monkeypatch.setattr(drv, "_time", lambda cands: {c: 1.0 + 0.1 * i for i, c in enumerate(cands)})
+            hist = drv.run(4)
+            search = [h for h in hist if h["kind"] == "search"][0]
+            out[use_graphs] = (search["mean_loss"], search["chosen"], [h["loss"] for h in hist if h["kind"] == "train"], opt.p.clone(),
+                               [e.clone() for e in opt.ema], replays[n0:])
+        finally:
+            red.remove()
+    me, ce, le, pe, ee, re_ = out[False]
+    mg, cg, lg, pg, eg, rg = out[True]
+    print("eager :", me, ce, le)
+    print("graph :", mg, cg, lg, "replays at resolutions", sorted(set(rg)), len(rg))
+    assert not re_ and len(rg) >= 8 and set(rg) == {64, 96}          # both resolutions of the search space were replayed from graphs
+    assert me == mg and ce == cg and le == lg
+    assert torch.equal(pe, pg) and all(torch.equal(a, b) for a, b in zip(ee, eg))

@@ -6,13 +6,13 @@
 #   gpurun_out/${ROUND}_kernel_table.txt   one line per kernel: HBM bytes, TB/s, MFMA busy %, VALU busy %, LDS conflict share (tools/pmc_table.py)
 #   gpurun_out/gemm_nt_traffic.json   HBM bytes per k_gemm_nt launch from FETCH_SIZE/WRITE_SIZE (gfx950 correction applied)
 # Copy them into profiles/ afterwards.
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r06}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 if [ -z "$PMC_ONLY" ]; then
 python3 bench.py 2> gpurun_out/${ROUND}_bench.err | tail -1 > gpurun_out/${ROUND}_bench_n1.json
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/_kt -o run -- python3 bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/_kt.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/_kt -o run -- python3 bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-roofline --prewarm-s 0 --no-calibration > gpurun_out/_kt.log 2>&1
 f=$(find gpurun_out/_kt -name "*kernel_trace.csv" | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-roofline ; dispatches after the 6th k_soft_ce (3 warm-up steps dropped; kept: the 7 timed steps + the 6 forward+backward-only probe steps behind fwd_loss_bwd_only_ms_per_step)"; python3 tools/prof_summary.py $f --after k_soft_ce 6; } > gpurun_out/${ROUND}_kernel_stats.txt
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-roofline --prewarm-s 0 --no-calibration ; dispatches after the 6th k_soft_ce (3 warm-up steps dropped; kept: the 7 timed steps + the 6 forward+backward-only probe steps behind fwd_loss_bwd_only_ms_per_step)"; python3 tools/prof_summary.py $f --after k_soft_ce 6; } > gpurun_out/${ROUND}_kernel_stats.txt
 rm -rf gpurun_out/_kt
 fi
 i=0
@@ -20,9 +20,9 @@ i=0
 # after which rocprofv3 aborts and hangs): one pass each, every pass under a hard timeout
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"; do
   i=$((i+1))
-  timeout 240 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/_pmc/p$i -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/_pmc$i.log 2>&1
+  timeout 240 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/_pmc/p$i -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --prewarm-s 0 --no-calibration > gpurun_out/_pmc$i.log 2>&1
 done
-{ echo "# rocprofv3 --pmc <one group per pass> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline ; per-dispatch averages"
+{ echo "# rocprofv3 --pmc <one group per pass> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --prewarm-s 0 --no-calibration ; per-dispatch averages"
   echo "# FETCH_SIZE/WRITE_SIZE are in KB; gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md): double it."
   python3 tools/pmc_summary.py gpurun_out/_pmc k_gemm k_ln k_mhsa k_outlook k_soft_ce k_bn k_adamw k_conv3x3 igemm kernel_grouped_conv; } > gpurun_out/${ROUND}_pmc_counters.txt
 ROUND=$ROUND python3 - <<'PY'

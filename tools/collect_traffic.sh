@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/_pmcw; i=0
 for grp in FETCH_SIZE WRITE_SIZE; do
   i=$((i+1))
-  timeout 400 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/_pmcw/p$i -o run -- python3 bench.py --workload $W "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/_pmcw$i.log 2>&1
+  timeout 400 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/_pmcw/p$i -o run -- python3 bench.py --workload $W "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --prewarm-s 0 --no-calibration > gpurun_out/_pmcw$i.log 2>&1
 done
 python3 tools/pmc_summary.py gpurun_out/_pmcw k_gemm > gpurun_out/_pmcw_counters.txt
 W=$W python3 - <<'PY'
