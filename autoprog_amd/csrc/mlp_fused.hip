@@ -9,12 +9,17 @@
 //   backward : X = dL/dy, Wa = fc2.weight^T copy [Hd, C], Wb = fc1.weight^T copy [C, Hd];  f: dh = bf16(acc g'(code) rs1), stored for the weight
 //              gradients;  epi2: out = bf16(acc) = dL/d(LN2 x)
 //
-// The two launches this replaces (fc1 + GELU 47 - 52 us, fc2 + residual 37 us at 25088 x 384 x 1152) write the hidden activation (57.8 MB), drain,
-// fill again and read it back; each runs its K loop at what one CU pulls from L2 and its store phase at what the chip writes, one after the
-// other.  Here a workgroup keeps its 128 rows of X as MFMA fragments in REGISTERS for the whole kernel, the hidden chunk never leaves the
-// registers either -- the accumulator layout of phase 1 (lane (fr, g) holds 8 consecutive hidden units of row fr) IS the operand layout of
-// phase 2 -- and the only thing that streams through LDS is the weights: 2 * 3 C * C * 2 bytes per workgroup, in 8-KB pieces by LDS-DMA.
+// STATUS (round 6): bit-identical to the two launches in both directions and OFF by default (functional.FUSED_MLP / AP_FUSED_MLP=1).  Between Python calls
+// version 2 below takes 77 / 66 us against 83 - 86 / 66 - 70 for the launches it replaces; inside the training step, where the chip holds ~1.4 GHz instead of
+// ~1.95, it takes 109 / 76 us against 84 / 68 (step 12.30 -> 12.79 ms): this kernel is bound by instruction issue and LDS / DMA latency, the 8-phase launches by
+// bandwidth.  DESIGN.md section 3 "Round 6" and profiles/r06_mlp_fused.txt have the measurements; tools/mlp_lab.py / mlp_stamps.py are the instruments.
 //
+// The idea.  The two launches write the hidden activation (57.8 MB), drain, fill again and read it back; each runs its K loop at what one CU pulls from L2 and
+// its store phase at what the chip writes, one after the other.  Here a workgroup keeps its 128 rows of X as MFMA fragments in REGISTERS for the whole kernel, the
+// hidden chunk never leaves the registers either -- the accumulator layout of phase 1 (lane (fr, g) holds 8 consecutive hidden units of row fr) IS the operand
+// layout of phase 2 -- and the only thing that streams through LDS is the weights: 2 * 3 C * C * 2 bytes per workgroup, in 8-KB pieces by LDS-DMA.
+//
+// Version 1 (this kernel, AP_MLP_FUSED_V=1; 111 / 81 us: abandoned for version 2 further down):
 //   workgroup : 256 threads = 4 waves, ONE per SIMD (the kernel is a 512-register kernel: 96 registers of X fragments + 192 of output accumulators
 //               at C = 384); wave w owns rows 32 w .. 32 w + 31 of the block in BOTH phases, so nothing is exchanged between waves -- the four
 //               waves share only the weight stream

@@ -374,9 +374,9 @@ def _launch_wgrads(problems, ln=None):
 STORE_GELU_GRAD = int(os.environ.get("AP_GELU_STORE_GRAD", "2"))
 
 
-# Round 6: the MLP of a transformer block as ONE launch per direction (csrc/mlp_fused.hip; C = 384, whole 128-row blocks).  Bit-identical to the
-# two launches it replaces and, measured, SLOWER than them (DESIGN.md section 3 "Round 6": 111 against 80 us forward, 81 against 65 backward at
-# 25088 rows): off by default, kept behind AP_FUSED_MLP=1 with its parity tests.
+# Round 6: the MLP of a transformer block as ONE launch per direction (csrc/mlp_fused.hip; C = 384, whole 128-row blocks).  Bit-identical to the two
+# launches it replaces; 7 - 10 % / 3 - 5 % faster than them between Python calls and SLOWER inside the training step (109 / 76 us against 84 / 68 at
+# 25088 rows, step 12.30 -> 12.79 ms: DESIGN.md section 3 "Round 6").  Off by default, kept behind AP_FUSED_MLP=1 with its parity tests.
 FUSED_MLP = os.environ.get("AP_FUSED_MLP", "0") == "1"
 
 

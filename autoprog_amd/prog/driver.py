@@ -156,7 +156,10 @@ class AutoProgDriver:
             (loss if k == 1 else loss / k).backward()
             self.reducer.finish()
             total = loss.detach() if total is None else total + loss.detach()
-        self.opt.step(clip_grad=self.clip_grad, clip_mode=self.clip_mode)
+        if self.clip_grad is not None:
+            self.opt.step(clip_grad=self.clip_grad, clip_mode=self.clip_mode)
+        else:
+            self.opt.step()                       # (any optimizer with the plain step() of the reference's loop works when nothing is clipped)
         return total if k == 1 else total / k
 
     def _eager(self):
