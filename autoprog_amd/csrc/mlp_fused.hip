@@ -464,7 +464,7 @@ __device__ unsigned long long mf_stamps[2 * 32 * 4 * 2];
 //               the last one; the slots without a chunk are loaded from the neighbouring chunk so that every count stays constant)
 //   LDS       : ring 5 x 24 KB | hidden chunk hand-off 16 KB | GELU table 16 KB | fc1 bias
 // (the table sits at LDS address 0: a table entry's byte offset is then the whole address of its ds_read_b32)
-constexpr int M2_TAB = 0, M2_BIAS = 16384, M2_A = 21504, M2_RING = M2_A + 16384, M2_LDS_BYTES = M2_RING + MF_RING;
+constexpr int M2_TAB = 0, M2_BIAS = 16384, M2_A = 21504, M2_RING = M2_A + 16384, M2_BIAS2 = M2_RING + MF_RING, M2_SCRATCH = M2_BIAS2 + 1536, M2_LDS_BYTES = M2_SCRATCH + 1024;
 static_assert(M2_LDS_BYTES <= 163840 && M2_BIAS + 4608 <= M2_A, "LDS");
 
 // LDS byte offsets of the table entries of the two bf16 values packed in w (gq_tab_index<0> / <16> times four), with packed 16-bit arithmetic:
@@ -494,6 +494,8 @@ __global__ void __launch_bounds__(512, 2) k_mlp_fused2(MlpArgs a) {
     if constexpr (!BWD) {                        // the fc1 bias into LDS, before any DMA is in flight
         float* lb = reinterpret_cast<float*>(mf_smem + M2_BIAS);
         for (int i = tid; i < a.Hd; i += 512) lb[i] = a.bias1 ? a.bias1[i] : 0.f;
+        float* lb2 = reinterpret_cast<float*>(mf_smem + M2_BIAS2);
+        for (int i = tid; i < C; i += 512) lb2[i] = a.bias2 ? a.bias2[i] : 0.f;
         __syncthreads();
     }
     const int lane_off0 = fr * 128 + ((g ^ (fr & 7)) << 4), lane_off1 = fr * 128 + (((4 + g) ^ (fr & 7)) << 4);
@@ -516,6 +518,20 @@ __global__ void __launch_bounds__(512, 2) k_mlp_fused2(MlpArgs a) {
 
     if (!roleB) {
         // ================================================================ role A: phase 1 + the chunk's epilogue
+        // The weights into THIS XCD's L2, ahead of the ring.  In the training step every block's weights come from memory (tools/check_mlp.py re-reads
+        // one set from L2: 69 us; with cold caches the same launch took 93, the two launches it replaces 84): the ring keeps three slots in flight, which
+        // covers an L2 hit, not a miss.  One 4-byte LDS-DMA per 128-byte line is enough to bring the line in -- a wave instruction touches 64 lines = 8 KB --
+        // so the workgroups that share an XCD (blockIdx % 8) split the 216 8-KB units of the two matrices between them: two or three instructions per
+        // producer wave, into a 256-byte scratch nobody reads, never waited for.
+        if (!(MF_ABL & 4)) {
+            const int xi = blockIdx.x >> 3, nx = (gridDim.x + 7) >> 3;
+            const int unitsA = a.Hd * a.ldwa * 2 / 8192, units = unitsA + C * a.ldwb * 2 / 8192;
+            for (int u = xi + nx * wave; u < units; u += nx * 4) {
+                const unsigned char* base = u < unitsA ? reinterpret_cast<const unsigned char*>(a.Wa) + (size_t)u * 8192
+                                                       : reinterpret_cast<const unsigned char*>(a.Wb) + (size_t)(u - unitsA) * 8192;
+                __builtin_amdgcn_global_load_lds(MF_GLB(base + lane * 128), MF_LDS(mf_smem + M2_SCRATCH + wave * 256), 4, 0, 0);
+            }
+        }
         u32x4 xf[2][KS];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -826,33 +842,73 @@ __global__ void __launch_bounds__(512, 2) k_mlp_fused2(MlpArgs a) {
             MF_STAMP(1, t, q, 1);
         });
     }
-    // ---- out: lane (fr, g) holds columns 32 tp + 8 g .. + 7 of row fr (tiles 2 tp, 2 tp + 1)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    // ---- out: lane (fr, g) holds columns 32 tp + 8 g .. + 7 of row fr (tiles 2 tp, 2 tp + 1).  Forward with a residual: its 24 chunks per lane through a
+    // three-deep pipeline of loads hipcc does not see, with counted waits -- written naively (a load, its use and the store per chunk, under the run-time
+    // `if (a.res)`) every chunk paid a memory latency: 26 000 cycles, a fifth of the launch (tools/mlp_stamps.py)
+    auto out_chunk = [&](int mt, int tp, const u32x4* r8, const u32x4* bb = nullptr) {
         const int64_t row = m0 + mt * 16 + fr;
+        const int col = tp * 32 + g * 8;
+        float v[8];
 #pragma unroll
-        for (int tp = 0; tp < C / 32; ++tp) {
-            const int col = tp * 32 + g * 8;
-            float v[8];
+        for (int r = 0; r < 4; ++r) { v[r] = oacc[mt][2 * tp][r]; v[4 + r] = oacc[mt][2 * tp + 1][r]; }
+        if constexpr (!BWD) {
+            if (bb) {                                   // (fc2's bias from LDS, zeros when there is none: adding +0 changes no bit of a finite sum)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = oacc[mt][2 * tp][r]; v[4 + r] = oacc[mt][2 * tp + 1][r]; }
-            if constexpr (!BWD) {
-                if (a.bias2) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(a.bias2 + col), b1 = *reinterpret_cast<const float4*>(a.bias2 + col + 4);
-                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                }
-                const float rs = rs2v[mt];
-                if (a.res) {
-                    const u32x4 r8 = ld16(a.res + row * a.ldr + col);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { v[2 * q] = __builtin_fmaf(v[2 * q], rs, bf_lo(r8[q])); v[2 * q + 1] = __builtin_fmaf(v[2 * q + 1], rs, bf_hi(r8[q])); }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] *= rs;
-                }
+                for (int q = 0; q < 4; ++q) { v[q] += __uint_as_float(bb[0][q]); v[4 + q] += __uint_as_float(bb[1][q]); }
+            } else if (a.bias2) {
+                const float4 b0 = *reinterpret_cast<const float4*>(a.bias2 + col), b1 = *reinterpret_cast<const float4*>(a.bias2 + col + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
             }
-            st16_nt(a.Out + row * a.ldo + col, pack8(v));
+            const float rs = rs2v[mt];
+            if (r8) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[2 * q] = __builtin_fmaf(v[2 * q], rs, bf_lo((*r8)[q])); v[2 * q + 1] = __builtin_fmaf(v[2 * q + 1], rs, bf_hi((*r8)[q])); }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] *= rs;
+            }
         }
+        st16_nt(a.Out + row * a.ldo + col, pack8(v));
+    };
+    constexpr int NCK = 2 * (C / 32);
+    bool piped = false;
+    if constexpr (!BWD) {
+        if (a.res) {
+            piped = true;
+            mf_vmcnt<0>();                         // (what is left of this wave's DMA: nothing is read from the ring any more, but the counts below start at zero)
+            u32x4 rb[3] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+            auto rload = [&](u32x4& d, int c) {
+                const bf16_t* rp = a.res + (int64_t)(m0 + (c / (C / 32)) * 16 + fr) * a.ldr + (c % (C / 32)) * 32 + g * 8;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(d) : "v"(rp) : "memory");
+            };
+            rload(rb[0], 0); rload(rb[1], 1); rload(rb[2], 2);
+            // fc2's bias of a chunk's eight columns out of LDS, one chunk ahead (inline asm: a bias LOAD from memory inside this loop would
+            // make hipcc wait for every load in flight)
+            const unsigned b2a = smem_a + M2_BIAS2 + g * 32;
+            u32x4 bb[2][2];
+            bb[0][0] = lds_ld16(b2a); bb[0][1] = lds_ld16(b2a + 16);
+            mf_for<0, NCK>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                if constexpr (c + 1 < NCK) {
+                    bb[(c + 1) & 1][0] = lds_ld16(b2a + ((c + 1) % (C / 32)) * 128); bb[(c + 1) & 1][1] = lds_ld16(b2a + ((c + 1) % (C / 32)) * 128 + 16);
+                }
+                // younger than the load of chunk c: the loads of c + 1, c + 2 (while they exist) and the stores of c - 2, c - 1 (from chunk 2 on)
+                constexpr int younger = (c + 1 < NCK) + (c + 2 < NCK) + (c >= 1) + (c >= 2);
+                mf_vmcnt<younger>();
+                if constexpr (c + 1 < NCK) mf_lgkmcnt<2>(); else mf_lgkmcnt<0>();       // this chunk's bias (the next one's two reads may be in flight)
+                asm volatile("" : "+v"(rb[c % 3]), "+v"(bb[c & 1][0]), "+v"(bb[c & 1][1]));
+                const u32x4 r8 = rb[c % 3];
+                const u32x4 b8[2] = {bb[c & 1][0], bb[c & 1][1]};
+                out_chunk(c / (C / 32), c % (C / 32), &r8, b8);
+                if constexpr (c + 3 < NCK) rload(rb[c % 3], c + 3);
+            });
+        }
+    }
+    if (!piped) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int tp = 0; tp < C / 32; ++tp) out_chunk(mt, tp, nullptr);
     }
     MF_STAMP(1, NCH + 1, 0, 0);
 }

@@ -375,9 +375,10 @@ STORE_GELU_GRAD = int(os.environ.get("AP_GELU_STORE_GRAD", "2"))
 
 
 # Round 6: the MLP of a transformer block as ONE launch per direction (csrc/mlp_fused.hip; C = 384, whole 128-row blocks).  Bit-identical to the two
-# launches it replaces; 7 - 10 % / 3 - 5 % faster than them between Python calls and SLOWER inside the training step (109 / 76 us against 84 / 68 at
-# 25088 rows, step 12.30 -> 12.79 ms: DESIGN.md section 3 "Round 6").  Off by default, kept behind AP_FUSED_MLP=1 with its parity tests.
-FUSED_MLP = os.environ.get("AP_FUSED_MLP", "0") == "1"
+# launches it replaces.  AP_FUSED_MLP: 1 (default) both directions, 2 forward only, 0 off (the two ap_gemm_nt launches).  In the step the forward launch takes
+# 77 us against 51 + 35, the backward 70 against 43 + 27 (DESIGN.md section 3 "Round 6": it needed its weights prefetched into L2 to get there).
+FUSED_MLP = int(os.environ.get("AP_FUSED_MLP", "1") or 0)
+FUSED_MLP_BWD = FUSED_MLP == 1
 
 
 def _gelu_bwd_kw(h):
@@ -693,7 +694,7 @@ class TransformerBlockFn(torch.autograd.Function):
                     dh8 = fp8_scales.quantize(("g", id(fc1_w)), dh)
             else:
                 fused = None
-                if FUSED_MLP and h.dtype == torch.uint8 and ops.mlp_fused_ok(dy2.shape[0], dy2.shape[1], h.shape[1]):
+                if FUSED_MLP and FUSED_MLP_BWD and h.dtype == torch.uint8 and ops.mlp_fused_ok(dy2.shape[0], dy2.shape[1], h.shape[1]):
                     # both input-gradient products of the MLP in one launch; the weight gradients read dL/dh and dL/dy as before
                     fused = ops.mlp_fused(dy2, bank.get_t(fc2_w), bank.get_t(fc1_w), backward=True, codes=h, row_scale_hidden=rs2, rows_per_scale=N)
                 if fused is not None:

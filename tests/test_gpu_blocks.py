@@ -310,7 +310,8 @@ def test_transformer_block_with_the_fused_mlp_is_the_block_bit_for_bit(monkeypat
     dy = torch.randn(32, 14, 14, 384, generator=g).to(torch.bfloat16).cuda()
     outs = {}
     for fused in (False, True):
-        monkeypatch.setattr(AF, "FUSED_MLP", fused)
+        monkeypatch.setattr(AF, "FUSED_MLP", 1 if fused else 0)
+        monkeypatch.setattr(AF, "FUSED_MLP_BWD", fused)
         blk.zero_grad(set_to_none=True)
         torch.manual_seed(5)                      # the same DropPath draws
         xg = x.clone().requires_grad_(True)
