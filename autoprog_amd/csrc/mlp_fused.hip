@@ -9,10 +9,11 @@
 //   backward : X = dL/dy, Wa = fc2.weight^T copy [Hd, C], Wb = fc1.weight^T copy [C, Hd];  f: dh = bf16(acc g'(code) rs1), stored for the weight
 //              gradients;  epi2: out = bf16(acc) = dL/d(LN2 x)
 //
-// STATUS (round 6): bit-identical to the two launches in both directions and OFF by default (functional.FUSED_MLP / AP_FUSED_MLP=1).  Between Python calls
-// version 2 below takes 77 / 66 us against 83 - 86 / 66 - 70 for the launches it replaces; inside the training step, where the chip holds ~1.4 GHz instead of
-// ~1.95, it takes 109 / 76 us against 84 / 68 (step 12.30 -> 12.79 ms): this kernel is bound by instruction issue and LDS / DMA latency, the 8-phase launches by
-// bandwidth.  DESIGN.md section 3 "Round 6" and profiles/r06_mlp_fused.txt have the measurements; tools/mlp_lab.py / mlp_stamps.py are the instruments.
+// STATUS (round 6): bit-identical to the two launches in both directions and ON by default (functional.FUSED_MLP / AP_FUSED_MLP=0 switches it off).  Version 2
+// below takes 74 - 76 / 68 - 69 us between Python calls and 77 / 70 us inside the training step, against 51 + 35 / 43 + 27 for the launches it replaces (step
+// 12.27 -> 12.09 ms on one box).  It was SLOWER in the step (109 / 76 us) until the weights were prefetched into L2 at kernel start: every workgroup streams all
+// 1.77 MB of weights through a ring that covers an L2 hit, not a miss, and in the step the weights are cold (tools/check_mlp_cold.py reproduces that outside the
+// step).  DESIGN.md section 3 "Round 6" and profiles/r06_mlp_fused.txt have the measurements; tools/mlp_lab.py / mlp_stamps.py are the instruments.
 //
 // The idea.  The two launches write the hidden activation (57.8 MB), drain, fill again and read it back; each runs its K loop at what one CU pulls from L2 and
 // its store phase at what the chip writes, one after the other.  Here a workgroup keeps its 128 rows of X as MFMA fragments in REGISTERS for the whole kernel, the

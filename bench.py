@@ -182,6 +182,7 @@ class GemmProbe:
         self.bytes = 0.0
         self.fp8_launches = 0
         self.fp8_flops = 0.0
+        self.fused_launches = 0
 
     def install(self):
         from autoprog_amd import ops
@@ -224,11 +225,33 @@ class GemmProbe:
             probe.fp8_flops += 2.0 * a8.shape[0] * nn * kk
             return out
         ops.gemm_nt_fp8 = timed8
+        # the fused MLP launches (ops.mlp_fused: fc1 -> GELU -> fc2 and its backward mirror, csrc/mlp_fused.hip) replace two ap_gemm_nt
+        # launches each and stay in the family: the FLOPs of both products, the bytes of every operand once
+        self._origm = ops.mlp_fused
+
+        def timedm(x, wa, wb, backward=False, **kw):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = probe._origm(x, wa, wb, backward=backward, **kw)
+            e1.record()
+            if out is None:                # refused (shape / capture): the caller falls back to the two launches, which are counted there
+                return out
+            M, C, Hd = x.shape[0], x.shape[1], wa.shape[0]
+            probe.records.append((e0, e1, 4.0 * M * C * Hd))
+            probe.keys.append((M, Hd, C, "fused-mlp-bwd" if backward else "fused-mlp-fwd"))
+            # x + both weights + out (+ residual forward), the hidden tensor in bf16 (forward: fc2's operand for its weight gradient;
+            # backward: fc1's output gradient) and the one-byte gelu' codes (written forward, read backward)
+            probe.bytes += 2.0 * (M * C * (2 if backward or kw.get("residual") is None else 3) + 2 * C * Hd + M * Hd) + 1.0 * M * Hd
+            probe.fused_launches += 1
+            return out
+        ops.mlp_fused = timedm
 
     def remove(self):
         from autoprog_amd import ops
         ops.gemm_nt = self._orig
         ops.gemm_nt_fp8 = self._orig8
+        ops.mlp_fused = self._origm
 
     def table(self):
         """per-shape HIP-event times INSIDE the training step (AP_GEMM_TABLE=1): the ground truth for tile-variant choices --
@@ -650,7 +673,7 @@ def main():
         except (OSError, ValueError):
             pass
         hbm_bound = ai < ridge
-        roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": "ap_gemm_nt launches (k_gemm_nt_8p<...> + k_gemm_nt_ws<...> + k_gemm_nt<...>)",
+        roofline = {"bound": "hbm" if hbm_bound else "mfma", "kernel": "ap_gemm_nt + ap_mlp_fused launches (k_gemm_nt_8p<...> + k_gemm_nt_ws<...> + k_gemm_nt<...> + k_mlp_fused2<...>)",
                     "achieved": round(tbs * 1e3 if hbm_bound else tflops, 2), "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else round(peak_mfma, 1),
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
                     "frac": round(tbs / PEAK_HBM_TBS if hbm_bound else tflops / peak_mfma, 4), "traffic": traffic,
@@ -659,7 +682,8 @@ def main():
                     "fp8_flop_share": round(probe.fp8_flops / flops, 4) if flops else 0.0,
                     "hbm_tbs_algorithmic": round(tbs, 3), "hbm_frac": round(tbs / PEAK_HBM_TBS, 4),
                     "algorithmic_bytes_per_launch": round(probe.bytes / max(launches, 1)),
-                    "launches_per_step": launches // nprobe, "fp8_launches_per_step": probe.fp8_launches // nprobe, "avg_launch_us": round(ms * 1e3 / launches, 2),
+                    "launches_per_step": launches // nprobe, "fp8_launches_per_step": probe.fp8_launches // nprobe,
+                    "fused_mlp_launches_per_step": probe.fused_launches // nprobe, "avg_launch_us": round(ms * 1e3 / launches, 2),
                     "gemm_ms_per_step": round(ms / nprobe, 3), "gemm_gflop_per_step": round(flops / nprobe / 1e9, 1)}
 
     cpu = None

@@ -24,7 +24,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
 done
 { echo "# rocprofv3 --pmc <one group per pass> -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --prewarm-s 0 --no-calibration ; per-dispatch averages"
   echo "# FETCH_SIZE/WRITE_SIZE are in KB; gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md): double it."
-  python3 tools/pmc_summary.py gpurun_out/_pmc k_gemm k_ln k_mhsa k_outlook k_soft_ce k_bn k_adamw k_conv3x3 igemm kernel_grouped_conv; } > gpurun_out/${ROUND}_pmc_counters.txt
+  python3 tools/pmc_summary.py gpurun_out/_pmc k_gemm k_mlp_fused k_ln k_mhsa k_outlook k_soft_ce k_bn k_adamw k_conv3x3 igemm kernel_grouped_conv; } > gpurun_out/${ROUND}_pmc_counters.txt
 ROUND=$ROUND python3 - <<'PY'
 import re, json, os, sys
 sys.path.insert(0, ".")
@@ -33,15 +33,15 @@ txt = open("gpurun_out/%s_pmc_counters.txt" % R).read()
 blocks = re.split(r"\n(?=\S)", txt)
 fetch = write = n = 0.0
 for b in blocks:
-    if b.startswith("void k_gemm_nt<") or b.startswith("void k_gemm_nt_8p<") or b.startswith("void k_gemm_nt_ws<") or b.startswith("k_gemm_nt_skinny"):
+    if b.startswith("void k_gemm_nt<") or b.startswith("void k_gemm_nt_8p<") or b.startswith("void k_gemm_nt_ws<") or b.startswith("k_gemm_nt_skinny") or b.startswith("void k_mlp_fused"):
         mf = re.search(r"FETCH_SIZE\s+avg\s+([\d.]+)\s+over (\d+)", b); mw = re.search(r"WRITE_SIZE\s+avg\s+([\d.]+)", b)
         if mf and mw:
             k = int(mf.group(2)); fetch += float(mf.group(1)) * k; write += float(mw.group(1)) * k; n += k
 if n:
     per = (2.0 * fetch + write) / n * 1024.0
     import bench
-    json.dump({"kernel": "k_gemm_nt_8p + k_gemm_nt_ws + k_gemm_nt (all instantiations)", "hbm_bytes_per_launch": round(per), "launches": int(n),
-               "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB per dispatch, dispatch-weighted over the k_gemm_nt* instantiations",
+    json.dump({"kernel": "k_gemm_nt_8p + k_gemm_nt_ws + k_gemm_nt + k_mlp_fused2 (all instantiations)", "hbm_bytes_per_launch": round(per), "launches": int(n),
+               "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB per dispatch, dispatch-weighted over the k_gemm_nt* and k_mlp_fused* instantiations",
                "source": "profiles/%s_pmc_counters.txt" % R, "src_sha256": bench.kernel_source_hash()}, open("gpurun_out/gemm_nt_traffic.json", "w"))
 PY
 python3 tools/pmc_table.py gpurun_out/${ROUND}_pmc_counters.txt gpurun_out/${ROUND}_kernel_stats.txt > gpurun_out/${ROUND}_kernel_table.txt
