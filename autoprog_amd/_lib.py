@@ -24,7 +24,9 @@ class MlpFusedArgs(Structure):
     _fields_ = [("x", c_void_p), ("ldx", c_int), ("wa", c_void_p), ("ldwa", c_int), ("wb", c_void_p), ("ldwb", c_int), ("out", c_void_p), ("ldo", c_int),
                 ("hidden_out", c_void_p), ("ldh", c_int), ("codes", c_void_p), ("bias1", c_void_p), ("bias2", c_void_p),
                 ("row_scale_hidden", c_void_p), ("row_scale_out", c_void_p), ("rows_per_scale", c_int), ("residual", c_void_p), ("ldr", c_int),
-                ("m", c_int), ("c", c_int), ("hidden", c_int), ("backward", c_int)]
+                ("m", c_int), ("c", c_int), ("hidden", c_int), ("backward", c_int),
+                ("ln_in", c_void_p), ("ld_ln", c_int), ("ln_out", c_void_p), ("ld_lno", c_int), ("ln_gamma", c_void_p), ("ln_beta", c_void_p),
+                ("ln_eps", c_float), ("ln_mean", c_void_p), ("ln_rstd", c_void_p)]
 
 
 class TnProblem(Structure):

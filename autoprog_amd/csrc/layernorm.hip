@@ -186,7 +186,7 @@ k_ln_fwd_lp(const bf16_t* __restrict__ x, const float* __restrict__ gamma, const
                 const int ch = lane_in_group + i * G;
                 if (ch < nchunks) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
+                    for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q = __builtin_fmaf(d, d, q); }     // (an explicit fma: mlp_fused.hip's in-kernel LayerNorm repeats this sum bit for bit)
                 }
             }
             for (int o = G >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);

@@ -62,6 +62,9 @@ struct MlpArgs {
     const bf16_t* res; int ldr;
     const unsigned* gelu_tab;
     int M, Hd;
+    // forward, optional (k_mlp_fused2<C, false, true>): X holds the rows BEFORE the LayerNorm in front of fc1; the producer waves normalise
+    // them in registers, write them to LnOut (row stride ldlo; the fc1 weight gradient reads them) and the row statistics to LnMean / LnRstd
+    bf16_t* LnOut; int ldlo; const float* LnG; const float* LnB; float ln_eps; float* LnMean; float* LnRstd;
 };
 
 constexpr int MF_BM = 128, MF_PIECE = 8192, MF_SLOT = 3 * MF_PIECE, MF_NSLOT = 5, MF_LA = 3, MF_DMA = 6;
@@ -479,8 +482,9 @@ __device__ __forceinline__ void mf_tab_addr2(unsigned w, unsigned& a0, unsigned&
     a1 = idx4 >> 16;
 }
 
-template <int C, bool BWD>
+template <int C, bool BWD, bool LN = false>
 __global__ void __launch_bounds__(512, 2) k_mlp_fused2(MlpArgs a) {
+    static_assert(!(BWD && LN), "the LayerNorm in front of fc1 belongs to the forward launch");
     static_assert(C == 384, "version 2 is written for C = 384 (six pieces per phase, two slots per phase)");
     constexpr int PP = C / 64, NCH = 3 * C / 64, KS = C / 32, NT2 = C / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
@@ -497,6 +501,16 @@ __global__ void __launch_bounds__(512, 2) k_mlp_fused2(MlpArgs a) {
         for (int i = tid; i < a.Hd; i += 512) lb[i] = a.bias1 ? a.bias1[i] : 0.f;
         float* lb2 = reinterpret_cast<float*>(mf_smem + M2_BIAS2);
         for (int i = tid; i < C; i += 512) lb2[i] = a.bias2 ? a.bias2[i] : 0.f;
+        if constexpr (LN) {                      // gamma | beta in the hand-off buffer, which nobody writes before the second slot barrier
+            // column c = 32 (4 i + 2 p + e) + 8 g + k  ->  float ((((g * KS / 4 + i) * 2 + p) * 8 + k) * 2 + e: the lanes of group g read their
+            // 2 x 8 x 2 values of (i, p) as four 16-byte words {(k, e = 0), (k, 1), (k + 1, 0), (k + 1, 1)}
+            float* lg = reinterpret_cast<float*>(mf_smem + M2_A);
+            for (int c = tid; c < 2 * C; c += 512) {
+                const int cc = c < C ? c : c - C, sidx = cc >> 5, gq = (cc >> 3) & 3, k = cc & 7;
+                const int idx = ((((gq * (KS / 4) + (sidx >> 2)) * 2 + ((sidx >> 1) & 1)) * 8 + k) * 2 + (sidx & 1));
+                lg[(c < C ? 0 : C) + idx] = c < C ? a.LnG[cc] : a.LnB[cc];
+            }
+        }
         __syncthreads();
     }
     const int lane_off0 = fr * 128 + ((g ^ (fr & 7)) << 4), lane_off1 = fr * 128 + (((4 + g) ^ (fr & 7)) << 4);
@@ -570,6 +584,76 @@ __global__ void __launch_bounds__(512, 2) k_mlp_fused2(MlpArgs a) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xf[mt][ks]));
             asm volatile("" : "+v"(rs1v[mt]));
+        }
+        if constexpr (LN) {
+            // LayerNorm of the wave's 32 rows, in the registers they were loaded into.  The arithmetic AND its order are k_ln_fwd_lp<3>'s (layernorm.hip:
+            // 16 lanes per row, lane q owns the 8-element chunks q, q + 16, q + 32, sums them in that order and the 16 partial sums meet in an xor
+            // butterfly 8, 4, 2, 1), so that the result is bit-identical to the separate launch: this lane (g = lane >> 4) holds chunks 4 i + j of its
+            // row, i.e. ALL chunks of the four "lanes" q = g + 4 j -- their partial sums are formed here in the same order, the butterfly's first two
+            // levels (q ^ 8, q ^ 4) pair chain j with j ^ 2 and j ^ 1 inside the lane, the last two (q ^ 2, q ^ 1) are lanes 32 and 16 apart.
+            // Chains 0 / 1 and 2 / 3 run as the two halves of packed fp32 instructions (v_pk_add / v_pk_fma / v_pk_mul: the same IEEE results per half).
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const float invC = 1.0f / (float)C;
+            const unsigned char* gb = mf_smem + M2_A + g * (KS / 4 * 2 * 64);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x2 v[KS / 4][2][8];                    // [i][chain pair][k]: .x = chunk 4 i + 2 p, .y = chunk 4 i + 2 p + 1
+#pragma unroll
+                for (int i = 0; i < KS / 4; ++i)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const unsigned w0 = xf[mt][4 * i + 2 * p][w], w1 = xf[mt][4 * i + 2 * p + 1][w];
+                            v[i][p][2 * w] = (f32x2){bf_lo(w0), bf_lo(w1)};
+                            v[i][p][2 * w + 1] = (f32x2){bf_hi(w0), bf_hi(w1)};
+                        }
+                f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < KS / 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { s01 += v[i][0][k]; s23 += v[i][1][k]; }
+                float sm = (s01.x + s23.x) + (s01.y + s23.y);
+                sm += __shfl_xor(sm, 32, 64);
+                sm += __shfl_xor(sm, 16, 64);
+                const float mu = sm * invC;
+                const f32x2 mu2 = {mu, mu};
+                f32x2 q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < KS / 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        v[i][0][k] -= mu2; v[i][1][k] -= mu2;
+                        q01 = __builtin_elementwise_fma(v[i][0][k], v[i][0][k], q01);
+                        q23 = __builtin_elementwise_fma(v[i][1][k], v[i][1][k], q23);
+                    }
+                float q = (q01.x + q23.x) + (q01.y + q23.y);
+                q += __shfl_xor(q, 32, 64);
+                q += __shfl_xor(q, 16, 64);
+                const float rsd = rsqrtf(q * invC + a.ln_eps);
+                if (g == 0) { a.LnMean[m0 + mt * 16 + fr] = mu; a.LnRstd[m0 + mt * 16 + fr] = rsd; }
+                const f32x2 rs2v = {rsd, rsd};
+#pragma unroll
+                for (int i = 0; i < KS / 4; ++i)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        unsigned o0[4], o1[4];
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            // gamma / beta of (k = 2 w, 2 w + 1) x (chunk 4 i + 2 p, + 1): one 16-byte read each (the staging loop interleaved them)
+                            const f32x4 gg = *reinterpret_cast<const f32x4*>(gb + ((i * 2 + p) * 4 + w) * 16);
+                            const f32x4 bb = *reinterpret_cast<const f32x4*>(gb + C * 4 + ((i * 2 + p) * 4 + w) * 16);
+                            const f32x2 e = __builtin_elementwise_fma(v[i][p][2 * w] * rs2v, (f32x2){gg[0], gg[1]}, (f32x2){bb[0], bb[1]});
+                            const f32x2 o = __builtin_elementwise_fma(v[i][p][2 * w + 1] * rs2v, (f32x2){gg[2], gg[3]}, (f32x2){bb[2], bb[3]});
+                            o0[w] = pack_bf2(e.x, o.x);
+                            o1[w] = pack_bf2(e.y, o.y);
+                        }
+                        xf[mt][4 * i + 2 * p] = (u32x4){o0[0], o0[1], o0[2], o0[3]};
+                        xf[mt][4 * i + 2 * p + 1] = (u32x4){o1[0], o1[1], o1[2], o1[3]};
+                        st16_nt(a.LnOut + (int64_t)(m0 + mt * 16 + fr) * a.ldlo + (4 * i + 2 * p) * 32 + g * 8, xf[mt][4 * i + 2 * p]);
+                        st16_nt(a.LnOut + (int64_t)(m0 + mt * 16 + fr) * a.ldlo + (4 * i + 2 * p + 1) * 32 + g * 8, xf[mt][4 * i + 2 * p + 1]);
+                    }
+            }
         }
         f32x4 hacc[2][4];
 #pragma unroll
@@ -934,28 +1018,34 @@ const unsigned* g8_gelu_table_ptr(hipStream_t st) {
 }
 #endif
 
-template <int C, bool BWD>
+template <int C, bool BWD, bool LN = false>
 static int mf_launch(const MlpArgs& a, hipStream_t st) {
     static int version = 0;                  // AP_MLP_FUSED_V = 1: the one-wave-per-SIMD kernel; default 2: producer / consumer waves
     if (!version) { const char* e = getenv("AP_MLP_FUSED_V"); version = (e && e[0] == '1') ? 1 : 2; }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)k_mlp_fused<C, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)k_mlp_fused2<C, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, M2_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)k_mlp_fused2<C, BWD, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, M2_LDS_BYTES);
         attr = true; (void)hipGetLastError();
     }
+    if (version == 1 && LN) return AP_ERR_UNSUPPORTED;
     if (version == 1) hipLaunchKernelGGL((k_mlp_fused<C, BWD>), dim3(a.M / MF_BM), dim3(256), MF_LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((k_mlp_fused2<C, BWD>), dim3(a.M / MF_BM), dim3(512), M2_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((k_mlp_fused2<C, BWD, LN>), dim3(a.M / MF_BM), dim3(512), M2_LDS_BYTES, st, a);
     return ap_check_launch();
 }
 
 extern "C" {
 
 int ap_mlp_fused(const ap_mlp_fused_args* p, ap_stream_t stream) {
-    if (!p || !p->x || !p->wa || !p->wb || !p->out || !p->hidden_out || !p->codes) return AP_ERR_NULL;
+    if (!p || !p->wa || !p->wb || !p->out || !p->hidden_out || !p->codes) return AP_ERR_NULL;
+    const bool ln = p->ln_in != nullptr;
+    if (!ln && !p->x) return AP_ERR_NULL;
+    if (ln && (!p->ln_out || !p->ln_gamma || !p->ln_beta || !p->ln_mean || !p->ln_rstd)) return AP_ERR_NULL;
+    if (ln && (p->backward || (p->ld_ln & 7) || p->ld_ln < p->c || (p->ld_lno & 7) || p->ld_lno < p->c)) return AP_ERR_SHAPE;
     const int C = p->c, Hd = p->hidden, M = p->m;
     if (M <= 0 || C <= 0 || Hd <= 0) return AP_ERR_SHAPE;
-    if ((p->ldx & 7) || (p->ldwa & 7) || (p->ldwb & 7) || (p->ldo & 7) || (p->ldh & 7) || p->ldx < C || p->ldwa < C || p->ldwb < Hd || p->ldo < C || p->ldh < Hd)
+    if (!ln && ((p->ldx & 7) || p->ldx < C)) return AP_ERR_SHAPE;
+    if ((p->ldwa & 7) || (p->ldwb & 7) || (p->ldo & 7) || (p->ldh & 7) || p->ldwa < C || p->ldwb < Hd || p->ldo < C || p->ldh < Hd)
         return AP_ERR_SHAPE;
     if (p->residual && ((p->ldr & 7) || p->ldr < C)) return AP_ERR_SHAPE;
     if (p->backward && (p->bias1 || p->bias2 || p->residual || p->row_scale_out)) return AP_ERR_SHAPE;
@@ -967,11 +1057,16 @@ int ap_mlp_fused(const ap_mlp_fused_args* p, ap_stream_t stream) {
     a.Hout = p->hidden_out; a.ldh = p->ldh; a.G = p->codes; a.bias1 = p->bias1; a.bias2 = p->bias2;
     a.rs1 = p->row_scale_hidden; a.rs2 = p->row_scale_out; a.rows_per_scale = p->rows_per_scale > 0 ? p->rows_per_scale : 1;
     a.res = p->residual; a.ldr = p->ldr; a.gelu_tab = nullptr; a.M = M; a.Hd = Hd;
+    a.LnOut = nullptr; a.ldlo = 0; a.LnG = a.LnB = nullptr; a.ln_eps = 0.f; a.LnMean = a.LnRstd = nullptr;
+    if (ln) {
+        a.X = p->ln_in; a.ldx = p->ld_ln; a.LnOut = p->ln_out; a.ldlo = p->ld_lno; a.LnG = p->ln_gamma; a.LnB = p->ln_beta; a.ln_eps = p->ln_eps;
+        a.LnMean = p->ln_mean; a.LnRstd = p->ln_rstd;
+    }
     (void)hipGetLastError();
     if (!p->backward) {
         a.gelu_tab = g8_gelu_table_ptr(st);
         if (!a.gelu_tab) return AP_ERR_UNSUPPORTED;            // (AP_GELU_TABLE=0, or a capture in front of the table's first build)
-        return mf_launch<384, false>(a, st);
+        return ln ? mf_launch<384, false, true>(a, st) : mf_launch<384, false>(a, st);
     }
     return mf_launch<384, true>(a, st);
 }

@@ -379,6 +379,8 @@ STORE_GELU_GRAD = int(os.environ.get("AP_GELU_STORE_GRAD", "2"))
 # 77 us against 51 + 35, the backward 70 against 43 + 27 (DESIGN.md section 3 "Round 6": it needed its weights prefetched into L2 to get there).
 FUSED_MLP = int(os.environ.get("AP_FUSED_MLP", "1") or 0)
 FUSED_MLP_BWD = FUSED_MLP == 1
+# AP_FUSED_MLP_LN=1: the LayerNorm in front of fc1 inside the fused forward launch (bit-identical to ap_layernorm_fwd; one launch less per block)
+FUSED_MLP_LN = os.environ.get("AP_FUSED_MLP_LN", "1") == "1"
 
 
 def _gelu_bwd_kw(h):
@@ -647,15 +649,22 @@ class TransformerBlockFn(torch.autograd.Function):
         else:
             o, lse = ops.mhsa_fwd(qkv, B, N, heads, scale, out_row_scale=k1)                   # rows of dropped samples: zeros
         x1 = _linear_fwd(o, proj_w, x8=oq, bias=proj_b, row_scale=rs1, rows_per_scale=N, residual=x2)
-        xn2, m2, r2, xq = _ln_fwd_for(x1, n2w, n2b, eps, fc1_w)
         fused = None
-        if FUSED_MLP and STORE_GELU_GRAD == 2 and not FP8_LINEAR and ops.mlp_fused_ok(B * N, C, fc1_w.shape[0]):
-            # fc1 -> GELU -> fc2 (+ DropPath scale + residual) in ONE launch (csrc/mlp_fused.hip): bit-identical to the two launches below
-            fused = ops.mlp_fused(xn2, bank.get(fc1_w), bank.get(fc2_w), bias1=fc1_b, bias2=fc2_b, row_scale_hidden=k2, row_scale_out=rs2,
-                                  rows_per_scale=N, residual=x1)
-        if fused is not None:
-            y, a, h = fused
-        else:
+        use_fused = FUSED_MLP and STORE_GELU_GRAD == 2 and not FP8_LINEAR and ops.mlp_fused_ok(B * N, C, fc1_w.shape[0])
+        if use_fused and FUSED_MLP_LN:
+            # LN2 -> fc1 -> GELU -> fc2 (+ DropPath scale + residual) in ONE launch (csrc/mlp_fused.hip): bit-identical to the three launches
+            fused = ops.mlp_fused(None, bank.get(fc1_w), bank.get(fc2_w), bias1=fc1_b, bias2=fc2_b, row_scale_hidden=k2, row_scale_out=rs2,
+                                  rows_per_scale=N, residual=x1, ln=(x1, n2w, n2b, eps))
+            if fused is not None:
+                y, a, h, xn2, m2, r2 = fused
+        if fused is None:
+            xn2, m2, r2, xq = _ln_fwd_for(x1, n2w, n2b, eps, fc1_w)
+            if use_fused:
+                fused = ops.mlp_fused(xn2, bank.get(fc1_w), bank.get(fc2_w), bias1=fc1_b, bias2=fc2_b, row_scale_hidden=k2, row_scale_out=rs2,
+                                      rows_per_scale=N, residual=x1)
+                if fused is not None:
+                    y, a, h = fused
+        if fused is None:
             h = _gelu_side_buffer(B * N, fc1_w.shape[0], x.device)
             a, aq = _linear_fwd(xn2, fc1_w, x8=xq, emit_for=fc2_w, bias=fc1_b, gelu=True, preact_out=h, preact_grad=STORE_GELU_GRAD, row_scale=k2, rows_per_scale=N)
             y = _linear_fwd(a, fc2_w, x8=aq, bias=fc2_b, row_scale=rs2, rows_per_scale=N, residual=x1)

@@ -214,12 +214,16 @@ def mlp_fused_ok(M, C, hidden):
 
 
 def mlp_fused(x, wa, wb, backward=False, bias1=None, bias2=None, row_scale_hidden=None, row_scale_out=None, rows_per_scale=1,
-              residual=None, codes=None):
+              residual=None, codes=None, ln=None):
     """the MLP of a block in one launch (include/autoprog_hip.h ap_mlp_fused).
     forward : x [M, C], wa = fc1 weight [H, C], wb = fc2 weight [C, H] -> (out [M, C], a [M, H] = gelu(.) * row_scale_hidden, codes [M, H] uint8)
     backward: x = dL/dout, wa = fc2 weight^T copy [H, ld(C)], wb = fc1 weight^T copy [C, ld(H)], codes = the forward's -> (dL/dx [M, C], dL/dh [M, H], codes)
+    ln = (rows [M, C], gamma, beta, eps) (forward; x = None): the LayerNorm in front of fc1 runs inside the launch, bit-identical to
+    layernorm_fwd -> (out, a, codes, LN(rows), mean, rstd)
     -> None when the library does not take the launch (the caller issues the two ap_gemm_nt launches)"""
     from ._lib import MlpFusedArgs
+    if ln is not None:
+        x = _req(ln[0], BF16, "ln rows")
     _req(x, BF16, "x"); _req(wa, BF16, "wa"); _req(wb, BF16, "wb")
     M, C = x.shape
     H = wa.shape[0]
@@ -247,10 +251,20 @@ def mlp_fused(x, wa, wb, backward=False, bias1=None, bias2=None, row_scale_hidde
         _req(residual, BF16, "residual")
         a.residual, a.ldr = residual.data_ptr(), residual.shape[1]
     a.m, a.c, a.hidden, a.backward = M, C, H, 1 if backward else 0
+    if ln is not None:
+        xn = torch.empty((M, C), dtype=BF16, device=x.device)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        a.x = None
+        a.ln_in, a.ld_ln, a.ln_out, a.ld_lno = x.data_ptr(), C, xn.data_ptr(), C
+        a.ln_gamma, a.ln_beta = _req(ln[1], torch.float32, "ln gamma").data_ptr(), _req(ln[2], torch.float32, "ln beta").data_ptr()
+        a.ln_eps, a.ln_mean, a.ln_rstd = float(ln[3]), mean.data_ptr(), rstd.data_ptr()
     code = lib.ap_mlp_fused(ctypes.byref(a), _stream())
     if code == -2:                    # AP_ERR_UNSUPPORTED (e.g. the GELU table cannot be built inside a stream capture)
         return None
     check(code, "ap_mlp_fused")
+    if ln is not None:
+        return out, hid, codes, xn, mean, rstd
     return out, hid, codes
 
 

@@ -237,12 +237,15 @@ class GemmProbe:
             e1.record()
             if out is None:                # refused (shape / capture): the caller falls back to the two launches, which are counted there
                 return out
-            M, C, Hd = x.shape[0], x.shape[1], wa.shape[0]
+            rows = x if x is not None else kw["ln"][0]            # (ln=: the LayerNorm in front of fc1 runs inside the launch, on these rows)
+            M, C, Hd = rows.shape[0], rows.shape[1], wa.shape[0]
             probe.records.append((e0, e1, 4.0 * M * C * Hd))
             probe.keys.append((M, Hd, C, "fused-mlp-bwd" if backward else "fused-mlp-fwd"))
             # x + both weights + out (+ residual forward), the hidden tensor in bf16 (forward: fc2's operand for its weight gradient;
             # backward: fc1's output gradient) and the one-byte gelu' codes (written forward, read backward)
             probe.bytes += 2.0 * (M * C * (2 if backward or kw.get("residual") is None else 3) + 2 * C * Hd + M * Hd) + 1.0 * M * Hd
+            if kw.get("ln") is not None:       # the residual rows ARE the LayerNorm's input (read once); the normalised rows leave for the weight gradient
+                probe.bytes += 2.0 * M * C - (2.0 * M * C if kw.get("residual") is not None and kw["residual"].data_ptr() == rows.data_ptr() else 0.0) + 2.0 * M * C
             probe.fused_launches += 1
             return out
         ops.mlp_fused = timedm

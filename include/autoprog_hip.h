@@ -167,6 +167,13 @@ typedef struct ap_mlp_fused_args {
     const ap_bf16* residual; int ldr;        /* forward: [m, c] or NULL; backward: NULL */
     int m, c, hidden;
     int backward;
+    /* forward, optional: the LayerNorm in front of fc1 (Transformer.forward, models/volo.py:233 `self.mlp(self.norm2(x))`) inside the same
+     * launch.  ln_in non-NULL: x is ignored, the rows are read from ln_in [m, c], normalised with ln_gamma / ln_beta / ln_eps (bit-identical to
+     * ap_layernorm_fwd), written to ln_out [m, c] (the fc1 weight gradient reads them) and their statistics to ln_mean / ln_rstd [m] */
+    const ap_bf16* ln_in; int ld_ln;
+    ap_bf16* ln_out; int ld_lno;
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    float* ln_mean; float* ln_rstd;
 } ap_mlp_fused_args;
 int ap_mlp_fused(const ap_mlp_fused_args* args, ap_stream_t stream);
 

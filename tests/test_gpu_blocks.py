@@ -290,8 +290,9 @@ def test_transformer_block_kernels_vs_fp64_with_the_same_rounding_points():
 
 def test_transformer_block_with_the_fused_mlp_is_the_block_bit_for_bit(monkeypatch):
     """AP_FUSED_MLP (functional.FUSED_MLP; csrc/mlp_fused.hip, round 6): a D1-shaped transformer block (32 x 14 x 14 x 384 = 6272 rows, 12 heads,
-    DropPath factors on both branches) with its MLP as one launch per direction -- output, input gradient and EVERY parameter gradient equal
-    the unfused block's bit for bit (deterministic weight gradients), and the fused launches really ran."""
+    DropPath factors on both branches) with its MLP as one launch per direction, with and without the LayerNorm in front of it inside the
+    forward launch (functional.FUSED_MLP_LN) -- output, input gradient and EVERY parameter gradient equal the unfused block's bit for bit
+    (deterministic weight gradients), and the fused launches really ran."""
     from autoprog_amd import functional as AF, ops
     from autoprog_amd.models import volo as V
     monkeypatch.setattr(ops, "deterministic", True)
@@ -309,20 +310,31 @@ def test_transformer_block_with_the_fused_mlp_is_the_block_bit_for_bit(monkeypat
     x = torch.randn(32, 14, 14, 384, generator=g).to(torch.bfloat16).cuda()
     dy = torch.randn(32, 14, 14, 384, generator=g).to(torch.bfloat16).cuda()
     outs = {}
-    for fused in (False, True):
+    lns = []
+    real_ln = ops.layernorm_fwd
+
+    def counted_ln(*a, **kw):
+        lns.append(1)
+        return real_ln(*a, **kw)
+    monkeypatch.setattr(ops, "layernorm_fwd", counted_ln)
+    for fused in (False, True, "ln"):
         monkeypatch.setattr(AF, "FUSED_MLP", 1 if fused else 0)
-        monkeypatch.setattr(AF, "FUSED_MLP_BWD", fused)
+        monkeypatch.setattr(AF, "FUSED_MLP_BWD", bool(fused))
+        monkeypatch.setattr(AF, "FUSED_MLP_LN", fused == "ln")
         blk.zero_grad(set_to_none=True)
         torch.manual_seed(5)                      # the same DropPath draws
         xg = x.clone().requires_grad_(True)
         y = blk(xg)
         y.backward(dy)
         outs[fused] = (y.detach().clone(), xg.grad.clone(), {n: p_.grad.clone() for n, p_ in blk.named_parameters()})
-    assert calls == [True, True], calls           # one forward and one backward launch, in the fused pass only
-    (y0, dx0, g0), (y1, dx1, g1) = outs[False], outs[True]
-    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
-    for n in g0:
-        assert torch.equal(g0[n], g1[n]), n
+    assert calls == [True, True, True, True], calls           # one forward and one backward launch per fused pass
+    assert len(lns) == 2 + 2 + 1, lns                          # the LayerNorm in front of the MLP has no launch of its own in the last pass
+    (y0, dx0, g0) = outs[False]
+    for mode in (True, "ln"):
+        (y1, dx1, g1) = outs[mode]
+        assert torch.equal(y0, y1) and torch.equal(dx0, dx1), mode
+        for n in g0:
+            assert torch.equal(g0[n], g1[n]), (mode, n)
 
 
 def test_outlooker_block_kernels_vs_fp64_with_the_same_rounding_points():

@@ -305,8 +305,8 @@ def test_mlp_fused_is_the_two_launches_bit_for_bit(ops, M, drop):
     """round 6: csrc/mlp_fused.hip -- fc1 -> GELU -> fc2 (+ DropPath scale + residual) of a transformer block (models/volo.py:147-167, :233) in ONE
     launch, and the two input-gradient products of its backward pass in one launch.  Same K order and rounding points as the two ap_gemm_nt
     launches each replaces: hidden activation, gelu' codes, dL/dh and both outputs BIT-IDENTICAL to them (with and without DropPath factors), and
-    within bf16 tolerance of fp64.  (The kernel is slower than the launches it replaces -- DESIGN.md section 3 "Round 6" -- and off by default:
-    this test and the block test below keep it honest.)"""
+    within bf16 tolerance of fp64.  With ln=: the LayerNorm in front of fc1 inside the same launch -- normalised rows, mean, rstd and everything
+    behind them bit-identical to ap_layernorm_fwd followed by the launch above."""
     import torch.nn.functional as F
     if os.environ.get("AP_GEMM_8P", "1") == "0" or os.environ.get("AP_GELU_TABLE", "1") == "0":
         pytest.skip("bit equality is against the 8-phase kernel's table path")
@@ -343,6 +343,22 @@ def test_mlp_fused_is_the_two_launches_bit_for_bit(ops, M, drop):
     dhref = (dy[rows].double() @ w2.double()) * gp * (kk / 0.8 if drop else 1.0)
     assert rel(dh1[rows.cuda()], dhref) < TOL_BF16
     assert rel(dx1[rows.cuda()], dhref.to(torch.bfloat16).double() @ w1.double()) < TOL_BF16
+    # the LayerNorm in front of fc1 inside the launch (rows with a mean and a spread of their own; the residual is the LayerNorm's input, as in the block)
+    xin = dev((x.float() * (1.0 + torch.rand(M, 1, generator=g) * 3.0) + torch.randn(M, 1, generator=g) * 2.0).to(torch.bfloat16))
+    lg, lb = dev(1.0 + 0.3 * torch.randn(C, generator=g)), dev(0.2 * torch.randn(C, generator=g))
+    xn0, m0, r0 = ops.layernorm_fwd(xin, lg, lb, 1e-5)
+    y0, a0, c0 = ops.mlp_fused(xn0, dw1, dw2, bias1=db1, bias2=db2, row_scale_hidden=k2, row_scale_out=rs2, rows_per_scale=N, residual=xin)
+    got = ops.mlp_fused(None, dw1, dw2, bias1=db1, bias2=db2, row_scale_hidden=k2, row_scale_out=rs2, rows_per_scale=N, residual=xin, ln=(xin, lg, lb, 1e-5))
+    if os.environ.get("AP_MLP_FUSED_V") == "1":
+        assert got is None                      # the first structure has no LayerNorm: refused, the caller launches ap_layernorm_fwd
+        return
+    assert got is not None
+    y1, a1, c1, xn1, m1, r1 = got
+    assert torch.equal(xn0, xn1) and torch.equal(m0, m1) and torch.equal(r0, r1)
+    assert torch.equal(a0, a1) and torch.equal(c0, c1) and torch.equal(y0, y1)
+    xr = xin[rows.cuda()].cpu().double()
+    lnref = (xr - xr.mean(1, keepdim=True)) / (xr.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt() * lg.cpu().double() + lb.cpu().double()
+    assert rel(xn1[rows.cuda()], lnref) < TOL_BF16
     # launches outside what the kernel is built for are refused, not mis-computed
     assert ops.mlp_fused(dx_[:1000].contiguous(), dw1, dw2) is None
 
@@ -816,14 +832,14 @@ def test_grouped_wgrad_launch_carries_the_layernorm_reductions(ops):
                                  {"AP_STEM_HIP_CONV": "0"}, {"AP_ASYNC_WGRAD": "1"}, {"AP_GEMM_TN_PLACE": "0"}, {"AP_FUSE_LN_REDUCE": "0"}, {"AP_CONV_WGRAD_P": "0"},
                                  {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}, {"AP_GELU_STORE_GRAD": "0"}, {"AP_GELU_STORE_GRAD": "1"}, {"AP_LN_BWD_PF": "0"}, {"AP_GEMM_BM224": "0"}, {"AP_GEMM_WS": "0"}, {"AP_GELU_TABLE": "0"}, {"AP_FUSE_POOL_BWD": "0"}, {"AP_STEM_FUSE_BN_PROJ": "0"}, {"AP_STEM_FUSE_BN_BWD_STATS": "0"}, {"AP_BN_PROJ_ACT_IN_BWD": "0"}, {"AP_WGRAD_WINDOW": "0"}, {"AP_STEM_FUSE_BN": "0"},
                                  {"AP_OUTLOOK_P": "0"}, {"AP_OUTLOOK_P": "2"}, {"AP_LN_FWD_LP": "0"}, {"AP_CONV_WAVES": "4"},
-                                 {"AP_FUSED_MLP": "0"}, {"AP_FUSED_MLP": "2"}, {"AP_MLP_FUSED_V": "1"}])
+                                 {"AP_FUSED_MLP": "0"}, {"AP_FUSED_MLP": "2"}, {"AP_FUSED_MLP_LN": "0"}, {"AP_MLP_FUSED_V": "1"}])
 def test_experimental_kernel_paths_stay_parity_green(env):
     """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:
     re-run the GEMM / block tests in a child process with the switch set (the switches are read once per process)"""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     key = next(iter(env))
-    if key == "AP_FUSED_MLP":          # the transformer blocks' MLP as two launches per direction / fused in the forward only, inside the batch-128 training step
+    if key in ("AP_FUSED_MLP", "AP_FUSED_MLP_LN"):          # the transformer blocks' MLP as two launches per direction / fused in the forward only, inside the batch-128 training step
         sel, files = "slice_loss", ["tests/test_gpu_fullsize.py"]
     elif key == "AP_MLP_FUSED_V":      # the one-wave-per-SIMD version of that kernel: bit-identical to the two launches as well
         sel, files = "mlp_fused", ["tests/test_gpu_kernels.py"]
@@ -914,6 +930,28 @@ def test_c_abi_error_codes_and_empty_inputs(ops):
     assert lib.ap_mhsa_bwd(P(q), P(q), P(q), P(f), P(q), 1, 300, 1, 32, ctypes.c_float(0.1), None, 0, st) == -4   # blocked path without workspace
     assert lib.ap_mhsa_fwd(P(q), None, P(f), 2, 16, 1, 32, ctypes.c_float(0.1), None, st) == -4
     assert lib.ap_outlook_fwd(P(x), P(x), 88, P(x), 1, 8, 8, 1, 16, ctypes.c_float(0.25), st) == -2     # outlook head_dim != 32
+    # the fused MLP (ap_mlp_fused_args)
+    from autoprog_amd._lib import MlpFusedArgs
+    big = torch.zeros(128, 1152, dtype=torch.bfloat16, device="cuda")
+    byt = torch.zeros(128, 1152, dtype=torch.uint8, device="cuda")
+
+    def margs(**kw):
+        a = MlpFusedArgs()
+        a.x, a.ldx, a.wa, a.ldwa, a.wb, a.ldwb, a.out, a.ldo = P(big), 384, P(big), 384, P(big), 1152, P(big), 384
+        a.hidden_out, a.ldh, a.codes, a.rows_per_scale, a.m, a.c, a.hidden, a.backward = P(big), 1152, P(byt), 1, 128, 384, 1152, 0
+        for k_, v_ in kw.items():
+            setattr(a, k_, v_)
+        return ctypes.byref(a)
+    assert lib.ap_mlp_fused(None, st) == -4
+    assert lib.ap_mlp_fused(margs(x=None), st) == -4                                               # no rows and no LayerNorm input
+    assert lib.ap_mlp_fused(margs(ldwb=384), st) == -1                                             # ldwb < hidden
+    assert lib.ap_mlp_fused(margs(c=256, hidden=768), st) == -2                                    # built for c = 384
+    assert lib.ap_mlp_fused(margs(m=100), st) == -2                                                # whole 128-row blocks
+    assert lib.ap_mlp_fused(margs(backward=1, bias1=P(f)), st) == -1                               # the backward launch takes no bias
+    assert lib.ap_mlp_fused(margs(x=None, ln_in=P(big), ld_ln=384), st) == -4                      # LayerNorm without its outputs / parameters
+    lnk = dict(x=None, ln_in=P(big), ld_ln=384, ln_out=P(big), ld_lno=384, ln_gamma=P(f), ln_beta=P(f), ln_eps=1e-5, ln_mean=P(f), ln_rstd=P(f))
+    assert lib.ap_mlp_fused(margs(backward=1, **lnk), st) == -1                                    # the LayerNorm belongs to the forward launch
+    assert lib.ap_mlp_fused(margs(**dict(lnk, ld_ln=380)), st) == -1
     torch.cuda.synchronize()                                                                          # nothing above may have faulted
 
 

@@ -61,6 +61,18 @@ def main():
         print("backward drop=%d: dh equal %s (max diff %.3g), dx equal %s (max diff %.3g, rel %.2e)" % (
             drop, torch.equal(dh0, dh1), (dh0.float() - dh1.float()).abs().max().item(), torch.equal(dx0, dx1),
             (dx0.float() - dx1.float()).abs().max().item(), ((dx0.float() - dx1.float()).norm() / dx0.float().norm()).item()))
+    # the LayerNorm in front of fc1 inside the launch: against layernorm_fwd + the fused launch, bit for bit
+    lg = rnd(C, scale=0.3) + 1.0; lb = rnd(C, scale=0.2)
+    xin = (rnd(M, C) * (1.0 + rnd(M, 1).abs()) + rnd(M, 1)).bfloat16()
+    xn0, m0_, r0_ = ops.layernorm_fwd(xin, lg, lb, 1e-5)
+    yl0, al0, hl0 = ops.mlp_fused(xn0, w1, w2, bias1=b1, bias2=b2, row_scale_hidden=keep, row_scale_out=rs2, rows_per_scale=N, residual=xin)
+    r = ops.mlp_fused(None, w1, w2, bias1=b1, bias2=b2, row_scale_hidden=keep, row_scale_out=rs2, rows_per_scale=N, residual=xin, ln=(xin, lg, lb, 1e-5))
+    assert r is not None, "ap_mlp_fused refused the LayerNorm launch"
+    yl1, al1, hl1, xn1, m1_, r1_ = r
+    torch.cuda.synchronize()
+    print("forward with LayerNorm: rows equal %s (max diff %.3g), mean equal %s (%.3g), rstd equal %s (%.3g), a equal %s, codes equal %s, out equal %s" % (
+        torch.equal(xn0, xn1), (xn0.float() - xn1.float()).abs().max().item(), torch.equal(m0_, m1_), (m0_ - m1_).abs().max().item(),
+        torch.equal(r0_, r1_), ((r0_ - r1_).abs() / r0_).max().item(), torch.equal(al0, al1), torch.equal(hl0, hl1), torch.equal(yl0, yl1)))
     # fp64 reference on a few rows (independent of the unfused kernels)
     rows = torch.randint(0, M, (64,), generator=g).to(dev)
     xr = xs[0][rows].double()
@@ -84,6 +96,13 @@ def main():
     print("rows %d: fused forward   %.1f us (best %.1f) | unfused %.1f us (best %.1f)" % (
         (M,) + timeit(lambda i: ops.mlp_fused(xs[i % R], w1, w2, bias1=b1, bias2=b2, row_scale_hidden=keep, row_scale_out=rs2, rows_per_scale=N, residual=ress[i % R]))
         + timeit(lambda i: unfused_fwd(xs[i % R], w1, b1, w2, b2, keep, rs2, N, ress[i % R]))))
+    def ln_then_fused(i):
+        xn, _, _ = ops.layernorm_fwd(xs[i % R], lg, lb, 1e-5)
+        return ops.mlp_fused(xn, w1, w2, bias1=b1, bias2=b2, row_scale_hidden=keep, row_scale_out=rs2, rows_per_scale=N, residual=xs[i % R])
+    print("rows %d: fused forward with LayerNorm %.1f us (best %.1f) | layernorm_fwd + fused %.1f us (best %.1f)" % (
+        (M,) + timeit(lambda i: ops.mlp_fused(None, w1, w2, bias1=b1, bias2=b2, row_scale_hidden=keep, row_scale_out=rs2, rows_per_scale=N, residual=xs[i % R],
+                                              ln=(xs[i % R], lg, lb, 1e-5)))
+        + timeit(ln_then_fused)))
     print("rows %d: fused backward  %.1f us (best %.1f) | unfused %.1f us (best %.1f)" % (
         (M,) + timeit(lambda i: ops.mlp_fused(xs[i % R], w2t, w1t, backward=True, codes=codes, row_scale_hidden=rs2, rows_per_scale=N))
         + timeit(lambda i: unfused_bwd(xs[i % R], w2t, w1t, codes, rs2, N))))
