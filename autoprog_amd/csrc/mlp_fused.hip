@@ -482,9 +482,11 @@ __device__ __forceinline__ void mf_tab_addr2(unsigned w, unsigned& a0, unsigned&
     a1 = idx4 >> 16;
 }
 
-template <int C, bool BWD, bool LN = false>
+// RES: the forward launch adds a residual (a.res != nullptr).  A template parameter, not a branch: with both epilogues in one kernel hipcc spilled
+// accumulator quadruples where the two paths join and reloaded them -- each reload behind an s_waitcnt vmcnt(0) -- in the middle of the pipelined epilogue.
+template <int C, bool BWD, bool LN = false, bool RES = false>
 __global__ void __launch_bounds__(512, 2) k_mlp_fused2(MlpArgs a) {
-    static_assert(!(BWD && LN), "the LayerNorm in front of fc1 belongs to the forward launch");
+    static_assert(!(BWD && (LN || RES)), "the LayerNorm in front of fc1 and the residual belong to the forward launch");
     static_assert(C == 384, "version 2 is written for C = 384 (six pieces per phase, two slots per phase)");
     constexpr int PP = C / 64, NCH = 3 * C / 64, KS = C / 32, NT2 = C / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
@@ -956,10 +958,9 @@ __global__ void __launch_bounds__(512, 2) k_mlp_fused2(MlpArgs a) {
         st16_nt(a.Out + row * a.ldo + col, pack8(v));
     };
     constexpr int NCK = 2 * (C / 32);
-    bool piped = false;
-    if constexpr (!BWD) {
-        if (a.res) {
-            piped = true;
+    constexpr bool piped = !BWD && RES;
+    if constexpr (piped) {
+        {
             mf_vmcnt<0>();                         // (what is left of this wave's DMA: nothing is read from the ring any more, but the counts below start at zero)
             u32x4 rb[3] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
             auto rload = [&](u32x4& d, int c) {
@@ -989,7 +990,7 @@ __global__ void __launch_bounds__(512, 2) k_mlp_fused2(MlpArgs a) {
             });
         }
     }
-    if (!piped) {
+    if constexpr (!piped) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1018,19 +1019,19 @@ const unsigned* g8_gelu_table_ptr(hipStream_t st) {
 }
 #endif
 
-template <int C, bool BWD, bool LN = false>
+template <int C, bool BWD, bool LN = false, bool RES = false>
 static int mf_launch(const MlpArgs& a, hipStream_t st) {
     static int version = 0;                  // AP_MLP_FUSED_V = 1: the one-wave-per-SIMD kernel; default 2: producer / consumer waves
     if (!version) { const char* e = getenv("AP_MLP_FUSED_V"); version = (e && e[0] == '1') ? 1 : 2; }
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)k_mlp_fused<C, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)k_mlp_fused2<C, BWD, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, M2_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)k_mlp_fused2<C, BWD, LN, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, M2_LDS_BYTES);
         attr = true; (void)hipGetLastError();
     }
     if (version == 1 && LN) return AP_ERR_UNSUPPORTED;
     if (version == 1) hipLaunchKernelGGL((k_mlp_fused<C, BWD>), dim3(a.M / MF_BM), dim3(256), MF_LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((k_mlp_fused2<C, BWD, LN>), dim3(a.M / MF_BM), dim3(512), M2_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((k_mlp_fused2<C, BWD, LN, RES>), dim3(a.M / MF_BM), dim3(512), M2_LDS_BYTES, st, a);
     return ap_check_launch();
 }
 
@@ -1066,7 +1067,8 @@ int ap_mlp_fused(const ap_mlp_fused_args* p, ap_stream_t stream) {
     if (!p->backward) {
         a.gelu_tab = g8_gelu_table_ptr(st);
         if (!a.gelu_tab) return AP_ERR_UNSUPPORTED;            // (AP_GELU_TABLE=0, or a capture in front of the table's first build)
-        return ln ? mf_launch<384, false, true>(a, st) : mf_launch<384, false>(a, st);
+        if (a.res) return ln ? mf_launch<384, false, true, true>(a, st) : mf_launch<384, false, false, true>(a, st);
+        return ln ? mf_launch<384, false, true, false>(a, st) : mf_launch<384, false, false, false>(a, st);
     }
     return mf_launch<384, true>(a, st);
 }
