@@ -381,6 +381,10 @@ FUSED_MLP = int(os.environ.get("AP_FUSED_MLP", "1") or 0)
 FUSED_MLP_BWD = FUSED_MLP == 1
 # AP_FUSED_MLP_LN=1: the LayerNorm in front of fc1 inside the fused forward launch (bit-identical to ap_layernorm_fwd; one launch less per block)
 FUSED_MLP_LN = os.environ.get("AP_FUSED_MLP_LN", "1") == "1"
+# The fused launch runs ONE 128-row block per CU, so its time does not shrink with the row count while the launches it replaces do: measured from
+# graphs on one box, 8192 rows (stage (9, 128 px), 64 workgroups) 4.08 -> 4.23 ms per step with it, 12800 rows 6.13 -> 6.24, 18432 rows 8.95 -> 8.87,
+# 25088 rows 12.20 -> 11.96 (profiles/r06_mlp_fused.txt).  Below this many rows the block keeps the two launches.
+FUSED_MLP_MIN_ROWS = int(os.environ.get("AP_FUSED_MLP_MIN_ROWS", "18432"))
 
 
 def _gelu_bwd_kw(h):
@@ -650,7 +654,7 @@ class TransformerBlockFn(torch.autograd.Function):
             o, lse = ops.mhsa_fwd(qkv, B, N, heads, scale, out_row_scale=k1)                   # rows of dropped samples: zeros
         x1 = _linear_fwd(o, proj_w, x8=oq, bias=proj_b, row_scale=rs1, rows_per_scale=N, residual=x2)
         fused = None
-        use_fused = FUSED_MLP and STORE_GELU_GRAD == 2 and not FP8_LINEAR and ops.mlp_fused_ok(B * N, C, fc1_w.shape[0])
+        use_fused = FUSED_MLP and STORE_GELU_GRAD == 2 and not FP8_LINEAR and B * N >= FUSED_MLP_MIN_ROWS and ops.mlp_fused_ok(B * N, C, fc1_w.shape[0])
         if use_fused and FUSED_MLP_LN:
             # LN2 -> fc1 -> GELU -> fc2 (+ DropPath scale + residual) in ONE launch (csrc/mlp_fused.hip): bit-identical to the three launches
             fused = ops.mlp_fused(None, bank.get(fc1_w), bank.get(fc2_w), bias1=fc1_b, bias2=fc2_b, row_scale_hidden=k2, row_scale_out=rs2,
@@ -703,7 +707,8 @@ class TransformerBlockFn(torch.autograd.Function):
                     dh8 = fp8_scales.quantize(("g", id(fc1_w)), dh)
             else:
                 fused = None
-                if FUSED_MLP and FUSED_MLP_BWD and h.dtype == torch.uint8 and ops.mlp_fused_ok(dy2.shape[0], dy2.shape[1], h.shape[1]):
+                if (FUSED_MLP and FUSED_MLP_BWD and h.dtype == torch.uint8 and dy2.shape[0] >= FUSED_MLP_MIN_ROWS
+                        and ops.mlp_fused_ok(dy2.shape[0], dy2.shape[1], h.shape[1])):
                     # both input-gradient products of the MLP in one launch; the weight gradients read dL/dh and dL/dy as before
                     fused = ops.mlp_fused(dy2, bank.get_t(fc2_w), bank.get_t(fc1_w), backward=True, codes=h, row_scale_hidden=rs2, rows_per_scale=N)
                 if fused is not None:
