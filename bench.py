@@ -183,6 +183,7 @@ class GemmProbe:
         self.fp8_launches = 0
         self.fp8_flops = 0.0
         self.fused_launches = 0
+        self.fused_hidden_bytes = 0.0
 
     def install(self):
         from autoprog_amd import ops
@@ -247,6 +248,7 @@ class GemmProbe:
             if kw.get("ln") is not None:       # the residual rows ARE the LayerNorm's input (read once); the normalised rows leave for the weight gradient
                 probe.bytes += 2.0 * M * C - (2.0 * M * C if kw.get("residual") is not None and kw["residual"].data_ptr() == rows.data_ptr() else 0.0) + 2.0 * M * C
             probe.fused_launches += 1
+            probe.fused_hidden_bytes += 2.0 * M * Hd          # what the second of the two replaced launches would have read back
             return out
         ops.mlp_fused = timedm
 
@@ -684,6 +686,9 @@ def main():
                     "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / peak_mfma, 4), "mfma_peak_tflops": round(peak_mfma, 1),
                     "fp8_flop_share": round(probe.fp8_flops / flops, 4) if flops else 0.0,
                     "hbm_tbs_algorithmic": round(tbs, 3), "hbm_frac": round(tbs / PEAK_HBM_TBS, 4),
+                    # for comparison with rounds 1 - 5, whose family had no fused launches: the same time priced against the bytes of the launches
+                    # the fused ones replace (+ the hidden tensor's read-back per fused launch)
+                    "hbm_frac_two_launch_accounting": round((probe.bytes + probe.fused_hidden_bytes) / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4),
                     "algorithmic_bytes_per_launch": round(probe.bytes / max(launches, 1)),
                     "launches_per_step": launches // nprobe, "fp8_launches_per_step": probe.fp8_launches // nprobe,
                     "fused_mlp_launches_per_step": probe.fused_launches // nprobe, "avg_launch_us": round(ms * 1e3 / launches, 2),
