@@ -80,4 +80,10 @@ for i in range(steps):
         gn = float(red.flat.norm()) * red.grad_scale
         out.append("%d:%.4f(g%.2e,%.2fGB)" % (i, float(loss), gn, torch.cuda.memory_allocated() / 2 ** 30))
 print(" ".join(out))
+# every parameter after the last step, as one hash: two runs that print the same hash took the same steps bit for bit (tools/soak_fused_pair.sh)
+import hashlib
+hsh = hashlib.sha256()
+for n_, p_ in sorted(model.named_parameters()):
+    hsh.update(p_.detach().float().cpu().numpy().tobytes())
+print("parameters sha256 %s" % hsh.hexdigest()[:32])
 print("peak allocated %.2f GB, reserved %.2f GB" % (torch.cuda.max_memory_allocated() / 2 ** 30, torch.cuda.memory_reserved() / 2 ** 30))
