@@ -296,7 +296,6 @@ def test_transformer_block_with_the_fused_mlp_is_the_block_bit_for_bit(monkeypat
     from autoprog_amd import functional as AF, ops
     from autoprog_amd.models import volo as V
     monkeypatch.setattr(ops, "deterministic", True)
-    monkeypatch.setattr(AF, "FUSED_MLP_MIN_ROWS", 0)          # (the block below has 6272 rows; by default blocks under 18432 rows keep the two launches)
     calls = []
     real = ops.mlp_fused
 
@@ -310,6 +309,10 @@ def test_transformer_block_with_the_fused_mlp_is_the_block_bit_for_bit(monkeypat
     g = torch.Generator().manual_seed(32)
     x = torch.randn(32, 14, 14, 384, generator=g).to(torch.bfloat16).cuda()
     dy = torch.randn(32, 14, 14, 384, generator=g).to(torch.bfloat16).cuda()
+    # the block below has 6272 rows: by default (functional.FUSED_MLP_MIN_ROWS = 18432: one 128-row block per CU does not pay on fewer) it keeps the two launches
+    blk(x.clone().requires_grad_(True)).backward(dy)
+    assert calls == [], calls
+    monkeypatch.setattr(AF, "FUSED_MLP_MIN_ROWS", 0)
     outs = {}
     lns = []
     real_ln = ops.layernorm_fwd

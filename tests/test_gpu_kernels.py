@@ -832,14 +832,16 @@ def test_grouped_wgrad_launch_carries_the_layernorm_reductions(ops):
                                  {"AP_STEM_HIP_CONV": "0"}, {"AP_ASYNC_WGRAD": "1"}, {"AP_GEMM_TN_PLACE": "0"}, {"AP_FUSE_LN_REDUCE": "0"}, {"AP_CONV_WGRAD_P": "0"},
                                  {"AP_GEMM_8P": "0"}, {"AP_GEMM_8P": "2"}, {"AP_GEMM_TN_8P": "0"}, {"AP_GELU_STORE_GRAD": "0"}, {"AP_GELU_STORE_GRAD": "1"}, {"AP_LN_BWD_PF": "0"}, {"AP_GEMM_BM224": "0"}, {"AP_GEMM_WS": "0"}, {"AP_GELU_TABLE": "0"}, {"AP_FUSE_POOL_BWD": "0"}, {"AP_STEM_FUSE_BN_PROJ": "0"}, {"AP_STEM_FUSE_BN_BWD_STATS": "0"}, {"AP_BN_PROJ_ACT_IN_BWD": "0"}, {"AP_WGRAD_WINDOW": "0"}, {"AP_STEM_FUSE_BN": "0"},
                                  {"AP_OUTLOOK_P": "0"}, {"AP_OUTLOOK_P": "2"}, {"AP_LN_FWD_LP": "0"}, {"AP_CONV_WAVES": "4"},
-                                 {"AP_FUSED_MLP": "0"}, {"AP_FUSED_MLP": "2"}, {"AP_FUSED_MLP_LN": "0"}, {"AP_MLP_FUSED_V": "1"}])
+                                 {"AP_FUSED_MLP": "0"}, {"AP_FUSED_MLP": "2"}, {"AP_FUSED_MLP_LN": "0"}, {"AP_FUSED_MLP_MIN_ROWS": "0"}, {"AP_MLP_FUSED_V": "1"}])
 def test_experimental_kernel_paths_stay_parity_green(env):
     """the kernels kept behind environment switches (DESIGN.md 'What bounds the GEMMs') must keep computing the same thing:
     re-run the GEMM / block tests in a child process with the switch set (the switches are read once per process)"""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     key = next(iter(env))
-    if key in ("AP_FUSED_MLP", "AP_FUSED_MLP_LN"):          # the transformer blocks' MLP as two launches per direction / fused in the forward only, inside the batch-128 training step
+    if key == "AP_FUSED_MLP_MIN_ROWS":     # the fused MLP in blocks of every size it takes: the batch-8 stage (9, 128 px) has 512 rows per block
+        sel, files = "test_d1_train_step_loss_and_every_gradient_vs_oracle", ["tests/test_gpu_fullsize.py"]
+    elif key in ("AP_FUSED_MLP", "AP_FUSED_MLP_LN"):          # the transformer blocks' MLP as two launches per direction / fused in the forward only, inside the batch-128 training step
         sel, files = "slice_loss", ["tests/test_gpu_fullsize.py"]
     elif key == "AP_MLP_FUSED_V":      # the one-wave-per-SIMD version of that kernel: bit-identical to the two launches as well
         sel, files = "mlp_fused", ["tests/test_gpu_kernels.py"]
