@@ -15,7 +15,7 @@ from autoprog_amd._lib import MlpFusedArgs  # noqa: E402
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 25088
     bwd = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    lib = ctypes.CDLL(os.path.join(ROOT, "tools", "mlp_lab", "libmlp_abl0.so"))
+    lib = ctypes.CDLL(os.path.join(ROOT, "tools", "mlp_lab", os.environ.get("MF_LAB_LIB", "libmlp_abl0.so")))
     lib.ap_mlp_fused.restype = ctypes.c_int
     lib.ap_mlp_fused.argtypes = [ctypes.POINTER(MlpFusedArgs), ctypes.c_void_p]
     C, H = 384, 1152
