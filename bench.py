@@ -341,6 +341,30 @@ def self_launch(n, argv):
     return subprocess.call(cmd, env=env)
 
 
+def prewarm(step, seconds, sync, all_max=None):
+    """>= `seconds` of step() in groups of eight -> (steps, seconds).  With more than one rank the steps contain collectives, so EVERY rank has
+    to stop after the same group: the clock that decides is the maximum over the ranks (all_max), not the rank's own -- a rank that left the
+    loop a group early would leave the others waiting in an all-reduce nobody answers (tests/test_dist_gloo.py runs two ranks of unequal speed)."""
+    t0, n = time.perf_counter(), 0
+    while True:
+        for _ in range(8):
+            step()
+        n += 8
+        sync()
+        el = time.perf_counter() - t0
+        if all_max is not None:
+            el = all_max(el)
+        if el >= seconds:
+            return n, el
+
+
+def all_ranks_max(value, device):
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def launch_check(world, rank):
     """--launch-check: the rendezvous + gradient-exchange plumbing of an N-rank run without the HIP path (CPU, gloo): every rank
     reduces a slab through GradientBucketReducer and rank 0 prints what it saw.  The product path itself has no CPU mode."""
@@ -573,15 +597,8 @@ def main():
     # ---- disclosed pre-warm: >= --prewarm-s seconds of the same step (untimed, reported), then the box calibration, then the counted warm-up
     prewarm_steps, prewarm_s = 0, 0.0
     if args.prewarm_s > 0:
-        tp = time.perf_counter()
-        while True:
-            for _ in range(8):
-                step()
-            prewarm_steps += 8
-            torch.cuda.synchronize()
-            prewarm_s = time.perf_counter() - tp
-            if prewarm_s >= args.prewarm_s:
-                break
+        prewarm_steps, prewarm_s = prewarm(step, args.prewarm_s, torch.cuda.synchronize,
+                                           (lambda t: all_ranks_max(t, dev)) if world > 1 else None)
         if args.workload == "stages":
             counter[0] = 0                       # (the stage walk of the timed region starts where it always did)
             if args.graph:

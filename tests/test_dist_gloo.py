@@ -547,3 +547,46 @@ def test_elastic_skip_accumulation_and_window_world_size_8():
     # buckets without a skipped member left during the backward pass of the last micro-batch, the other two in finish(): same order everywhere
     assert all(o == orders[0] for o in orders), orders
     assert orders[0][0] == [0, 3, 4] and sorted(orders[0][1]) == [0, 1, 2, 3, 4] and orders[0][1][:3] == [0, 3, 4], orders[0]
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# bench.py's timed pre-warm on more than one rank
+def _prewarm_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        import time
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        buf = torch.zeros(4)
+        steps = [0]
+
+        def step():                                # a "training step": rank-dependent host time, then the gradient exchange
+            time.sleep(0.004 if rank == 0 else 0.009)
+            dist.all_reduce(buf)
+            steps[0] += 1
+        n, secs = bench.prewarm(step, 0.25, lambda: None, lambda t: bench.all_ranks_max(t, "cpu"))
+        dist.barrier()                             # every collective above has found its partner: nobody is left inside an all-reduce
+        q.put((rank, n, steps[0], secs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_prewarm_stops_every_rank_after_the_same_step_world_size_2():
+    """bench.py runs >= --prewarm-s seconds of the step in front of the counted warm-up.  The steps of an N-rank run contain collectives, so the
+    ranks must leave that loop after the SAME number of steps although their clocks differ: the deciding clock is the maximum over the ranks
+    (bench.prewarm / all_ranks_max).  Two gloo ranks whose steps take 4 and 9 ms of host time: equal step counts, no rank left waiting."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_prewarm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, s0, t0), (_, n1, s1, t1) = res
+    assert n0 == n1 == s0 == s1 and n0 % 8 == 0 and n0 >= 8
+    assert t0 == t1 and t0 >= 0.25               # the same (maximum) clock on both ranks
