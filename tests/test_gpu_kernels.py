@@ -300,7 +300,7 @@ def test_eight_bit_gelu_derivative_against_the_exact_derivative(ops):
     assert e < 4e-3, e
 
 
-@pytest.mark.parametrize("M,drop", [(6272, False), (6272, True), (25088, True)])
+@pytest.mark.parametrize("M,drop", [(128, True), (1152, False), (6272, False), (6272, True), (25088, True)])
 def test_mlp_fused_is_the_two_launches_bit_for_bit(ops, M, drop):
     """round 6: csrc/mlp_fused.hip -- fc1 -> GELU -> fc2 (+ DropPath scale + residual) of a transformer block (models/volo.py:147-167, :233) in ONE
     launch, and the two input-gradient products of its backward pass in one launch.  Same K order and rounding points as the two ap_gemm_nt
@@ -310,12 +310,15 @@ def test_mlp_fused_is_the_two_launches_bit_for_bit(ops, M, drop):
     import torch.nn.functional as F
     if os.environ.get("AP_GEMM_8P", "1") == "0" or os.environ.get("AP_GELU_TABLE", "1") == "0":
         pytest.skip("bit equality is against the 8-phase kernel's table path")
-    C, H, N = 384, 1152, 196
+    C, H, N = 384, 1152, (196 if M >= 196 else 64)
+    # bit equality is against the 8-phase kernel; launches of fewer than 4096 rows go to other ap_gemm_nt kernels (another summation order, the GELU
+    # evaluated instead of looked up): the fused launch of a single block / of nine blocks is checked against fp64 alone
+    bit = M >= 4096
     x, w1, w2 = rnd(M, C, seed=1), rnd(H, C, scale=C ** -0.5, seed=2), rnd(C, H, scale=H ** -0.5, seed=3)
     g = torch.Generator().manual_seed(4)
     b1, b2 = torch.randn(H, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
     res, dy = rnd(M, C, seed=5), rnd(M, C, seed=6)
-    keep = (torch.rand(M // N, generator=g) < 0.8).float()
+    keep = (torch.rand((M + N - 1) // N, generator=g) < 0.8).float()
     k2, rs2 = (dev(keep), dev(keep / 0.8)) if drop else (None, None)
     dx_, dw1, dw2, db1, db2, dres, ddy = dev(x), dev(w1), dev(w2), dev(b1), dev(b2), dev(res), dev(dy)
     # forward
@@ -325,7 +328,9 @@ def test_mlp_fused_is_the_two_launches_bit_for_bit(ops, M, drop):
     got = ops.mlp_fused(dx_, dw1, dw2, bias1=db1, bias2=db2, row_scale_hidden=k2, row_scale_out=rs2, rows_per_scale=N, residual=dres)
     assert got is not None, "ap_mlp_fused refused a launch it is built for"
     y1, a1, codes1 = got
-    assert torch.equal(a0, a1) and torch.equal(codes0, codes1) and torch.equal(y0, y1)
+    assert not bit or (torch.equal(a0, a1) and torch.equal(codes0, codes1) and torch.equal(y0, y1))
+    if not bit:
+        codes0 = codes1                          # (the backward below reads the fused forward's own codes)
     rows = torch.arange(0, M, 37)
     h = (x[rows].double() @ w1.double().t() + b1.double()).to(torch.bfloat16).double()
     kk = keep[rows // N].double()[:, None] if drop else 1.0
@@ -338,7 +343,7 @@ def test_mlp_fused_is_the_two_launches_bit_for_bit(ops, M, drop):
     dh0 = ops.gemm_nt(ddy, w2t, mul_by=codes0, row_scale=rs2, rows_per_scale=N)
     dx0 = ops.gemm_nt(dh0, w1t)
     dx1, dh1, _ = ops.mlp_fused(ddy, w2t, w1t, backward=True, codes=codes0, row_scale_hidden=rs2, rows_per_scale=N)
-    assert torch.equal(dh0, dh1) and torch.equal(dx0, dx1)
+    assert not bit or (torch.equal(dh0, dh1) and torch.equal(dx0, dx1))
     gp = (codes0[rows.cuda()].cpu().double() - ops.GELU_CODE_ZERO) / ops.GELU_CODE_SCALE
     dhref = (dy[rows].double() @ w2.double()) * gp * (kk / 0.8 if drop else 1.0)
     assert rel(dh1[rows.cuda()], dhref) < TOL_BF16
@@ -360,7 +365,7 @@ def test_mlp_fused_is_the_two_launches_bit_for_bit(ops, M, drop):
     lnref = (xr - xr.mean(1, keepdim=True)) / (xr.var(1, unbiased=False, keepdim=True) + 1e-5).sqrt() * lg.cpu().double() + lb.cpu().double()
     assert rel(xn1[rows.cuda()], lnref) < TOL_BF16
     # launches outside what the kernel is built for are refused, not mis-computed
-    assert ops.mlp_fused(dx_[:1000].contiguous(), dw1, dw2) is None
+    assert ops.mlp_fused(dev(rnd(1000, C, seed=9)), dw1, dw2) is None
 
 
 @pytest.mark.parametrize("M,N1,N2", [(1024, 128, 128), (1000, 192, 576), (3000, 486, 192), (25088 // 8, 1152, 384), (130, 1000, 384),
